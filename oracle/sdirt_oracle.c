@@ -1,0 +1,668 @@
+/*
+ * sdirt_oracle.c -- CPU restatement of the Sdirt dual-pixel PSF hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This file is the parity oracle: only tests/,
+ * __graft_entry__.smoke() and the cpu_baseline leg of bench.py may load it.
+ * The product (sdirt_amd/, libsdirt_dp.so) never links, loads or calls it.
+ *
+ * It restates, operation for operation and in the same fp32 evaluation order,
+ * what the reference (LinYark/Sdirt, pure PyTorch, CPU path) computes:
+ *
+ *   or_points_to_object   deeplens/optics.py:956-960, 1302-1306
+ *   or_pupil_samples      deeplens/optics.py:482-488
+ *   or_sample_rays        deeplens/optics.py:479,490-494 + basics.py:245
+ *   or_trace              deeplens/optics.py:601-627,666-689 (loop over surfaces)
+ *     surface_reaction    deeplens/surfaces.py:391-520
+ *     newton              deeplens/surfaces.py:523-586 (GLOBAL trip count, :547)
+ *     sag_g / sag_dgd     deeplens/surfaces.py:787-830, 688-743
+ *     refract / normal    deeplens/surfaces.py:633-679, 589-630
+ *   or_propagate_to       deeplens/basics.py:256-274
+ *   or_psf_center         deeplens/optics.py:889-904
+ *   or_forward_integral   deeplens/monte_carlo.py:9-68
+ *     splat_small_r/big_r deeplens/monte_carlo.py:135-240, 242-372
+ *   or_psf_normalize      deeplens/optics.py:983-987
+ *   or_psf                deeplens/optics.py:934-996 (everything chained)
+ *
+ * Parity pinning: checked against the golden fixtures in tests/golden/
+ * (generated from the real reference by oracle/gen_golden.py) by
+ * tests/test_oracle_golden.py -- ray states after every surface are BIT-EXACT
+ * for sphere/plane surfaces, Newton trip counts are equal, and the documented
+ * non-bit-exact items are: (a) r2**4..6 in the asphere polynomials (torch uses
+ * Sleef pow, <=1 ulp; here: double product rounded once), (b) sin/cos/acos
+ * (Sleef vs libm, <=1 ulp), (c) the reduction order of torch.sum over the spp
+ * axis (chief-ray centre; machine dependent in torch -- here: double
+ * accumulation).
+ *
+ * Layout: torch's own -- o,d as [S][N][3] (AoS last dim), ra/obliq as [S][N].
+ * Build: gcc -O2 -ffp-contract=off -fno-fast-math (see oracle/Makefile).
+ * All arithmetic is IEEE binary32 unless a `double` appears explicitly; doubles
+ * appear exactly where the reference holds a Python/numpy float64 scalar that
+ * torch rounds to fp32 at the point of use.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define OR_PLANE 0
+#define OR_SPHERE 1
+#define OR_ASPHERE 2
+
+#define NEWTONS_MAXITER 10          /* surfaces.py:26 */
+#define NEWTONS_TOL_TIGHT 10e-6     /* surfaces.py:27 */
+#define NEWTONS_TOL_LOOSE 50e-6     /* surfaces.py:28 */
+#define NEWTONS_STEP_BOUND 5.0f     /* surfaces.py:29 */
+#define EPSILON_D 1e-9              /* basics.py:35 */
+#define MAXT_F 1e5f                 /* basics.py:33 */
+
+typedef struct {
+    int32_t kind;        /* OR_PLANE / OR_SPHERE / OR_ASPHERE (surfaces.py:409,456,491) */
+    int32_t ai_degree;   /* 0 or number of even-asphere terms (surfaces.py:306-328) */
+    float r;             /* semi-aperture, python float in the reference */
+    float d;             /* vertex z, fp32 tensor */
+    float c;             /* curvature, fp32 tensor */
+    float k;             /* conic, fp32 tensor */
+    float ai[8];         /* ai2, ai4, ... fp32 tensors */
+    double r_d;          /* r as the python double it is (r**2 is squared in double) */
+    double n1, n2;       /* Material.ior(wvln) before/after, float64 (basics.py:316-340) */
+} or_surface;
+
+/* ------------------------------------------------------------------------ */
+/* small helpers                                                             */
+/* ------------------------------------------------------------------------ */
+static inline float clampf(float v, float lo, float hi)
+{
+    /* torch.clamp: min(max(v, lo), hi); NaN propagates */
+    if (v != v) return v;
+    v = v < lo ? lo : v;
+    v = v > hi ? hi : v;
+    return v;
+}
+
+/* torch.nn.functional.normalize on the last dim of size 3 (basics.py:245,
+ * surfaces.py:628): v / max(||v||, 1e-12).  torch's CPU norm kernel for a
+ * contiguous innermost dim accumulates with fused multiply-adds
+ * (acc = fma(v,v,acc), x then y then z) and takes one sqrt; measured 100 %
+ * bit-equal against torch 2.10 at one thread. */
+static inline void normalize3(float* x, float* y, float* z)
+{
+    float acc = (*x) * (*x);
+    acc = fmaf(*y, *y, acc);
+    acc = fmaf(*z, *z, acc);
+    float nrm = sqrtf(acc);
+    if (nrm < 1e-12f) nrm = 1e-12f;
+    *x = *x / nrm;
+    *y = *y / nrm;
+    *z = *z / nrm;
+}
+
+/* r2 ** n as torch evaluates it on CPU: n==2 -> x*x, n==3 -> (x*x)*x, otherwise
+ * a <=1-ulp vector pow.  For n>=4 we use the correctly rounded value of the
+ * exact power (product in double, rounded once). */
+static inline float powi(float x, int n)
+{
+    if (n == 1) return x;
+    if (n == 2) return x * x;
+    if (n == 3) return (x * x) * x;
+    double p = (double)x;
+    double acc = p;
+    for (int i = 1; i < n; ++i) acc *= p;
+    return (float)acc;
+}
+
+/* surfaces.py:787-808  _g(r2) */
+static inline float sag_g(const or_surface* s, float r2, float onepk, float c2)
+{
+    float sf = sqrtf(1.0f - (onepk * r2) * c2);
+    float total = (r2 * s->c) / (1.0f + sf);
+    for (int i = 0; i < s->ai_degree; ++i)
+        total = total + s->ai[i] * powi(r2, i + 1);
+    return total;
+}
+
+/* surfaces.py:811-830  _dgd(r2) */
+static inline float sag_dgd(const or_surface* s, float r2, float onepk, float c2)
+{
+    float a = (onepk * r2) * c2;
+    float sf = sqrtf(1.0f - a);
+    float onesf = 1.0f + sf;
+    float dsdr2 = ((onesf + (a / 2.0f) / sf) * s->c) / (onesf * onesf);
+    if (s->ai_degree > 0) {
+        dsdr2 = dsdr2 + s->ai[0];
+        for (int i = 1; i < s->ai_degree; ++i)
+            dsdr2 = dsdr2 + (((float)(i + 1)) * s->ai[i]) * powi(r2, i);
+    }
+    return dsdr2;
+}
+
+/* thresholds shared by _valid / _valid_loose (surfaces.py:724-743):
+ * (1-EPSILON)/c**2/(1+k) is evaluated by torch as reciprocal(c*c) * fp32(1-1e-9)
+ * / (1+k)  (python_float / tensor == tensor.reciprocal() * python_float). */
+static inline float loose_limit(const or_surface* s, float onepk, float c2)
+{
+    float rc = 1.0f / c2;
+    rc = rc * (float)(1.0 - EPSILON_D);
+    return rc / onepk;
+}
+
+/* ------------------------------------------------------------------------ */
+/* Newton intersection, reference batch semantics (surfaces.py:523-586)      */
+/* ------------------------------------------------------------------------ */
+typedef struct {
+    int trips_forced;    /* >=0: run exactly this many loop trips; <0: reference rule */
+    int trips_out;       /* trips actually run */
+} newton_ctl;
+
+static void newton(const or_surface* s, int64_t M, const float* o, const float* d,
+                   const float* ra, float* t_out, uint8_t* valid_out, newton_ctl* ctl,
+                   float* t0_buf, float* ft_buf)
+{
+    const float onepk = 1.0f + s->k;
+    const float c2 = s->c * s->c;
+    const float lim_loose = loose_limit(s, onepk, c2);
+    const float r2lim = (float)(s->r_d * s->r_d);
+    const float tol_loose = (float)NEWTONS_TOL_LOOSE;
+    const float tol_tight = (float)NEWTONS_TOL_TIGHT;
+    const float eps = (float)EPSILON_D;
+    const int k_gt_m1 = s->k > -1.0f;
+
+    float* t = t_out;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < M; ++i) {
+        t0_buf[i] = (s->d - o[3 * i + 2]) / d[3 * i + 2];
+        t[i] = t0_buf[i];
+        ft_buf[i] = MAXT_F;
+    }
+    int it = 0;
+    for (;;) {
+        if (ctl->trips_forced >= 0) {
+            if (it >= ctl->trips_forced) break;
+        } else {
+            int any = 0;
+#pragma omp parallel for schedule(static) reduction(|:any)
+            for (int64_t i = 0; i < M; ++i) any |= (fabsf(ft_buf[i]) > tol_loose);
+            if (!any || it >= NEWTONS_MAXITER) break;
+        }
+        ++it;
+#pragma omp parallel for schedule(static)
+        for (int64_t i = 0; i < M; ++i) {
+            const float ox = o[3 * i], oy = o[3 * i + 1], oz = o[3 * i + 2];
+            const float dx = d[3 * i], dy = d[3 * i + 1], dz = d[3 * i + 2];
+            const float ti = t[i];
+            float nx = ox + dx * ti, ny = oy + dy * ti, nz = oz + dz * ti;
+            float rr = nx * nx + ny * ny;
+            int v = (k_gt_m1 ? (rr < lim_loose) : (rr > 0.0f)) && (ra[i] > 0.0f);
+            float vf = v ? 1.0f : 0.0f;
+            float x = nx * vf, y = ny * vf;
+            float r2 = x * x + y * y;
+            float ft = (sag_g(s, r2, onepk, c2) + s->d) - nz;
+            float dr2dt = 2.0f * ((dx * dx + dy * dy) * ti + (dx * ox + dy * oy));
+            float dfdt = sag_dgd(s, r2, onepk, c2) * dr2dt - dz;
+            ft_buf[i] = ft;
+            t[i] = ti - clampf(ft / (dfdt + eps), -NEWTONS_STEP_BOUND, NEWTONS_STEP_BOUND);
+        }
+    }
+    ctl->trips_out = it;
+
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < M; ++i) {
+        const float ox = o[3 * i], oy = o[3 * i + 1], oz = o[3 * i + 2];
+        const float dx = d[3 * i], dy = d[3 * i + 1], dz = d[3 * i + 2];
+        float t1 = t[i] - t0_buf[i];                    /* :563 */
+        float ti = t0_buf[i] + t1;                      /* :567 */
+        float nx = ox + dx * ti, ny = oy + dy * ti, nz = oz + dz * ti;
+        float rr = nx * nx + ny * ny;
+        int v = (rr < r2lim) && (!k_gt_m1 || rr < lim_loose) && (ra[i] > 0.0f);
+        float vf = v ? 1.0f : 0.0f;
+        float x = nx * vf, y = ny * vf;
+        float r2 = x * x + y * y;
+        float ft = (sag_g(s, r2, onepk, c2) + s->d) - nz;
+        float dr2dt = 2.0f * ((dx * dx + dy * dy) * ti + (dx * ox + dy * oy));
+        float dfdt = sag_dgd(s, r2, onepk, c2) * dr2dt - dz;
+        ti = ti - clampf(ft / (dfdt + eps), -NEWTONS_STEP_BOUND, NEWTONS_STEP_BOUND);
+        nx = ox + dx * ti; ny = oy + dy * ti;
+        rr = nx * nx + ny * ny;
+        v = (rr < r2lim) && (!k_gt_m1 || rr < lim_loose) && (fabsf(ft) < tol_tight) &&
+            (ra[i] > 0.0f) && (ti > 0.0f);
+        t[i] = ti;
+        valid_out[i] = (uint8_t)v;
+    }
+}
+
+/* surfaces.py:633-679 (+ _normal :589-630), forward==True branch negates n.
+ * `forward` False (backward tracing) keeps n and uses eta = n2/n1. */
+static void refract(const or_surface* s, int64_t M, const float* o, float* d, float* ra,
+                    float* obliq, double eta_d, int forward)
+{
+    const float eta = (float)eta_d;
+    const float eta2 = (float)(eta_d * eta_d);
+    const float onepk = 1.0f + s->k;
+    const float c2 = s->c * s->c;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < M; ++i) {
+        const float x = o[3 * i], y = o[3 * i + 1], z = o[3 * i + 2];
+        float nx, ny, nz;
+        if (s->kind == OR_PLANE) {
+            nx = 0.0f; ny = 0.0f; nz = -1.0f;
+        } else if (s->kind == OR_SPHERE) {
+            float R = 1.0f / s->c;
+            float dR = s->d + R;
+            if (s->c > 0.0f) {
+                nx = 2.0f * x; ny = 2.0f * y; nz = 2.0f * z - 2.0f * dR;
+            } else {
+                nx = -2.0f * x; ny = -2.0f * y; nz = -2.0f * z + 2.0f * dR;
+            }
+        } else {
+            float vf = ra[i] > 0.0f ? 1.0f : 0.0f;
+            float xv = x * vf, yv = y * vf;
+            float r2 = xv * xv + yv * yv;
+            float ds = sag_dgd(s, r2, onepk, c2);
+            nx = (ds * 2.0f) * xv; ny = (ds * 2.0f) * yv; nz = -1.0f;
+        }
+        normalize3(&nx, &ny, &nz);
+        if (forward) { nx = -nx; ny = -ny; nz = -nz; }
+        const float dx = d[3 * i], dy = d[3 * i + 1], dz = d[3 * i + 2];
+        float cosi = (dx * nx + dy * ny) + dz * nz;
+        float c2i = cosi * cosi;
+        float omc = 1.0f - c2i;
+        int v = (c2i > 0.1f) && (eta2 * omc < 1.0f) && (ra[i] > 0.0f);
+        float vf = v ? 1.0f : 0.0f;
+        float sr = sqrtf(1.0f - (eta2 * omc) * vf);
+        float ndx = sr * nx + eta * (dx - cosi * nx);
+        float ndy = sr * ny + eta * (dy - cosi * ny);
+        float ndz = sr * nz + eta * (dz - cosi * nz);
+        if (!v) { ndx = dx; ndy = dy; ndz = dz; }
+        obliq[i] = obliq[i] * ((ndx * dx + ndy * dy) + ndz * dz);
+        d[3 * i] = ndx; d[3 * i + 1] = ndy; d[3 * i + 2] = ndz;
+        ra[i] = ra[i] * vf;
+    }
+}
+
+/* surfaces.py:391-520: one Aspheric.ray_reaction over the whole batch. */
+static int surface_reaction(const or_surface* s, int64_t M, float* o, float* d, float* ra,
+                            float* obliq, int trips_forced, float* w0, float* w1, float* w2,
+                            uint8_t* wv)
+{
+    /* :399 forward = sum(d_z * ra) > 0 over the WHOLE batch */
+    double acc = 0.0;
+#pragma omp parallel for schedule(static) reduction(+:acc)
+    for (int64_t i = 0; i < M; ++i) acc += (double)(d[3 * i + 2] * ra[i]);
+    const int forward = acc > 0.0;
+    const double eta = forward ? s->n1 / s->n2 : s->n2 / s->n1;
+    int trips = 0;
+
+    if (s->kind == OR_PLANE) {
+        const float rlim = (float)s->r_d;
+#pragma omp parallel for schedule(static)
+        for (int64_t i = 0; i < M; ++i) {
+            float t = (s->d - o[3 * i + 2]) / d[3 * i + 2];
+            float nx = o[3 * i] + t * d[3 * i];
+            float ny = o[3 * i + 1] + t * d[3 * i + 1];
+            float nz = o[3 * i + 2] + t * d[3 * i + 2];
+            int v = (sqrtf(nx * nx + ny * ny) <= rlim) && (ra[i] > 0.0f);
+            if (v) { o[3 * i] = nx; o[3 * i + 1] = ny; o[3 * i + 2] = nz; }
+            ra[i] = ra[i] * (v ? 1.0f : 0.0f);
+        }
+        if (eta != 1.0) refract(s, M, o, d, ra, obliq, eta, forward);   /* :450 */
+        return 0;
+    }
+
+    newton_ctl ctl = { trips_forced, 0 };
+    newton(s, M, o, d, ra, w0, wv, &ctl, w1, w2);
+    trips = ctl.trips_out;
+    const float r2lim = (float)(s->r_d * s->r_d);
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < M; ++i) {
+        float t = w0[i];
+        float nx = o[3 * i] + t * d[3 * i];
+        float ny = o[3 * i + 1] + t * d[3 * i + 1];
+        float nz = o[3 * i + 2] + t * d[3 * i + 2];
+        int v;
+        if (s->kind == OR_SPHERE)      /* :464 Newton's own flag is dropped */
+            v = (nx * nx + ny * ny <= r2lim) && (t >= 0.0f) && (ra[i] > 0.0f);
+        else                           /* :495-499 */
+            v = wv[i];
+        if (v) { o[3 * i] = nx; o[3 * i + 1] = ny; o[3 * i + 2] = nz; }
+        ra[i] = ra[i] * (v ? 1.0f : 0.0f);
+    }
+    refract(s, M, o, d, ra, obliq, eta, forward);
+    return trips;
+}
+
+/* ------------------------------------------------------------------------ */
+/* public entry points                                                       */
+/* ------------------------------------------------------------------------ */
+
+/* optics.py:956-960 + 1302-1306.  points [N][3] normalised -> object space. */
+void or_points_to_object(const float* points, int64_t N, double tan_hfov, double r_last,
+                         double sensor_w, double sensor_h, float* point_obj)
+{
+    const float tf = (float)tan_hfov, rl = (float)r_last;
+    const float sw = (float)sensor_w, sh = (float)sensor_h;
+    for (int64_t i = 0; i < N; ++i) {
+        float depth = points[3 * i + 2];
+        float scale = ((-depth) * tf) / rl;
+        point_obj[3 * i] = ((points[3 * i] * scale) * sw) / 2.0f;       /* sensor_size[1] */
+        point_obj[3 * i + 1] = ((points[3 * i + 1] * scale) * sh) / 2.0f; /* sensor_size[0] */
+        point_obj[3 * i + 2] = depth;
+    }
+}
+
+/* optics.py:482-488: uniforms -> points on the entrance pupil disc. */
+void or_pupil_samples(const float* u_theta, const float* u_r2, int64_t S, double pupil_r,
+                      float* x2, float* y2)
+{
+    const float pi = (float)3.141592653589793;
+    const float pr2 = (float)(pupil_r * pupil_r);
+    for (int64_t s = 0; s < S; ++s) {
+        float theta = (u_theta[s] * 2.0f) * pi;
+        float r = sqrtf(u_r2[s] * pr2);
+        x2[s] = r * cosf(theta);
+        y2[s] = r * sinf(theta);
+    }
+}
+
+/* optics.py:479,490-493 + basics.py:238-245: o,d [S][N][3], ra/obliq [S][N]. */
+void or_sample_rays(const float* point_obj, int64_t N, const float* x2, const float* y2,
+                    int64_t S, double pupil_z, float* o, float* d, float* ra, float* obliq)
+{
+    const float pz = (float)pupil_z;
+#pragma omp parallel for schedule(static)
+    for (int64_t s = 0; s < S; ++s)
+        for (int64_t n = 0; n < N; ++n) {
+            int64_t i = s * N + n;
+            float ox = point_obj[3 * n], oy = point_obj[3 * n + 1], oz = point_obj[3 * n + 2];
+            float dx = x2[s] - ox, dy = y2[s] - oy, dz = pz - oz;
+            normalize3(&dx, &dy, &dz);
+            o[3 * i] = ox; o[3 * i + 1] = oy; o[3 * i + 2] = oz;
+            d[3 * i] = dx; d[3 * i + 1] = dy; d[3 * i + 2] = dz;
+            ra[i] = 1.0f; obliq[i] = 1.0f;
+        }
+}
+
+/* optics.py:601-627,666-717.  Traces surfaces [first,last) in forward order when
+ * the first ray's d_z > 0 (optics.py:618), else in reverse order.  trips_io:
+ * per surface; on input a value >=0 forces that many Newton loop trips, a
+ * negative value selects the reference's global rule; on output the trips run.
+ * If rec_o/rec_d/rec_ra are non-NULL the state after every surface is stored
+ * ([K][M][3] / [K][M]) in the order the surfaces were visited. */
+void or_trace(const or_surface* surf, int first, int last, int64_t M, float* o, float* d,
+              float* ra, float* obliq, int32_t* trips_io, float* rec_o, float* rec_d,
+              float* rec_ra)
+{
+    float* w0 = (float*)malloc(sizeof(float) * M);
+    float* w1 = (float*)malloc(sizeof(float) * M);
+    float* w2 = (float*)malloc(sizeof(float) * M);
+    uint8_t* wv = (uint8_t*)malloc(M);
+    const int is_forward = d[2] > 0.0f;
+    const int K = last - first;
+    for (int step = 0; step < K; ++step) {
+        int k = is_forward ? first + step : last - 1 - step;
+        int forced = trips_io ? trips_io[k] : -1;
+        int trips = surface_reaction(&surf[k], M, o, d, ra, obliq, forced, w0, w1, w2, wv);
+        if (trips_io) trips_io[k] = trips;
+        if (rec_o) memcpy(rec_o + (size_t)step * M * 3, o, sizeof(float) * M * 3);
+        if (rec_d) memcpy(rec_d + (size_t)step * M * 3, d, sizeof(float) * M * 3);
+        if (rec_ra) memcpy(rec_ra + (size_t)step * M, ra, sizeof(float) * M);
+    }
+    free(w0); free(w1); free(w2); free(wv);
+}
+
+/* basics.py:256-264 */
+void or_propagate_to(double z, int64_t M, float* o, const float* d)
+{
+    const float zf = (float)z;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < M; ++i) {
+        float t = (zf - o[3 * i + 2]) / d[3 * i + 2];
+        o[3 * i] = o[3 * i] + d[3 * i] * t;
+        o[3 * i + 1] = o[3 * i + 1] + d[3 * i + 1] * t;
+        o[3 * i + 2] = o[3 * i + 2] + d[3 * i + 2] * t;
+    }
+}
+
+/* optics.py:902-904: centre[n] = -(sum_s o*ra / (sum_s ra + 1e-9))[:2].
+ * Returns 0 if no ray at all has ra==1 (the reference asserts, :902). */
+int or_center_from_rays(int64_t S, int64_t N, const float* o, const float* ra, float* center)
+{
+    int any = 0;
+    for (int64_t n = 0; n < N; ++n) {
+        double sx = 0.0, sy = 0.0, sr = 0.0;
+        for (int64_t s = 0; s < S; ++s) {
+            int64_t i = s * N + n;
+            sx += (double)(o[3 * i] * ra[i]);
+            sy += (double)(o[3 * i + 1] * ra[i]);
+            sr += (double)ra[i];
+            any |= (ra[i] == 1.0f);
+        }
+        float den = (float)sr + (float)EPSILON_D;
+        center[2 * n] = -((float)sx / den);
+        center[2 * n + 1] = -((float)sy / den);
+    }
+    return any;
+}
+
+/* ---- dual-pixel closed-form weights ------------------------------------- */
+typedef struct { float h, f, w, r; double fmh; } dp_param;
+
+static inline float seg(float u)   /* u - 1/2*sin(2u)  (monte_carlo.py:182) */
+{
+    return u - 0.5f * sinf(2.0f * u);
+}
+
+/* monte_carlo.py:169-206 (r <= 0.5) */
+static inline void dp_weights_small(const dp_param* p, float x_tan, float* sl, float* sr)
+{
+    const float fmh = (float)p->fmh, r = p->r, rr = r * r;
+    float fx = p->f * x_tan;
+    float xr = p->w - ((fx - p->w) * p->h) / fmh;
+    float xm = ((-fx) * p->h) / fmh;
+    float xl = (-p->w) - ((fx + p->w) * p->h) / fmh;
+    xr = clampf(xr, -r, r); xm = clampf(xm, -r, r); xl = clampf(xl, -r, r);
+    float ur = acosf(xr / r), um = acosf(xm / r), ul = acosf(xl / r);
+    float sr_ml = rr * (seg(um) - seg(ur));
+    float sl_ml = rr * (seg(ul) - seg(um));
+    float hx = p->h * x_tan;
+    xr = p->w - hx; xm = 0.0f - hx; xl = (-p->w) - hx;
+    xr = clampf(xr, -0.5f, 0.5f); xm = clampf(xm, -0.5f, 0.5f); xl = clampf(xl, -0.5f, 0.5f);
+    float xri = clampf(xr, -r, r), xmi = clampf(xm, -r, r), xli = clampf(xl, -r, r);
+    ur = acosf(xri / r); um = acosf(xmi / r); ul = acosf(xli / r);
+    float sr_in = rr * (seg(um) - seg(ur));
+    float sl_in = rr * (seg(ul) - seg(um));
+    float sr_mg = (xr - xm) * 1.0f - sr_in;
+    float sl_mg = (xm - xl) * 1.0f - sl_in;
+    *sr = sr_ml + sr_mg;
+    *sl = sl_ml + sl_mg;
+}
+
+/* monte_carlo.py:274-338 (r >= 0.5) */
+static inline void dp_weights_big(const dp_param* p, double r_d, float x_tan, float* sl,
+                                  float* sr)
+{
+    const float fmh = (float)p->fmh, r = p->r, rr = r * r;
+    /* :275 torch.asin(torch.tensor(0.5/r)) with r an fp32 0-dim tensor */
+    const float tr = asinf((float)(1.0f / r) * 0.5f);
+    const float tl = (float)3.141592653589793 - tr;
+    (void)r_d;
+    float fx = p->f * x_tan;
+    float xr = p->w - ((fx - p->w) * p->h) / fmh;
+    float xm = ((-fx) * p->h) / fmh;
+    float xl = (-p->w) - ((fx + p->w) * p->h) / fmh;
+    xr = clampf(xr, -0.5f, 0.5f); xm = clampf(xm, -0.5f, 0.5f); xl = clampf(xl, -0.5f, 0.5f);
+    float ur = acosf(xr / r), um = acosf(xm / r), ul = acosf(xl / r);
+    float sr_ml = rr * (seg(um) - seg(ur));
+    float sl_ml = rr * (seg(ul) - seg(um));
+    float ure = clampf(ur, tr, tl), ume = clampf(um, tr, tl), ule = clampf(ul, tr, tl);
+    float xre = cosf(ure) * r, xme = cosf(ume) * r, xle = cosf(ule) * r;
+    float sr_ext = (rr * (seg(ume) - seg(ure))) - (xre - xme);
+    float sl_ext = (rr * (seg(ule) - seg(ume))) - (xme - xle);
+    sr_ml = sr_ml - sr_ext;
+    sl_ml = sl_ml - sl_ext;
+
+    float hx = p->h * x_tan;
+    xr = p->w - hx; xm = 0.0f - hx; xl = (-p->w) - hx;
+    xr = clampf(xr, -0.5f, 0.5f); xm = clampf(xm, -0.5f, 0.5f); xl = clampf(xl, -0.5f, 0.5f);
+    ur = acosf(xr / r); um = acosf(xm / r); ul = acosf(xl / r);
+    float sr_in = rr * (seg(um) - seg(ur));
+    float sl_in = rr * (seg(ul) - seg(um));
+    ure = clampf(ur, tr, tl); ume = clampf(um, tr, tl); ule = clampf(ul, tr, tl);
+    xre = cosf(ure) * r; xme = cosf(ume) * r; xle = cosf(ule) * r;
+    float sr_mge = (rr * (seg(ume) - seg(ure))) - (xre - xme);
+    float sl_mge = (rr * (seg(ule) - seg(ume))) - (xme - xle);
+    sr_in = sr_in - sr_mge;
+    sl_in = sl_in - sl_mge;
+    float sr_mg = (xr - xm) * 1.0f - sr_in;
+    float sl_mg = (xm - xl) * 1.0f - sl_in;
+    *sr = sr_ml + sr_mg;
+    *sl = sl_ml + sl_mg;
+}
+
+/* monte_carlo.py:135-240 / 242-372 for ONE point source: points [S][2] (already
+ * shifted and masked), ra [S], x_tan [S] -> l_grid, r_grid [ks][ks] (zeroed
+ * here).  dp == NULL reproduces param_list=None (defaults, R grid stays 0).
+ * index_put_(accumulate=True) on CPU adds serially in index order: all
+ * top-left taps, then top-right, bottom-left, bottom-right (:225-228). */
+void or_assign_points_to_pixels(const float* points, const float* ra, const float* x_tan,
+                                int64_t S, int64_t stride, int ks, double x_min, double x_max,
+                                const double* dp /* h,f,w,r or NULL */, float* l_grid,
+                                float* r_grid)
+{
+    dp_param p;
+    const int have = dp != NULL;
+    p.h = (float)(have ? dp[0] : 0.78); p.f = (float)(have ? dp[1] : 1.44);
+    p.w = (float)(have ? dp[2] : 0.3);  p.r = (float)(have ? dp[3] : 0.5);
+    p.fmh = (have ? dp[1] : 1.44) - (have ? dp[0] : 0.78);
+    const double r_d = have ? dp[3] : 0.5;
+    const int big = r_d > 0.5;                      /* forward_integral :59 */
+    const float xminf = (float)x_min, ymaxf = (float)x_max;
+    const float dxr = (float)(x_max - x_min), dyr = (float)(x_min - x_max);
+    const float ksm1 = (float)(ks - 1);
+    memset(l_grid, 0, sizeof(float) * ks * ks);
+    memset(r_grid, 0, sizeof(float) * ks * ks);
+    for (int tap = 0; tap < 4; ++tap)
+        for (int64_t s = 0; s < S; ++s) {
+            const float px = points[2 * s * stride], py = points[2 * s * stride + 1];
+            float sl, sr;
+            if (big) dp_weights_big(&p, r_d, x_tan[s * stride], &sl, &sr);
+            else dp_weights_small(&p, x_tan[s * stride], &sl, &sr);
+            float pn0 = (py - ymaxf) / dyr;              /* row  (:210) */
+            float pn1 = (px - xminf) / dxr;              /* col  (:211) */
+            float pf0 = pn0 * ksm1, pf1 = pn1 * ksm1;
+            float fl0 = floorf(pf0), fl1 = floorf(pf1);
+            float wb = pf0 - fl0, wr = pf1 - fl1;
+            int64_t r0 = (int64_t)fl0, c0 = (int64_t)fl1;
+            int64_t rr_, cc_;
+            float wgt;
+            switch (tap) {
+            case 0: rr_ = r0; cc_ = c0; wgt = (1.0f - wb) * (1.0f - wr); break;
+            case 1: rr_ = r0; cc_ = (int64_t)floorf(pf1 + 1.0f); wgt = (1.0f - wb) * wr; break;
+            case 2: rr_ = (int64_t)floorf(pf0 + 1.0f); cc_ = c0; wgt = wb * (1.0f - wr); break;
+            default: rr_ = r0 + 1; cc_ = c0 + 1; wgt = wb * wr; break;
+            }
+            if (rr_ < 0) rr_ += ks;                       /* torch negative-index wrap */
+            if (cc_ < 0) cc_ += ks;
+            if (rr_ < 0 || rr_ >= ks || cc_ < 0 || cc_ >= ks) continue;  /* torch raises */
+            float wra = wgt * ra[s * stride];
+            l_grid[rr_ * ks + cc_] += wra * sl;
+            if (have) r_grid[rr_ * ks + cc_] += wra * sr;
+        }
+}
+
+/* monte_carlo.py:9-68.  Sensor-plane rays o,d [S][N][3], ra [S][N]; centre [N][2]
+ * (pointc_ref).  Produces RAW l/r grids [N][ks][ks] (no `direct` swap, no
+ * normalisation). */
+void or_forward_integral(int64_t S, int64_t N, const float* o, const float* d, const float* ra,
+                         double ps, int ks, const float* center, const double* dp,
+                         float* l_grid, float* r_grid)
+{
+    const double range_hi = (ks / 2.0 - 0.5) * ps, range_lo = (-ks / 2.0 + 0.5) * ps;
+    const float lim = (float)(range_hi - 0.01 * ps);
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int64_t n = 0; n < N; ++n) {
+        float* pts = (float*)malloc(sizeof(float) * S * 2);
+        float* ran = (float*)malloc(sizeof(float) * S);
+        float* xt = (float*)malloc(sizeof(float) * S);
+        for (int64_t s = 0; s < S; ++s) {
+            int64_t i = s * N + n;
+            float px = (-o[3 * i]) - center[2 * n];
+            float py = (-o[3 * i + 1]) - center[2 * n + 1];
+            float r = ra[i] * (fabsf(px) < lim ? 1.0f : 0.0f);
+            r = r * (fabsf(py) < lim ? 1.0f : 0.0f);
+            pts[2 * s] = px * r; pts[2 * s + 1] = py * r;
+            ran[s] = r;
+            xt[s] = (-d[3 * i]) / d[3 * i + 2];
+        }
+        or_assign_points_to_pixels(pts, ran, xt, S, 1, ks, range_lo, range_hi, dp,
+                                   l_grid + (size_t)n * ks * ks, r_grid + (size_t)n * ks * ks);
+        free(pts); free(ran); free(xt);
+    }
+}
+
+/* optics.py:983-987 */
+void or_psf_normalize(int64_t N, int ks, float* psf)
+{
+    for (int64_t n = 0; n < N; ++n) {
+        float* g = psf + (size_t)n * ks * ks;
+        float mx = g[0];
+        for (int i = 1; i < ks * ks; ++i) mx = g[i] > mx ? g[i] : mx;
+        float den = mx + 1e-6f;
+        for (int i = 0; i < ks * ks; ++i) g[i] = g[i] / den;
+    }
+}
+
+/* optics.py:934-996 chained, for the CPU baseline and end-to-end checks.
+ * x2,y2 [S] / xc,yc [Sc]: pupil samples for the primary and chief-ray passes
+ * (the latter already on the 0.25x pupil).  Writes raw-or-normalised L and R
+ * [N][ks][ks] and the centres [N][2].  surf_c: surface table at the centre
+ * wavelength (optics.py:900 always uses DEFAULT_WAVE).  Returns 0 on the
+ * reference's 'No sampled rays is valid.' assertion. */
+int or_psf(const or_surface* surf, const or_surface* surf_c, int K, const float* point_obj,
+           int64_t N, const float* x2, const float* y2, int64_t S, const float* xc,
+           const float* yc, int64_t Sc, double pupil_z, double d_sensor, double ps, int ks,
+           const double* dp, int normalize, float* center, float* l_grid, float* r_grid)
+{
+    int64_t Mm = S > Sc ? S : Sc;
+    Mm *= N;
+    float* o = (float*)malloc(sizeof(float) * Mm * 3);
+    float* d = (float*)malloc(sizeof(float) * Mm * 3);
+    float* ra = (float*)malloc(sizeof(float) * Mm);
+    float* ob = (float*)malloc(sizeof(float) * Mm);
+    or_sample_rays(point_obj, N, xc, yc, Sc, pupil_z, o, d, ra, ob);
+    or_trace(surf_c, 0, K, Sc * N, o, d, ra, ob, NULL, NULL, NULL, NULL);
+    or_propagate_to(d_sensor, Sc * N, o, d);
+    int ok = or_center_from_rays(Sc, N, o, ra, center);
+    or_sample_rays(point_obj, N, x2, y2, S, pupil_z, o, d, ra, ob);
+    or_trace(surf, 0, K, S * N, o, d, ra, ob, NULL, NULL, NULL, NULL);
+    or_propagate_to(d_sensor, S * N, o, d);
+    or_forward_integral(S, N, o, d, ra, ps, ks, center, dp, l_grid, r_grid);
+    if (normalize) {
+        or_psf_normalize(N, ks, l_grid);
+        or_psf_normalize(N, ks, r_grid);
+    }
+    free(o); free(d); free(ra); free(ob);
+    return ok;
+}
+
+int or_num_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+void or_set_num_threads(int n)
+{
+#ifdef _OPENMP
+    omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
+int or_sizeof_surface(void) { return (int)sizeof(or_surface); }
