@@ -1,0 +1,225 @@
+/*
+ * sdirt_dp.h -- C ABI of libsdirt_dp.so, the MI355X (gfx950) dual-pixel
+ * ray-traced PSF renderer.
+ *
+ * The reference (LinYark/Sdirt) has no native/FFI layer: its boundary for this
+ * path is the Python call surface of deeplens/optics.py, surfaces.py and
+ * monte_carlo.py.  Each entry point below replaces one of those calls; the
+ * reference file:line it stands in for is cited on the declaration.  The
+ * Python package sdirt_amd/ binds these symbols with ctypes and re-exposes the
+ * reference's signatures (INTEGRATION.md shows the binding).
+ *
+ * Conventions
+ *  - plain C types only; every pointer marked `dev` is a DEVICE pointer
+ *    (hipMalloc'd or a torch.cuda tensor's data_ptr()); `host` pointers are
+ *    read during the call and may be freed right after it returns;
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *  - data-path calls never allocate, never free and never synchronise: they
+ *    enqueue kernels on `stream` and return.  Only sdirt_lens_create /
+ *    sdirt_lens_destroy touch the allocator;
+ *  - every function returns SDIRT_OK (0) or a negative sdirt_status; the text
+ *    of the last error on the calling thread is returned by sdirt_last_error();
+ *  - rays are stored SoA (sdirt_rays): 8 arrays of S*N floats, element
+ *    [s*N + n] = sample s of point source n -- consecutive lanes read
+ *    consecutive addresses.  The reference keeps o,d as [S,N,3]
+ *    (deeplens/basics.py:216-245); the shim converts at the API edge only.
+ */
+#ifndef SDIRT_DP_H
+#define SDIRT_DP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SDIRT_ABI_VERSION 1
+#define SDIRT_MAX_SURFACES 64
+#define SDIRT_MAX_AI 8
+#define SDIRT_NEWTON_MAXITER 10 /* deeplens/surfaces.py:26 */
+#define SDIRT_MAX_KS 143        /* two ks*ks fp32 tiles must fit in 160 KiB of LDS */
+
+typedef enum sdirt_status {
+    SDIRT_OK = 0,
+    SDIRT_ERR_INVALID_ARGUMENT = -1,
+    SDIRT_ERR_UNSUPPORTED = -2, /* e.g. conic k <= -1 together with a feature not built */
+    SDIRT_ERR_HIP = -3,         /* a HIP runtime call failed, see sdirt_last_error() */
+    SDIRT_ERR_NO_DEVICE = -4
+} sdirt_status;
+
+typedef enum sdirt_surface_kind {
+    SDIRT_PLANE = 0,  /* c == 0: stop / flat        deeplens/surfaces.py:409 */
+    SDIRT_SPHERE = 1, /* ai is None and k == 0      deeplens/surfaces.py:456 */
+    SDIRT_ASPHERE = 2 /* everything else            deeplens/surfaces.py:491 */
+} sdirt_surface_kind;
+
+/* One optical surface, as deeplens/surfaces.py:291-331 (Aspheric.__init__) holds
+ * it: r is a Python float (double), d/c/k/ai are fp32 tensors.  n1/n2 are
+ * Material.ior(wvln) of the medium before/after the surface, float64
+ * (deeplens/basics.py:316-340). */
+typedef struct sdirt_surface_desc {
+    int32_t kind;      /* sdirt_surface_kind */
+    int32_t ai_degree; /* 0, or number of even-asphere terms ai2, ai4, ... (<= 8) */
+    double r;          /* semi-aperture [mm] */
+    float d;           /* vertex z [mm] */
+    float c;           /* curvature 1/roc [1/mm] */
+    float k;           /* conic constant */
+    float ai[SDIRT_MAX_AI];
+    double n1;
+    double n2;
+} sdirt_surface_desc;
+
+/* A lens prescription at ONE wavelength, resident on the device. */
+typedef struct sdirt_lens sdirt_lens;
+
+/* SoA ray bundle: the reference's Ray(o, d, ra, obliq) (deeplens/basics.py:216-245). */
+typedef struct sdirt_rays {
+    float* ox; float* oy; float* oz; /* dev, S*N each */
+    float* dx; float* dy; float* dz; /* dev, S*N each, unit length */
+    float* ra;                       /* dev, validity 0/1                      */
+    float* obliq;                    /* dev, product of cos(refraction angles); may be NULL */
+} sdirt_rays;
+
+/* Dual-pixel sensor model parameters: the reference's param_list
+ * [h, f, w, r, direct] without the direction letter
+ * (deeplens/monte_carlo.py:157-164).  NULL where a `const sdirt_dp_params*` is
+ * taken means param_list=None: defaults h=0.78 f=1.44 w=0.3 r=0.5 and, as in
+ * the reference (monte_carlo.py:231), the R grid is left all-zero. */
+typedef struct sdirt_dp_params {
+    double h, f, w, r;
+} sdirt_dp_params;
+
+/* ---- library ------------------------------------------------------------ */
+int sdirt_abi_version(void);
+const char* sdirt_last_error(void);
+/* Number of visible HIP devices (0 if none); does not initialise a context. */
+int sdirt_device_count(void);
+
+/* ---- lens ---------------------------------------------------------------- */
+/* Replaces Lensgroup.read_lens_json + per-call Material.ior evaluation
+ * (deeplens/optics.py:2173-2198, deeplens/surfaces.py:399-405): builds the flat
+ * per-surface constant block (fp32 thresholds rounded exactly where torch
+ * rounds them) and uploads it to the current device. */
+int sdirt_lens_create(const sdirt_surface_desc* surfaces /*host*/, int32_t n_surfaces,
+                      sdirt_lens** out_lens);
+void sdirt_lens_destroy(sdirt_lens* lens);
+int32_t sdirt_lens_num_surfaces(const sdirt_lens* lens);
+
+/* ---- staged path (same decomposition as the reference) ------------------ */
+
+/* Lensgroup.psf_diff, deeplens/optics.py:956-960 + calc_scale_pinhole :1302-1306:
+ * normalised points [N,3] (x,y in [-1,1], z = depth mm) -> object-space points.
+ * sensor_w/h = sensor_size[1], sensor_size[0]. */
+int sdirt_points_to_object(const float* points /*dev [N,3]*/, int64_t n_points, double tan_hfov,
+                           double r_last, double sensor_w, double sensor_h,
+                           float* point_obj /*dev [N,3]*/, void* stream);
+
+/* Lensgroup.sample_from_points, deeplens/optics.py:482-488: uniforms in [0,1)
+ * -> points on the pupil disc of radius pupil_r. */
+int sdirt_pupil_samples(const float* u_theta /*dev [S]*/, const float* u_r2 /*dev [S]*/,
+                        int64_t spp, double pupil_r, float* x2 /*dev [S]*/, float* y2 /*dev [S]*/,
+                        void* stream);
+
+/* Lensgroup.sample_from_points + Ray.__init__, deeplens/optics.py:479,490-494,
+ * deeplens/basics.py:238-245: rays from every point to every pupil sample,
+ * normalised; ra = obliq = 1. */
+int sdirt_sample_rays(const float* point_obj /*dev [N,3]*/, int64_t n_points,
+                      const float* x2 /*dev [S]*/, const float* y2 /*dev [S]*/, int64_t spp,
+                      double pupil_z, sdirt_rays rays, void* stream);
+
+/* Ray.__init__, deeplens/basics.py:233-245: build a ray bundle from the
+ * reference's AoS tensors o,d [M,3] (d is L2-normalised with eps 1e-12 when
+ * normalize != 0); ra (dev [M]) may be NULL (= all ones); obliq is set to 1. */
+int sdirt_rays_from_aos(const float* o /*dev [M,3]*/, const float* d /*dev [M,3]*/,
+                        const float* ra /*dev [M] or NULL*/, int64_t n_rays, int32_t normalize,
+                        sdirt_rays rays, void* stream);
+
+/* Inverse view for callers that read ray.o / ray.d as [..., 3] tensors. */
+int sdirt_rays_to_aos(sdirt_rays rays, int64_t n_rays, float* o /*dev [M,3] or NULL*/,
+                      float* d /*dev [M,3] or NULL*/, void* stream);
+
+/* Lensgroup.trace / _forward_tracing / _backward_tracing,
+ * deeplens/optics.py:601-627,666-717, with Aspheric.ray_reaction
+ * (deeplens/surfaces.py:391-520) per surface: traces surfaces [first,last) in
+ * increasing order (backward == 0) or decreasing order (backward != 0), in place.
+ *
+ * trips (host, one int per lens surface, indexed by surface): number of Newton
+ * loop trips to run on that surface.  The reference runs the loop until EVERY
+ * ray of the batch has |f(t)| <= 50e-6 or 10 trips (surfaces.py:547), so the
+ * count is a property of the whole batch; conv_mask (dev, one uint32 per lens
+ * surface, zeroed by the caller, may be NULL) receives, OR-ed over all rays,
+ * bit j (1..trips) = "some ray still had |f(t)| > 50e-6 in trip j".  A trip
+ * table T reproduces the reference's batch exactly iff for every surface bits
+ * 1..T-1 are set and bit T is clear (or T == 10); sdirt_amd/newton.py runs that
+ * check and re-launches with the corrected table when speculation fails. */
+int sdirt_trace(const sdirt_lens* lens, int32_t first, int32_t last, int32_t backward,
+                const int32_t* trips /*host [K]*/, sdirt_rays rays, int64_t n_rays,
+                uint32_t* conv_mask /*dev [K] or NULL*/, void* stream);
+
+/* Ray.propagate_to, deeplens/basics.py:256-264. */
+int sdirt_propagate_to(double z, sdirt_rays rays, int64_t n_rays, void* stream);
+
+/* Centroid part of Lensgroup.psf_center, deeplens/optics.py:902-904:
+ * center[n] = -(sum_s o*ra / (sum_s ra + 1e-9)).xy;  any_valid (dev int32,
+ * zeroed by caller, may be NULL) is set to 1 if any ray has ra == 1. */
+int sdirt_center_from_rays(sdirt_rays rays, int64_t spp, int64_t n_points,
+                           float* center /*dev [N,2]*/, int32_t* any_valid /*dev*/, void* stream);
+
+/* forward_integral + assign_points_to_pixels_small_r / _big_r,
+ * deeplens/monte_carlo.py:9-68, 135-240, 242-372: sensor-plane rays -> RAW left
+ * and right grids [N,ks,ks] (fully overwritten).  r_grid may be NULL.
+ * ps = pixel size; center = pointc_ref [N,2]. */
+int sdirt_forward_integral(sdirt_rays rays, int64_t spp, int64_t n_points, double ps, int32_t ks,
+                           const float* center /*dev [N,2]*/, const sdirt_dp_params* dp /*host*/,
+                           float* l_grid /*dev [N,ks,ks]*/, float* r_grid /*dev or NULL*/,
+                           void* stream);
+
+/* deeplens/optics.py:983-987: psf / (max + 1e-6), per point, in place. */
+int sdirt_psf_normalize(float* psf /*dev [N,ks,ks]*/, int64_t n_points, int32_t ks, void* stream);
+
+/* ---- fused hot path ------------------------------------------------------ */
+
+/* Chief-ray centre, Lensgroup.psf_center(method='chief_ray'),
+ * deeplens/optics.py:898-904, fused: sample (xc,yc are pupil samples on the
+ * shrunk pupil) -> trace to sensor -> centroid, rays never leave registers. */
+int sdirt_chief_center(const sdirt_lens* lens, const float* point_obj /*dev [N,3]*/,
+                       int64_t n_points, const float* xc /*dev [Sc]*/, const float* yc /*dev [Sc]*/,
+                       int64_t spp_center, double pupil_z, double d_sensor,
+                       const int32_t* trips /*host [K]*/, float* center /*dev [N,2]*/,
+                       int32_t* any_valid /*dev or NULL*/, uint32_t* conv_mask /*dev [K] or NULL*/,
+                       void* stream);
+
+#define SDIRT_PSF_NORMALIZE 1u /* apply optics.py:983-987 to each written grid */
+#define SDIRT_PSF_ACCUMULATE 2u /* internal: grids pre-zeroed, blocks add partial tiles */
+
+/* Lensgroup.psf_diff, deeplens/optics.py:934-996, fused from sampling to the
+ * normalised left/right PSFs: one workgroup per (point, spp-slice), rays
+ * generated in registers, per-surface constants read through the scalar cache,
+ * L/R tiles accumulated with LDS float atomics, one coalesced store.
+ * center = pointc_ref [N,2] (from sdirt_chief_center, or the pinhole centre
+ * for center=False, optics.py:973-976).  r_psf may be NULL. */
+int sdirt_psf_lr(const sdirt_lens* lens, const float* point_obj /*dev [N,3]*/, int64_t n_points,
+                 const float* x2 /*dev [S]*/, const float* y2 /*dev [S]*/, int64_t spp,
+                 double pupil_z, double d_sensor, double ps, int32_t ks,
+                 const float* center /*dev [N,2]*/, const sdirt_dp_params* dp /*host or NULL*/,
+                 const int32_t* trips /*host [K]*/, uint32_t flags, float* l_psf /*dev [N,ks,ks]*/,
+                 float* r_psf /*dev or NULL*/, uint32_t* conv_mask /*dev [K] or NULL*/,
+                 void* stream);
+
+/* ---- image-space consumer of the PSFs ------------------------------------ */
+
+/* local_psf_render_fast / local_psf_render / local_dp_psf_render,
+ * deeplens/render_psf.py:76-188: per-pixel L/R PSF convolution with replicate
+ * padding and flipped kernels.  img [B,C,H,W] fp32, psf [B,H,W,2,ks,ks] fp32;
+ * half_precision != 0 reproduces the fp16 arithmetic of the _fast variant
+ * (inputs rounded to fp16, products rounded to fp16, fp32 accumulation, result
+ * rounded to fp16), 0 the fp32 arithmetic of local_dp_psf_render. */
+int sdirt_local_psf_render(const float* img /*dev*/, const float* psf /*dev*/, int32_t batch,
+                           int32_t channels, int32_t height, int32_t width, int32_t ks,
+                           int32_t half_precision, float* out_l /*dev [B,C,H,W]*/,
+                           float* out_r /*dev [B,C,H,W]*/, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDIRT_DP_H */

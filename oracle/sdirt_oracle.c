@@ -142,7 +142,7 @@ static inline float sag_dgd(const or_surface* s, float r2, float onepk, float c2
 /* thresholds shared by _valid / _valid_loose (surfaces.py:724-743):
  * (1-EPSILON)/c**2/(1+k) is evaluated by torch as reciprocal(c*c) * fp32(1-1e-9)
  * / (1+k)  (python_float / tensor == tensor.reciprocal() * python_float). */
-static inline float loose_limit(const or_surface* s, float onepk, float c2)
+static inline float loose_limit(float onepk, float c2)
 {
     float rc = 1.0f / c2;
     rc = rc * (float)(1.0 - EPSILON_D);
@@ -163,7 +163,7 @@ static void newton(const or_surface* s, int64_t M, const float* o, const float* 
 {
     const float onepk = 1.0f + s->k;
     const float c2 = s->c * s->c;
-    const float lim_loose = loose_limit(s, onepk, c2);
+    const float lim_loose = loose_limit(onepk, c2);
     const float r2lim = (float)(s->r_d * s->r_d);
     const float tol_loose = (float)NEWTONS_TOL_LOOSE;
     const float tol_tight = (float)NEWTONS_TOL_TIGHT;

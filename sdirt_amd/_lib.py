@@ -1,0 +1,104 @@
+"""ctypes binding of libsdirt_dp.so (include/sdirt_dp.h).
+
+The library is the product: there is NO CPU fallback.  If the shared object is
+missing, `lib()` raises SdirtError telling how to build it; if no MI355X is
+visible, the first device call fails with the HIP error text.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libsdirt_dp.so")
+
+MAX_SURFACES = 64
+MAX_AI = 8
+NEWTON_MAXITER = 10
+MAX_KS = 143
+PSF_NORMALIZE = 1
+
+KIND_PLANE, KIND_SPHERE, KIND_ASPHERE = 0, 1, 2
+
+
+class SdirtError(RuntimeError):
+    pass
+
+
+class SurfaceDesc(C.Structure):
+    """sdirt_surface_desc"""
+    _fields_ = [("kind", C.c_int32), ("ai_degree", C.c_int32), ("r", C.c_double),
+                ("d", C.c_float), ("c", C.c_float), ("k", C.c_float),
+                ("ai", C.c_float * MAX_AI), ("n1", C.c_double), ("n2", C.c_double)]
+
+
+class Rays(C.Structure):
+    """sdirt_rays: eight device pointers"""
+    _fields_ = [(n, C.c_void_p) for n in ("ox", "oy", "oz", "dx", "dy", "dz", "ra", "obliq")]
+
+
+class DpParams(C.Structure):
+    """sdirt_dp_params"""
+    _fields_ = [("h", C.c_double), ("f", C.c_double), ("w", C.c_double), ("r", C.c_double)]
+
+
+_P, _I64, _I32, _U32, _D = C.c_void_p, C.c_int64, C.c_int32, C.c_uint32, C.c_double
+
+# name -> (restype, argtypes); mirrors include/sdirt_dp.h one to one
+SIGNATURES = {
+    "sdirt_abi_version": (C.c_int, []),
+    "sdirt_last_error": (C.c_char_p, []),
+    "sdirt_device_count": (C.c_int, []),
+    "sdirt_lens_create": (C.c_int, [C.POINTER(SurfaceDesc), _I32, C.POINTER(_P)]),
+    "sdirt_lens_destroy": (None, [_P]),
+    "sdirt_lens_num_surfaces": (_I32, [_P]),
+    "sdirt_points_to_object": (C.c_int, [_P, _I64, _D, _D, _D, _D, _P, _P]),
+    "sdirt_pupil_samples": (C.c_int, [_P, _P, _I64, _D, _P, _P, _P]),
+    "sdirt_sample_rays": (C.c_int, [_P, _I64, _P, _P, _I64, _D, Rays, _P]),
+    "sdirt_rays_from_aos": (C.c_int, [_P, _P, _P, _I64, _I32, Rays, _P]),
+    "sdirt_rays_to_aos": (C.c_int, [Rays, _I64, _P, _P, _P]),
+    "sdirt_trace": (C.c_int, [_P, _I32, _I32, _I32, C.POINTER(_I32), Rays, _I64, _P, _P]),
+    "sdirt_propagate_to": (C.c_int, [_D, Rays, _I64, _P]),
+    "sdirt_center_from_rays": (C.c_int, [Rays, _I64, _I64, _P, _P, _P]),
+    "sdirt_forward_integral": (C.c_int, [Rays, _I64, _I64, _D, _I32, _P, C.POINTER(DpParams),
+                                         _P, _P, _P]),
+    "sdirt_psf_normalize": (C.c_int, [_P, _I64, _I32, _P]),
+    "sdirt_chief_center": (C.c_int, [_P, _P, _I64, _P, _P, _I64, _D, _D, C.POINTER(_I32), _P, _P,
+                                     _P, _P]),
+    "sdirt_psf_lr": (C.c_int, [_P, _P, _I64, _P, _P, _I64, _D, _D, _D, _I32, _P,
+                               C.POINTER(DpParams), C.POINTER(_I32), _U32, _P, _P, _P, _P]),
+    "sdirt_local_psf_render": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P, _P]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library, with argtypes set.  Raises SdirtError if not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SdirtError(
+                f"{LIB_PATH} is missing: build it with `make -C sdirt_amd/csrc` "
+                "(or `python -c 'import __graft_entry__ as g; g.build()'`). "
+                "sdirt_amd has no CPU fallback.")
+        try:
+            h = C.CDLL(LIB_PATH)
+        except OSError as e:      # pragma: no cover
+            raise SdirtError(f"cannot load {LIB_PATH}: {e}") from e
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(h, name)
+            fn.restype = res
+            fn.argtypes = args
+        if h.sdirt_abi_version() != 1:
+            raise SdirtError("libsdirt_dp.so ABI version mismatch; rebuild")
+        _lib = h
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib().sdirt_last_error().decode("utf-8", "replace")
+        raise SdirtError(f"libsdirt_dp error {rc}: {msg}")
+
+
+def device_count():
+    return lib().sdirt_device_count()

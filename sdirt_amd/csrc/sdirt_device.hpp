@@ -1,0 +1,368 @@
+// sdirt_device.hpp -- per-ray device math of the dual-pixel PSF path (gfx950).
+//
+// Everything here is scalar-per-ray fp32 arithmetic written in the SAME
+// evaluation order as the reference's torch CPU ops, and the translation unit
+// is compiled with -ffp-contract=off and hipcc's default correctly rounded
+// fp32 divide/sqrt, so that a ray traced here is bit-identical to the same ray
+// traced by an IEEE-754 CPU evaluation of the reference op sequence
+// (deeplens/surfaces.py:391-830, deeplens/monte_carlo.py:135-372).
+//
+// Wave-uniform data (the per-surface constant block, DP-sensor parameters) is
+// read through `const __restrict__` kernel-argument pointers with wave-uniform
+// indices, i.e. through the scalar cache into SGPRs: it costs no VGPRs and no
+// LDS bandwidth.  Per-ray state lives in VGPRs for the whole trace.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sdirt {
+
+constexpr int kMaxAi = 8;
+constexpr float kNewtonStepBound = 5.0f;   // deeplens/surfaces.py:29
+constexpr float kMaxT = 1e5f;              // deeplens/basics.py:33
+
+// Flat per-surface constant block.  Every field that the reference obtains by
+// rounding a Python/numpy float64 to fp32 at the point of use is rounded on the
+// host, once, in sdirt_lens_create (see sdirt_dp.hip: make_dev_surface).
+struct DevSurface {
+    int32_t kind;        // 0 plane, 1 sphere, 2 asphere
+    int32_t ai_degree;
+    int32_t do_refract;  // plane: eta != 1 (surfaces.py:450); curved: always 1
+    int32_t k_gt_m1;     // k > -1 (surfaces.py:727,738)
+    float d, c, k;
+    float r_lim;         // fp32(r)                         surfaces.py:421
+    float r2_lim;        // fp32(r*r in double)             surfaces.py:464,728
+    float c2;            // c*c (fp32)
+    float onepk;         // 1 + k
+    float lim_loose;     // ((1/c2) * fp32(1-1e-9)) / (1+k) surfaces.py:728,739
+    float d_plus_R;      // d + 1/c                         surfaces.py:607-615
+    float eta_f, eta2_f; // forward: fp32(n1/n2), fp32((n1/n2)^2)   surfaces.py:401,663-669
+    float eta_b, eta2_b; // backward: fp32(n2/n1), fp32((n2/n1)^2)  surfaces.py:404
+    float ai[kMaxAi];    // ai2, ai4, ...
+    float kai[kMaxAi];   // (i+1) * ai[i]  (python int * fp32 tensor)  surfaces.py:823
+};
+
+struct DevDpParams {
+    float h, f, w, r;    // fp32 of the python floats        monte_carlo.py:157-164
+    float fmh;           // fp32(f - h) evaluated in double
+    float rr;            // r * r (fp32)
+    float tr, tl;        // big-r only: asin(0.5/r), pi - tr  monte_carlo.py:275-276
+    int32_t big;         // r > 0.5                           monte_carlo.py:59
+    int32_t have_r;      // param_list is not None -> R grid is filled (:231)
+};
+
+struct Ray {
+    float ox, oy, oz, dx, dy, dz, ra, ob;
+};
+
+__device__ __forceinline__ float clampf(float v, float lo, float hi)
+{
+    // torch.clamp semantics: NaN propagates
+    if (v != v) return v;
+    v = v < lo ? lo : v;
+    v = v > hi ? hi : v;
+    return v;
+}
+
+// torch.nn.functional.normalize over a last dim of 3 (basics.py:245,
+// surfaces.py:628): v / max(||v||, 1e-12); torch's CPU kernel accumulates the
+// squares with fused multiply-adds (x*x, then fma y, then fma z).
+__device__ __forceinline__ void normalize3(float& x, float& y, float& z)
+{
+    float acc = x * x;
+    acc = __builtin_fmaf(y, y, acc);
+    acc = __builtin_fmaf(z, z, acc);
+    float nrm = __builtin_sqrtf(acc);
+    nrm = nrm < 1e-12f ? 1e-12f : nrm;
+    x = x / nrm;
+    y = y / nrm;
+    z = z / nrm;
+}
+
+// r2 ** n as torch evaluates it on CPU: n==2 -> x*x, n==3 -> (x*x)*x, n>=4 a
+// <=1 ulp vector pow; for n>=4 we return the correctly rounded exact power
+// (product in fp64, rounded once) -- identical to oracle/sdirt_oracle.c:powi.
+__device__ __forceinline__ float powi(float x, int n)
+{
+    if (n == 1) return x;
+    if (n == 2) return x * x;
+    if (n == 3) return (x * x) * x;
+    double p = (double)x, acc = p;
+    for (int i = 1; i < n; ++i) acc *= p;
+    return (float)acc;
+}
+
+// surfaces.py:787-808 and 811-830 evaluated together (they share sqrt(1-a)).
+__device__ __forceinline__ void sag_g_dgd(const DevSurface& s, float r2, float& g, float& dgd)
+{
+    const float a = (s.onepk * r2) * s.c2;
+    const float sf = __builtin_sqrtf(1.0f - a);
+    const float onesf = 1.0f + sf;
+    g = (r2 * s.c) / onesf;
+    dgd = ((onesf + (a / 2.0f) / sf) * s.c) / (onesf * onesf);
+    if (s.ai_degree > 0) {
+        dgd = dgd + s.ai[0];
+        g = g + s.ai[0] * r2;
+        float pw = r2;   // r2 ** i
+        for (int i = 1; i < s.ai_degree; ++i) {
+            dgd = dgd + s.kai[i] * pw;
+            pw = powi(r2, i + 1);
+            g = g + s.ai[i] * pw;
+        }
+    }
+}
+
+__device__ __forceinline__ float sag_dgd_only(const DevSurface& s, float r2)
+{
+    float g, dgd;
+    sag_g_dgd(s, r2, g, dgd);
+    return dgd;
+}
+
+// surfaces.py:523-586.  `trips` loop iterations (wave-uniform), then the extra
+// differentiable step and the validity test.  Returns Newton's own validity;
+// mask_out (wave-uniform, lives in SGPRs) gets bit j set when ANY active lane of
+// the wave had |f(t)| > 50e-6 in trip j -- the per-wave share of the reference's
+// batch-wide `.any()` loop condition (surfaces.py:547).
+__device__ __forceinline__ bool newton(const DevSurface& s, const Ray& r, int trips, float& t_out,
+                                       uint32_t& mask_out)
+{
+    const float tol_loose = (float)50e-6, tol_tight = (float)10e-6, eps = (float)1e-9;
+    const float t0 = (s.d - r.oz) / r.dz;
+    const float dd = r.dx * r.dx + r.dy * r.dy;
+    const float dox = r.dx * r.ox + r.dy * r.oy;
+    const bool alive = r.ra > 0.0f;
+    float t = t0;
+    uint32_t mask = 0;
+    for (int it = 1; it <= trips; ++it) {
+        const float nx = r.ox + r.dx * t, ny = r.oy + r.dy * t, nz = r.oz + r.dz * t;
+        const float rr = nx * nx + ny * ny;
+        const bool v = (s.k_gt_m1 ? (rr < s.lim_loose) : (rr > 0.0f)) && alive;
+        const float vf = v ? 1.0f : 0.0f;
+        const float x = nx * vf, y = ny * vf;
+        const float r2 = x * x + y * y;
+        float g, dgd;
+        sag_g_dgd(s, r2, g, dgd);
+        const float ft = (g + s.d) - nz;
+        const float dr2dt = 2.0f * (dd * t + dox);
+        const float dfdt = dgd * dr2dt - r.dz;
+        mask |= (__ballot(__builtin_fabsf(ft) > tol_loose) != 0ull) ? (1u << it) : 0u;
+        t = t - clampf(ft / (dfdt + eps), -kNewtonStepBound, kNewtonStepBound);
+    }
+    mask_out = mask;
+    const float t1 = t - t0;   // :563
+    t = t0 + t1;               // :567
+    float nx = r.ox + r.dx * t, ny = r.oy + r.dy * t;
+    const float nz = r.oz + r.dz * t;
+    float rr = nx * nx + ny * ny;
+    bool v = (rr < s.r2_lim) && (!s.k_gt_m1 || rr < s.lim_loose) && alive;
+    const float vf = v ? 1.0f : 0.0f;
+    const float x = nx * vf, y = ny * vf;
+    const float r2 = x * x + y * y;
+    float g, dgd;
+    sag_g_dgd(s, r2, g, dgd);
+    const float ft = (g + s.d) - nz;
+    const float dr2dt = 2.0f * (dd * t + dox);
+    const float dfdt = dgd * dr2dt - r.dz;
+    t = t - clampf(ft / (dfdt + eps), -kNewtonStepBound, kNewtonStepBound);
+    nx = r.ox + r.dx * t;
+    ny = r.oy + r.dy * t;
+    rr = nx * nx + ny * ny;
+    v = (rr < s.r2_lim) && (!s.k_gt_m1 || rr < s.lim_loose) && (__builtin_fabsf(ft) < tol_tight) &&
+        alive && (t > 0.0f);
+    t_out = t;
+    return v;
+}
+
+// surfaces.py:633-679 with _normal (:589-630).  FWD: rays travel +z (n negated,
+// eta = n1/n2); !FWD: backward tracing.
+template <bool FWD>
+__device__ __forceinline__ void refract(const DevSurface& s, Ray& r)
+{
+    float nx, ny, nz;
+    if (s.kind == 0) {
+        nx = 0.0f; ny = 0.0f; nz = -1.0f;
+    } else if (s.kind == 1) {
+        if (s.c > 0.0f) {
+            nx = 2.0f * r.ox; ny = 2.0f * r.oy; nz = 2.0f * r.oz - 2.0f * s.d_plus_R;
+        } else {
+            nx = -2.0f * r.ox; ny = -2.0f * r.oy; nz = -2.0f * r.oz + 2.0f * s.d_plus_R;
+        }
+    } else {
+        const float vf = r.ra > 0.0f ? 1.0f : 0.0f;
+        const float xv = r.ox * vf, yv = r.oy * vf;
+        const float ds = sag_dgd_only(s, xv * xv + yv * yv);
+        nx = (ds * 2.0f) * xv; ny = (ds * 2.0f) * yv; nz = -1.0f;
+    }
+    normalize3(nx, ny, nz);
+    if (FWD) { nx = -nx; ny = -ny; nz = -nz; }
+    const float eta = FWD ? s.eta_f : s.eta_b;
+    const float eta2 = FWD ? s.eta2_f : s.eta2_b;
+    const float cosi = (r.dx * nx + r.dy * ny) + r.dz * nz;
+    const float c2i = cosi * cosi;
+    const float omc = 1.0f - c2i;
+    const bool v = (c2i > 0.1f) && (eta2 * omc < 1.0f) && (r.ra > 0.0f);
+    const float vf = v ? 1.0f : 0.0f;
+    const float sr = __builtin_sqrtf(1.0f - (eta2 * omc) * vf);
+    float ndx = sr * nx + eta * (r.dx - cosi * nx);
+    float ndy = sr * ny + eta * (r.dy - cosi * ny);
+    float ndz = sr * nz + eta * (r.dz - cosi * nz);
+    if (!v) { ndx = r.dx; ndy = r.dy; ndz = r.dz; }
+    r.ob = r.ob * ((ndx * r.dx + ndy * r.dy) + ndz * r.dz);
+    r.dx = ndx; r.dy = ndy; r.dz = ndz;
+    r.ra = r.ra * vf;
+}
+
+// Aspheric.ray_reaction, surfaces.py:391-520.  Returns the Newton convergence
+// mask of this ray on this surface (0 for planes).
+template <bool FWD>
+__device__ __forceinline__ uint32_t surface_reaction(const DevSurface& s, Ray& r, int trips)
+{
+    uint32_t mask = 0;
+    if (s.kind == 0) {
+        const float t = (s.d - r.oz) / r.dz;
+        const float nx = r.ox + t * r.dx, ny = r.oy + t * r.dy, nz = r.oz + t * r.dz;
+        const bool v = (__builtin_sqrtf(nx * nx + ny * ny) <= s.r_lim) && (r.ra > 0.0f);
+        if (v) { r.ox = nx; r.oy = ny; r.oz = nz; }
+        r.ra = r.ra * (v ? 1.0f : 0.0f);
+        if (s.do_refract) refract<FWD>(s, r);
+        return 0;
+    }
+    float t;
+    const bool vn = newton(s, r, trips, t, mask);
+    const float nx = r.ox + t * r.dx, ny = r.oy + t * r.dy, nz = r.oz + t * r.dz;
+    bool v;
+    if (s.kind == 1) v = (nx * nx + ny * ny <= s.r2_lim) && (t >= 0.0f) && (r.ra > 0.0f);  // :464
+    else v = vn;                                                                           // :495
+    if (v) { r.ox = nx; r.oy = ny; r.oz = nz; }
+    r.ra = r.ra * (v ? 1.0f : 0.0f);
+    refract<FWD>(s, r);
+    return mask;
+}
+
+// Ray.propagate_to, basics.py:256-264
+__device__ __forceinline__ void propagate_to(Ray& r, float z)
+{
+    const float t = (z - r.oz) / r.dz;
+    r.ox = r.ox + r.dx * t;
+    r.oy = r.oy + r.dy * t;
+    r.oz = r.oz + r.dz * t;
+}
+
+// ---- dual-pixel closed-form sub-pixel weights -------------------------------
+__device__ __forceinline__ float seg(float u)   // u - 1/2*sin(2u), monte_carlo.py:182
+{
+    return u - 0.5f * __ocml_sin_f32(2.0f * u);
+}
+
+// monte_carlo.py:169-206 (r <= 0.5)
+__device__ __forceinline__ void dp_weights_small(const DevDpParams& p, float x_tan, float& sl,
+                                                 float& sr)
+{
+    const float r = p.r, rr = p.rr, fmh = p.fmh;
+    const float fx = p.f * x_tan;
+    float xr = p.w - ((fx - p.w) * p.h) / fmh;
+    float xm = ((-fx) * p.h) / fmh;
+    float xl = (-p.w) - ((fx + p.w) * p.h) / fmh;
+    xr = clampf(xr, -r, r); xm = clampf(xm, -r, r); xl = clampf(xl, -r, r);
+    float ur = __ocml_acos_f32(xr / r), um = __ocml_acos_f32(xm / r), ul = __ocml_acos_f32(xl / r);
+    float sm = seg(um);
+    const float sr_ml = rr * (sm - seg(ur));
+    const float sl_ml = rr * (seg(ul) - sm);
+    const float hx = p.h * x_tan;
+    xr = p.w - hx; xm = 0.0f - hx; xl = (-p.w) - hx;
+    xr = clampf(xr, -0.5f, 0.5f); xm = clampf(xm, -0.5f, 0.5f); xl = clampf(xl, -0.5f, 0.5f);
+    const float xri = clampf(xr, -r, r), xmi = clampf(xm, -r, r), xli = clampf(xl, -r, r);
+    ur = __ocml_acos_f32(xri / r); um = __ocml_acos_f32(xmi / r); ul = __ocml_acos_f32(xli / r);
+    sm = seg(um);
+    const float sr_in = rr * (sm - seg(ur));
+    const float sl_in = rr * (seg(ul) - sm);
+    const float sr_mg = (xr - xm) * 1.0f - sr_in;
+    const float sl_mg = (xm - xl) * 1.0f - sl_in;
+    sr = sr_ml + sr_mg;
+    sl = sl_ml + sl_mg;
+}
+
+// monte_carlo.py:274-338 (r > 0.5)
+__device__ __forceinline__ void dp_weights_big(const DevDpParams& p, float x_tan, float& sl,
+                                               float& sr)
+{
+    const float r = p.r, rr = p.rr, fmh = p.fmh, tr = p.tr, tl = p.tl;
+    const float fx = p.f * x_tan;
+    float xr = p.w - ((fx - p.w) * p.h) / fmh;
+    float xm = ((-fx) * p.h) / fmh;
+    float xl = (-p.w) - ((fx + p.w) * p.h) / fmh;
+    xr = clampf(xr, -0.5f, 0.5f); xm = clampf(xm, -0.5f, 0.5f); xl = clampf(xl, -0.5f, 0.5f);
+    float ur = __ocml_acos_f32(xr / r), um = __ocml_acos_f32(xm / r), ul = __ocml_acos_f32(xl / r);
+    float sm = seg(um);
+    float sr_ml = rr * (sm - seg(ur));
+    float sl_ml = rr * (seg(ul) - sm);
+    float ure = clampf(ur, tr, tl), ume = clampf(um, tr, tl), ule = clampf(ul, tr, tl);
+    float xre = __ocml_cos_f32(ure) * r, xme = __ocml_cos_f32(ume) * r, xle = __ocml_cos_f32(ule) * r;
+    float sme = seg(ume);
+    sr_ml = sr_ml - ((rr * (sme - seg(ure))) - (xre - xme));
+    sl_ml = sl_ml - ((rr * (seg(ule) - sme)) - (xme - xle));
+
+    const float hx = p.h * x_tan;
+    xr = p.w - hx; xm = 0.0f - hx; xl = (-p.w) - hx;
+    xr = clampf(xr, -0.5f, 0.5f); xm = clampf(xm, -0.5f, 0.5f); xl = clampf(xl, -0.5f, 0.5f);
+    ur = __ocml_acos_f32(xr / r); um = __ocml_acos_f32(xm / r); ul = __ocml_acos_f32(xl / r);
+    sm = seg(um);
+    float sr_in = rr * (sm - seg(ur));
+    float sl_in = rr * (seg(ul) - sm);
+    ure = clampf(ur, tr, tl); ume = clampf(um, tr, tl); ule = clampf(ul, tr, tl);
+    xre = __ocml_cos_f32(ure) * r; xme = __ocml_cos_f32(ume) * r; xle = __ocml_cos_f32(ule) * r;
+    sme = seg(ume);
+    sr_in = sr_in - ((rr * (sme - seg(ure))) - (xre - xme));
+    sl_in = sl_in - ((rr * (seg(ule) - sme)) - (xme - xle));
+    const float sr_mg = (xr - xm) * 1.0f - sr_in;
+    const float sl_mg = (xm - xl) * 1.0f - sl_in;
+    sr = sr_ml + sr_mg;
+    sl = sl_ml + sl_mg;
+}
+
+// Splat geometry of one sensor-plane ray (monte_carlo.py:24-38, 209-222):
+// window test, bilinear taps.  Returns false when the ray carries no weight.
+struct SplatTaps {
+    int i_tl, i_tr, i_bl, i_br;     // linear indices into a ks*ks tile
+    float w_tl, w_tr, w_bl, w_br;   // bilinear weight * ra
+};
+
+struct SplatGeom {
+    float lim;      // fp32((ks/2-0.5)*ps - 0.01*ps)              monte_carlo.py:37
+    float x_min;    // fp32((-ks/2+0.5)*ps)
+    float y_max;    // fp32(( ks/2-0.5)*ps)
+    float dx_rng;   // fp32(x_max - x_min)
+    float dy_rng;   // fp32(y_min - y_max)
+    float ksm1;     // ks - 1
+    int32_t ks;
+};
+
+__device__ __forceinline__ bool splat_taps(const SplatGeom& gm, float sx, float sy, float cx,
+                                           float cy, float ra, SplatTaps& tp)
+{
+    float px = (-sx) - cx;                     // points = -o.xy ; points - pointc_ref
+    float py = (-sy) - cy;
+    float w = ra * (__builtin_fabsf(px) < gm.lim ? 1.0f : 0.0f);
+    w = w * (__builtin_fabsf(py) < gm.lim ? 1.0f : 0.0f);
+    if (!(w != 0.0f)) return false;            // adds exact zeros in the reference
+    px = px * w; py = py * w;                  // :38
+    const float pf0 = ((py - gm.y_max) / gm.dy_rng) * gm.ksm1;   // row
+    const float pf1 = ((px - gm.x_min) / gm.dx_rng) * gm.ksm1;   // col
+    const float fl0 = __builtin_floorf(pf0), fl1 = __builtin_floorf(pf1);
+    const float wb = pf0 - fl0, wr = pf1 - fl1;
+    const int r0 = (int)fl0, c0 = (int)fl1;
+    const int r1 = (int)__builtin_floorf(pf0 + 1.0f), c1 = (int)__builtin_floorf(pf1 + 1.0f);
+    const int ks = gm.ks;
+    tp.i_tl = r0 * ks + c0;       tp.w_tl = ((1.0f - wb) * (1.0f - wr)) * w;
+    tp.i_tr = r0 * ks + c1;       tp.w_tr = ((1.0f - wb) * wr) * w;
+    tp.i_bl = r1 * ks + c0;       tp.w_bl = (wb * (1.0f - wr)) * w;
+    tp.i_br = (r0 + 1) * ks + (c0 + 1); tp.w_br = (wb * wr) * w;
+    // The window test keeps every tap inside [0, ks-1]; guard anyway so that a
+    // NaN position can never write outside the tile.
+    const bool ok = r0 >= 0 && c0 >= 0 && r1 < ks && c1 < ks && (r0 + 1) < ks && (c0 + 1) < ks;
+    return ok;
+}
+
+}  // namespace sdirt

@@ -1,0 +1,880 @@
+// sdirt_dp.hip -- kernels and C ABI of libsdirt_dp.so (MI355X / gfx950 only).
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared
+// (sdirt_amd/csrc/Makefile).  See include/sdirt_dp.h for the ABI and DESIGN.md
+// for the data layout and the roofline of each kernel.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/sdirt_dp.h"
+#include "sdirt_device.hpp"
+
+using namespace sdirt;
+
+// ---------------------------------------------------------------------------
+// host-side helpers
+// ---------------------------------------------------------------------------
+struct sdirt_lens {
+    int32_t n_surfaces;
+    DevSurface* dev;               // device table [n_surfaces]
+    std::vector<DevSurface> host;  // host mirror
+};
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(SDIRT_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                                  \
+    } while (0)
+
+#define LAUNCH_CHECK()                                                                  \
+    do {                                                                                \
+        hipError_t e_ = hipGetLastError();                                              \
+        if (e_ != hipSuccess)                                                           \
+            return fail(SDIRT_ERR_HIP, "kernel launch failed: %s (%s:%d)",              \
+                        hipGetErrorString(e_), __FILE__, __LINE__);                     \
+    } while (0)
+
+static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// Per-surface constant block; every double->float rounding happens here, at the
+// same place the reference's torch scalar handling performs it.
+static DevSurface make_dev_surface(const sdirt_surface_desc& in)
+{
+    DevSurface s;
+    std::memset(&s, 0, sizeof(s));
+    s.kind = in.kind;
+    s.ai_degree = in.kind == SDIRT_ASPHERE ? in.ai_degree : 0;
+    s.d = in.d; s.c = in.c; s.k = in.k;
+    s.k_gt_m1 = in.k > -1.0f;
+    s.r_lim = (float)in.r;
+    s.r2_lim = (float)(in.r * in.r);
+    s.c2 = in.c * in.c;
+    s.onepk = 1.0f + in.k;
+    if (in.kind != SDIRT_PLANE) {
+        float rc = 1.0f / s.c2;                       // tensor.reciprocal()
+        rc = rc * (float)(1.0 - 1e-9);                // * python float (1-EPSILON)
+        s.lim_loose = rc / s.onepk;
+        s.d_plus_R = in.d + 1.0f / in.c;
+    }
+    const double eta_f = in.n1 / in.n2, eta_b = in.n2 / in.n1;
+    s.eta_f = (float)eta_f;  s.eta2_f = (float)(eta_f * eta_f);
+    s.eta_b = (float)eta_b;  s.eta2_b = (float)(eta_b * eta_b);
+    s.do_refract = in.kind == SDIRT_PLANE ? (eta_f != 1.0) : 1;
+    for (int i = 0; i < kMaxAi; ++i) {
+        s.ai[i] = i < s.ai_degree ? in.ai[i] : 0.0f;
+        s.kai[i] = (float)(i + 1) * s.ai[i];
+    }
+    return s;
+}
+
+static DevDpParams make_dp(const sdirt_dp_params* dp)
+{
+    DevDpParams p;
+    const double h = dp ? dp->h : 0.78, f = dp ? dp->f : 1.44, w = dp ? dp->w : 0.3,
+                 r = dp ? dp->r : 0.5;
+    p.h = (float)h; p.f = (float)f; p.w = (float)w; p.r = (float)r;
+    p.fmh = (float)(f - h);
+    p.rr = p.r * p.r;
+    p.big = r > 0.5;
+    p.have_r = dp != nullptr;
+    p.tr = std::asin((1.0f / p.r) * 0.5f);
+    p.tl = (float)3.141592653589793 - p.tr;
+    return p;
+}
+
+static SplatGeom make_geom(double ps, int ks)
+{
+    SplatGeom g;
+    const double hi = (ks / 2.0 - 0.5) * ps, lo = (-ks / 2.0 + 0.5) * ps;
+    g.lim = (float)(hi - 0.01 * ps);
+    g.x_min = (float)lo;
+    g.y_max = (float)hi;
+    g.dx_rng = (float)(hi - lo);
+    g.dy_rng = (float)(lo - hi);
+    g.ksm1 = (float)(ks - 1);
+    g.ks = ks;
+    return g;
+}
+
+struct TripTable {
+    int8_t t[SDIRT_MAX_SURFACES];
+};
+
+static int make_trips(const sdirt_lens* lens, const int32_t* trips, TripTable& tt)
+{
+    for (int k = 0; k < SDIRT_MAX_SURFACES; ++k) tt.t[k] = 0;
+    for (int k = 0; k < lens->n_surfaces; ++k) {
+        int v = trips ? trips[k] : SDIRT_NEWTON_MAXITER;
+        if (v < 0 || v > SDIRT_NEWTON_MAXITER)
+            return fail(SDIRT_ERR_INVALID_ARGUMENT, "trips[%d]=%d outside [0,%d]", k, v,
+                        SDIRT_NEWTON_MAXITER);
+        tt.t[k] = (int8_t)v;
+    }
+    return SDIRT_OK;
+}
+
+// ---------------------------------------------------------------------------
+// device helpers shared by the kernels
+// ---------------------------------------------------------------------------
+constexpr int kBlock = 256;
+
+__device__ __forceinline__ Ray load_ray(const sdirt_rays& R, int64_t i)
+{
+    Ray r;
+    r.ox = R.ox[i]; r.oy = R.oy[i]; r.oz = R.oz[i];
+    r.dx = R.dx[i]; r.dy = R.dy[i]; r.dz = R.dz[i];
+    r.ra = R.ra[i];
+    r.ob = R.obliq ? R.obliq[i] : 1.0f;
+    return r;
+}
+
+__device__ __forceinline__ void store_ray(const sdirt_rays& R, int64_t i, const Ray& r)
+{
+    R.ox[i] = r.ox; R.oy[i] = r.oy; R.oz[i] = r.oz;
+    R.dx[i] = r.dx; R.dy[i] = r.dy; R.dz[i] = r.dz;
+    R.ra[i] = r.ra;
+    if (R.obliq) R.obliq[i] = r.ob;
+}
+
+// Trace one ray through surfaces [first,last) in the travel direction.  The
+// per-wave convergence masks are OR-ed into lds_mask[k] by lane 0.
+template <bool FWD>
+__device__ __forceinline__ void trace_ray(const DevSurface* __restrict__ lens, int first, int last,
+                                          const TripTable& trips, Ray& r, uint32_t* lds_mask)
+{
+    const int n = last - first;
+    for (int step = 0; step < n; ++step) {
+        const int k = FWD ? first + step : last - 1 - step;
+        const uint32_t m = surface_reaction<FWD>(lens[k], r, trips.t[k]);
+        if (lds_mask && m != 0u && ((int)__lane_id() == __builtin_ctzll(__ballot(1))))
+            atomicOr(&lds_mask[k], m);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// staged kernels
+// ---------------------------------------------------------------------------
+__global__ void k_points_to_object(const float* __restrict__ pts, int64_t N, float tf, float rl,
+                                   float sw, float sh, float* __restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const float depth = pts[3 * i + 2];
+    const float scale = ((-depth) * tf) / rl;                 // optics.py:1305
+    out[3 * i] = ((pts[3 * i] * scale) * sw) / 2.0f;          // optics.py:959
+    out[3 * i + 1] = ((pts[3 * i + 1] * scale) * sh) / 2.0f;  // optics.py:960
+    out[3 * i + 2] = depth;
+}
+
+__global__ void k_pupil_samples(const float* __restrict__ ut, const float* __restrict__ ur,
+                                int64_t S, float pr2, float* __restrict__ x2,
+                                float* __restrict__ y2)
+{
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    const float theta = (ut[s] * 2.0f) * (float)3.141592653589793;   // optics.py:483
+    const float r = __builtin_sqrtf(ur[s] * pr2);                     // optics.py:484
+    x2[s] = r * __ocml_cos_f32(theta);
+    y2[s] = r * __ocml_sin_f32(theta);
+}
+
+__device__ __forceinline__ Ray make_ray(float px, float py, float pz, float x2, float y2, float z2)
+{
+    Ray r;
+    r.ox = px; r.oy = py; r.oz = pz;
+    r.dx = x2 - px; r.dy = y2 - py; r.dz = z2 - pz;   // optics.py:490
+    normalize3(r.dx, r.dy, r.dz);                       // basics.py:245
+    r.ra = 1.0f; r.ob = 1.0f;
+    return r;
+}
+
+__global__ void k_sample_rays(const float* __restrict__ po, int64_t N, const float* __restrict__ x2,
+                              const float* __restrict__ y2, int64_t S, float pz, sdirt_rays R)
+{
+    const int64_t M = S * N;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t s = i / N, n = i - s * N;
+        Ray r = make_ray(po[3 * n], po[3 * n + 1], po[3 * n + 2], x2[s], y2[s], pz);
+        store_ray(R, i, r);
+    }
+}
+
+__global__ void k_rays_from_aos(const float* __restrict__ o, const float* __restrict__ d,
+                                const float* __restrict__ ra, int64_t M, int normalize, sdirt_rays R)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        Ray r;
+        r.ox = o[3 * i]; r.oy = o[3 * i + 1]; r.oz = o[3 * i + 2];
+        r.dx = d[3 * i]; r.dy = d[3 * i + 1]; r.dz = d[3 * i + 2];
+        if (normalize) normalize3(r.dx, r.dy, r.dz);
+        r.ra = ra ? ra[i] : 1.0f;
+        r.ob = 1.0f;
+        store_ray(R, i, r);
+    }
+}
+
+__global__ void k_rays_to_aos(sdirt_rays R, int64_t M, float* __restrict__ o, float* __restrict__ d)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        if (o) { o[3 * i] = R.ox[i]; o[3 * i + 1] = R.oy[i]; o[3 * i + 2] = R.oz[i]; }
+        if (d) { d[3 * i] = R.dx[i]; d[3 * i + 1] = R.dy[i]; d[3 * i + 2] = R.dz[i]; }
+    }
+}
+
+template <bool FWD>
+__global__ void __launch_bounds__(kBlock)
+k_trace(const DevSurface* __restrict__ lens, int K, int first, int last, TripTable trips,
+        sdirt_rays R, int64_t M, uint32_t* __restrict__ conv_mask)
+{
+    __shared__ uint32_t lds_mask[SDIRT_MAX_SURFACES];
+    if (threadIdx.x < SDIRT_MAX_SURFACES) lds_mask[threadIdx.x] = 0;
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        Ray r = load_ray(R, i);
+        trace_ray<FWD>(lens, first, last, trips, r, conv_mask ? lds_mask : nullptr);
+        store_ray(R, i, r);
+    }
+    __syncthreads();
+    if (conv_mask && (int)threadIdx.x < K && lds_mask[threadIdx.x])
+        atomicOr(&conv_mask[threadIdx.x], lds_mask[threadIdx.x]);
+}
+
+__global__ void k_propagate(float z, sdirt_rays R, int64_t M)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const float dz = R.dz[i];
+        const float t = (z - R.oz[i]) / dz;
+        R.ox[i] = R.ox[i] + R.dx[i] * t;
+        R.oy[i] = R.oy[i] + R.dy[i] * t;
+        R.oz[i] = R.oz[i] + dz * t;
+    }
+}
+
+// Centroid over the spp axis with fp64 accumulation; one thread per point so
+// that consecutive lanes read consecutive addresses of the [S,N] arrays.
+__global__ void k_center_from_rays(sdirt_rays R, int64_t S, int64_t N, float* __restrict__ center,
+                                   int32_t* __restrict__ any_valid)
+{
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    double sx = 0.0, sy = 0.0, sr = 0.0;
+    int any = 0;
+    for (int64_t s = 0; s < S; ++s) {
+        const int64_t i = s * N + n;
+        const float ra = R.ra[i];
+        sx += (double)(R.ox[i] * ra);
+        sy += (double)(R.oy[i] * ra);
+        sr += (double)ra;
+        any |= (ra == 1.0f);
+    }
+    const float den = (float)sr + (float)1e-9;
+    center[2 * n] = -((float)sx / den);
+    center[2 * n + 1] = -((float)sy / den);
+    if (any_valid && any) atomicOr(any_valid, 1);
+}
+
+// forward_integral on SoA [S,N] rays: one thread per ray (coalesced reads),
+// contributions added to the pre-zeroed [N,ks,ks] grids with global float
+// atomics -- consecutive lanes are consecutive POINTS, so the 64 atomics of a
+// wave instruction go to 64 different tiles.
+__global__ void __launch_bounds__(kBlock)
+k_forward_integral(sdirt_rays R, int64_t S, int64_t N, SplatGeom gm, DevDpParams dp,
+                   const float* __restrict__ center, float* __restrict__ lg,
+                   float* __restrict__ rg)
+{
+    const int64_t M = S * N;
+    const int64_t tile = (int64_t)gm.ks * gm.ks;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t n = i % N;
+        SplatTaps tp;
+        if (!splat_taps(gm, R.ox[i], R.oy[i], center[2 * n], center[2 * n + 1], R.ra[i], tp))
+            continue;
+        const float x_tan = (-R.dx[i]) / R.dz[i];    // monte_carlo.py:48
+        float sl, sr;
+        if (dp.big) dp_weights_big(dp, x_tan, sl, sr);
+        else dp_weights_small(dp, x_tan, sl, sr);
+        float* L = lg + n * tile;
+        atomicAdd(L + tp.i_tl, tp.w_tl * sl);
+        atomicAdd(L + tp.i_tr, tp.w_tr * sl);
+        atomicAdd(L + tp.i_bl, tp.w_bl * sl);
+        atomicAdd(L + tp.i_br, tp.w_br * sl);
+        if (rg && dp.have_r) {
+            float* Rr = rg + n * tile;
+            atomicAdd(Rr + tp.i_tl, tp.w_tl * sr);
+            atomicAdd(Rr + tp.i_tr, tp.w_tr * sr);
+            atomicAdd(Rr + tp.i_bl, tp.w_bl * sr);
+            atomicAdd(Rr + tp.i_br, tp.w_br * sr);
+        }
+    }
+}
+
+__device__ __forceinline__ float block_max(float v, float* red)
+{
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    const int wave = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[wave] = v;
+    __syncthreads();
+    float m = red[0];
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) m = fmaxf(m, red[w]);
+    return m;
+}
+
+// optics.py:983-987: one workgroup per point.
+__global__ void __launch_bounds__(kBlock) k_psf_normalize(float* __restrict__ psf, int tile)
+{
+    __shared__ float red[kBlock / 64];
+    float* g = psf + (int64_t)blockIdx.x * tile;
+    float mx = -INFINITY;
+    for (int i = threadIdx.x; i < tile; i += blockDim.x) mx = fmaxf(mx, g[i]);
+    mx = block_max(mx, red);
+    const float den = mx + 1e-6f;
+    for (int i = threadIdx.x; i < tile; i += blockDim.x) g[i] = g[i] / den;
+}
+
+// ---------------------------------------------------------------------------
+// fused kernels
+// ---------------------------------------------------------------------------
+
+// psf_center: one workgroup per point, Sc rays, fp64 partial sums reduced in a
+// fixed order (deterministic).
+__global__ void __launch_bounds__(kBlock)
+k_chief_center(const DevSurface* __restrict__ lens, int K, TripTable trips,
+               const float* __restrict__ po, const float* __restrict__ xc,
+               const float* __restrict__ yc, int Sc, float pz, float zs,
+               float* __restrict__ center, int32_t* __restrict__ any_valid,
+               uint32_t* __restrict__ conv_mask)
+{
+    __shared__ uint32_t lds_mask[SDIRT_MAX_SURFACES];
+    __shared__ double red[3][kBlock];
+    __shared__ int red_any;
+    const int n = blockIdx.x;
+    if (threadIdx.x < SDIRT_MAX_SURFACES) lds_mask[threadIdx.x] = 0;
+    if (threadIdx.x == 0) red_any = 0;
+    __syncthreads();
+    const float px = po[3 * n], py = po[3 * n + 1], pzo = po[3 * n + 2];
+    double sx = 0.0, sy = 0.0, sr = 0.0;
+    int any = 0;
+    for (int s = threadIdx.x; s < Sc; s += blockDim.x) {
+        Ray r = make_ray(px, py, pzo, xc[s], yc[s], pz);
+        trace_ray<true>(lens, 0, K, trips, r, conv_mask ? lds_mask : nullptr);
+        propagate_to(r, zs);
+        sx += (double)(r.ox * r.ra);
+        sy += (double)(r.oy * r.ra);
+        sr += (double)r.ra;
+        any |= (r.ra == 1.0f);
+    }
+    red[0][threadIdx.x] = sx; red[1][threadIdx.x] = sy; red[2][threadIdx.x] = sr;
+    if (any) red_any = 1;
+    __syncthreads();
+    for (int off = kBlock / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + off];
+            red[1][threadIdx.x] += red[1][threadIdx.x + off];
+            red[2][threadIdx.x] += red[2][threadIdx.x + off];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float den = (float)red[2][0] + (float)1e-9;
+        center[2 * n] = -((float)red[0][0] / den);
+        center[2 * n + 1] = -((float)red[1][0] / den);
+        if (any_valid && red_any) atomicOr(any_valid, 1);
+    }
+    if (conv_mask && (int)threadIdx.x < K && lds_mask[threadIdx.x])
+        atomicOr(&conv_mask[threadIdx.x], lds_mask[threadIdx.x]);
+}
+
+// psf_diff fused: sample -> trace -> propagate -> window -> DP weights -> LDS
+// splat -> (max-normalise) -> store.  gridDim.x = N * nsplit; the workgroup
+// (n, j) handles samples [j*chunk, (j+1)*chunk) of point n.
+//   nsplit == 1 : the tile is complete in LDS -> normalise (flag) and store.
+//   nsplit  > 1 : tiles are added to the pre-zeroed output with global float
+//                 atomics; the caller normalises afterwards.
+template <bool HAVE_R>
+__global__ void __launch_bounds__(kBlock)
+k_psf_lr(const DevSurface* __restrict__ lens, int K, TripTable trips,
+         const float* __restrict__ po, const float* __restrict__ x2, const float* __restrict__ y2,
+         int S, int nsplit, int chunk, float pz, float zs, SplatGeom gm, DevDpParams dp,
+         const float* __restrict__ center, uint32_t flags, float* __restrict__ lout,
+         float* __restrict__ rout, uint32_t* __restrict__ conv_mask)
+{
+    extern __shared__ __attribute__((aligned(16))) float tiles[];   // [L | R] ks*ks each
+    __shared__ uint32_t lds_mask[SDIRT_MAX_SURFACES];
+    __shared__ float red[kBlock / 64];
+    const int tile = gm.ks * gm.ks;
+    float* tl = tiles;
+    float* trr = tiles + tile;
+    const int n = blockIdx.x / nsplit;
+    const int j = blockIdx.x - n * nsplit;
+
+    for (int i = threadIdx.x; i < (HAVE_R ? 2 : 1) * tile; i += blockDim.x) tiles[i] = 0.0f;
+    if (threadIdx.x < SDIRT_MAX_SURFACES) lds_mask[threadIdx.x] = 0;
+    __syncthreads();
+
+    const float px = po[3 * n], py = po[3 * n + 1], pzo = po[3 * n + 2];
+    const float cx = center[2 * n], cy = center[2 * n + 1];
+    const int s_end = min(S, (j + 1) * chunk);
+    for (int s = j * chunk + threadIdx.x; s < s_end; s += blockDim.x) {
+        Ray r = make_ray(px, py, pzo, x2[s], y2[s], pz);
+        trace_ray<true>(lens, 0, K, trips, r, conv_mask ? lds_mask : nullptr);
+        propagate_to(r, zs);
+        SplatTaps tp;
+        if (!splat_taps(gm, r.ox, r.oy, cx, cy, r.ra, tp)) continue;
+        const float x_tan = (-r.dx) / r.dz;
+        float sl, sr;
+        if (dp.big) dp_weights_big(dp, x_tan, sl, sr);
+        else dp_weights_small(dp, x_tan, sl, sr);
+        atomicAdd(&tl[tp.i_tl], tp.w_tl * sl);
+        atomicAdd(&tl[tp.i_tr], tp.w_tr * sl);
+        atomicAdd(&tl[tp.i_bl], tp.w_bl * sl);
+        atomicAdd(&tl[tp.i_br], tp.w_br * sl);
+        if (HAVE_R) {
+            atomicAdd(&trr[tp.i_tl], tp.w_tl * sr);
+            atomicAdd(&trr[tp.i_tr], tp.w_tr * sr);
+            atomicAdd(&trr[tp.i_bl], tp.w_bl * sr);
+            atomicAdd(&trr[tp.i_br], tp.w_br * sr);
+        }
+    }
+    __syncthreads();
+
+    float* Lg = lout + (int64_t)n * tile;
+    float* Rg = HAVE_R ? rout + (int64_t)n * tile : nullptr;
+    if (nsplit == 1) {
+        float denl = 1.0f, denr = 1.0f;
+        if (flags & SDIRT_PSF_NORMALIZE) {
+            float mx = -INFINITY;
+            for (int i = threadIdx.x; i < tile; i += blockDim.x) mx = fmaxf(mx, tl[i]);
+            denl = block_max(mx, red) + 1e-6f;
+            if (HAVE_R) {
+                mx = -INFINITY;
+                for (int i = threadIdx.x; i < tile; i += blockDim.x) mx = fmaxf(mx, trr[i]);
+                denr = block_max(mx, red) + 1e-6f;
+            }
+            for (int i = threadIdx.x; i < tile; i += blockDim.x) {
+                Lg[i] = tl[i] / denl;
+                if (HAVE_R) Rg[i] = trr[i] / denr;
+            }
+        } else {
+            for (int i = threadIdx.x; i < tile; i += blockDim.x) {
+                Lg[i] = tl[i];
+                if (HAVE_R) Rg[i] = trr[i];
+            }
+        }
+    } else {
+        for (int i = threadIdx.x; i < tile; i += blockDim.x) {
+            const float a = tl[i];
+            if (a != 0.0f) atomicAdd(&Lg[i], a);
+            if (HAVE_R) {
+                const float b = trr[i];
+                if (b != 0.0f) atomicAdd(&Rg[i], b);
+            }
+        }
+    }
+    if (conv_mask && (int)threadIdx.x < K && lds_mask[threadIdx.x])
+        atomicOr(&conv_mask[threadIdx.x], lds_mask[threadIdx.x]);
+}
+
+// ---------------------------------------------------------------------------
+// per-pixel PSF convolution (render_psf.py:76-188)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float round_half(float v) { return (float)(_Float16)v; }
+
+// One thread per output pixel (b, y, x); loops over the ks*ks taps once and
+// accumulates all channels of L and R.  The per-pixel kernels are read with the
+// flipped index (render_psf.py:138) so that consecutive lanes (consecutive x)
+// read consecutive ks*ks*2 blocks.
+template <int C, bool HALF>
+__global__ void __launch_bounds__(kBlock)
+k_local_psf_render(const float* __restrict__ img, const float* __restrict__ psf, int B, int H, int W,
+                   int ks, float* __restrict__ outl, float* __restrict__ outr)
+{
+    const int64_t HW = (int64_t)H * W;
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= (int64_t)B * HW) return;
+    const int b = (int)(p / HW);
+    const int64_t q = p - (int64_t)b * HW;
+    const int y = (int)(q / W), x = (int)(q - (int64_t)y * W);
+    const int pad = (ks - 1) / 2, kk = ks * ks;
+    const float* kl = psf + p * 2 * kk;
+    const float* kr = kl + kk;
+    float accl[C], accr[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) { accl[c] = 0.0f; accr[c] = 0.0f; }
+    for (int i = 0; i < ks; ++i) {
+        const int yy = min(max(y + i - pad, 0), H - 1);          // replicate padding
+        for (int jx = 0; jx < ks; ++jx) {
+            const int xx = min(max(x + jx - pad, 0), W - 1);
+            const int f = (ks - 1 - i) * ks + (ks - 1 - jx);     // flipped kernel tap
+            float wl = kl[f], wr = kr[f];
+            if (HALF) { wl = round_half(wl); wr = round_half(wr); }
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                float v = img[((int64_t)(b * C + c) * H + yy) * W + xx];
+                if (HALF) {
+                    v = round_half(v);
+                    accl[c] += round_half(v * wl);
+                    accr[c] += round_half(v * wr);
+                } else {
+                    accl[c] += v * wl;
+                    accr[c] += v * wr;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const int64_t o = ((int64_t)(b * C + c) * H + y) * W + x;
+        outl[o] = HALF ? round_half(accl[c]) : accl[c];
+        outr[o] = HALF ? round_half(accr[c]) : accr[c];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------
+static inline int grid_for(int64_t work, int block, int cap = 256 * 16)
+{
+    int64_t g = (work + block - 1) / block;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+extern "C" {
+
+int sdirt_abi_version(void) { return SDIRT_ABI_VERSION; }
+
+const char* sdirt_last_error(void) { return g_err; }
+
+int sdirt_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int sdirt_lens_create(const sdirt_surface_desc* surfaces, int32_t n_surfaces, sdirt_lens** out)
+{
+    if (!surfaces || !out) return fail(SDIRT_ERR_INVALID_ARGUMENT, "null argument");
+    if (n_surfaces < 1 || n_surfaces > SDIRT_MAX_SURFACES)
+        return fail(SDIRT_ERR_INVALID_ARGUMENT, "n_surfaces=%d outside [1,%d]", n_surfaces,
+                    SDIRT_MAX_SURFACES);
+    for (int i = 0; i < n_surfaces; ++i) {
+        const sdirt_surface_desc& s = surfaces[i];
+        if (s.kind < SDIRT_PLANE || s.kind > SDIRT_ASPHERE)
+            return fail(SDIRT_ERR_INVALID_ARGUMENT, "surface %d: unknown kind %d", i, s.kind);
+        if (s.ai_degree < 0 || s.ai_degree > SDIRT_MAX_AI)
+            return fail(SDIRT_ERR_INVALID_ARGUMENT, "surface %d: ai_degree %d outside [0,%d]", i,
+                        s.ai_degree, SDIRT_MAX_AI);
+        if ((s.kind == SDIRT_PLANE) != (s.c == 0.0f))
+            return fail(SDIRT_ERR_INVALID_ARGUMENT,
+                        "surface %d: kind/curvature mismatch (plane <=> c == 0)", i);
+        if (!(s.n1 > 0.0) || !(s.n2 > 0.0))
+            return fail(SDIRT_ERR_INVALID_ARGUMENT, "surface %d: refractive index <= 0", i);
+    }
+    sdirt_lens* L = new (std::nothrow) sdirt_lens();
+    if (!L) return fail(SDIRT_ERR_HIP, "out of host memory");
+    L->n_surfaces = n_surfaces;
+    L->dev = nullptr;
+    L->host.resize(n_surfaces);
+    for (int i = 0; i < n_surfaces; ++i) L->host[i] = make_dev_surface(surfaces[i]);
+    hipError_t e = hipMalloc(&L->dev, sizeof(DevSurface) * n_surfaces);
+    if (e == hipSuccess)
+        e = hipMemcpy(L->dev, L->host.data(), sizeof(DevSurface) * n_surfaces,
+                      hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        if (L->dev) (void)hipFree(L->dev);
+        delete L;
+        return fail(e == hipErrorNoDevice ? SDIRT_ERR_NO_DEVICE : SDIRT_ERR_HIP,
+                    "lens upload failed: %s", hipGetErrorString(e));
+    }
+    *out = L;
+    return SDIRT_OK;
+}
+
+void sdirt_lens_destroy(sdirt_lens* lens)
+{
+    if (!lens) return;
+    if (lens->dev) (void)hipFree(lens->dev);
+    delete lens;
+}
+
+int32_t sdirt_lens_num_surfaces(const sdirt_lens* lens) { return lens ? lens->n_surfaces : 0; }
+
+int sdirt_points_to_object(const float* points, int64_t N, double tan_hfov, double r_last,
+                           double sensor_w, double sensor_h, float* point_obj, void* stream)
+{
+    if (!points || !point_obj || N < 0) return fail(SDIRT_ERR_INVALID_ARGUMENT, "bad argument");
+    if (N == 0) return SDIRT_OK;
+    k_points_to_object<<<grid_for(N, kBlock, 1 << 30), kBlock, 0, as_stream(stream)>>>(
+        points, N, (float)tan_hfov, (float)r_last, (float)sensor_w, (float)sensor_h, point_obj);
+    LAUNCH_CHECK();
+    return SDIRT_OK;
+}
+
+int sdirt_pupil_samples(const float* u_theta, const float* u_r2, int64_t S, double pupil_r,
+                        float* x2, float* y2, void* stream)
+{
+    if (!u_theta || !u_r2 || !x2 || !y2 || S < 0)
+        return fail(SDIRT_ERR_INVALID_ARGUMENT, "bad argument");
+    if (S == 0) return SDIRT_OK;
+    k_pupil_samples<<<grid_for(S, kBlock, 1 << 30), kBlock, 0, as_stream(stream)>>>(
+        u_theta, u_r2, S, (float)(pupil_r * pupil_r), x2, y2);
+    LAUNCH_CHECK();
+    return SDIRT_OK;
+}
+
+static int check_rays(const sdirt_rays& R)
+{
+    if (!R.ox || !R.oy || !R.oz || !R.dx || !R.dy || !R.dz || !R.ra)
+        return fail(SDIRT_ERR_INVALID_ARGUMENT, "sdirt_rays has a null array");
+    return SDIRT_OK;
+}
+
+int sdirt_sample_rays(const float* point_obj, int64_t N, const float* x2, const float* y2, int64_t S,
+                      double pupil_z, sdirt_rays rays, void* stream)
+{
+    if (!point_obj || !x2 || !y2 || N < 0 || S < 0)
+        return fail(SDIRT_ERR_INVALID_ARGUMENT, "bad argument");
+    if (int rc = check_rays(rays)) return rc;
+    if (N * S == 0) return SDIRT_OK;
+    k_sample_rays<<<grid_for(N * S, kBlock), kBlock, 0, as_stream(stream)>>>(
+        point_obj, N, x2, y2, S, (float)pupil_z, rays);
+    LAUNCH_CHECK();
+    return SDIRT_OK;
+}
+
+int sdirt_rays_from_aos(const float* o, const float* d, const float* ra, int64_t M, int32_t normalize,
+                        sdirt_rays rays, void* stream)
+{
+    if (!o || !d || M < 0) return fail(SDIRT_ERR_INVALID_ARGUMENT, "bad argument");
+    if (int rc = check_rays(rays)) return rc;
+    if (M == 0) return SDIRT_OK;
+    k_rays_from_aos<<<grid_for(M, kBlock), kBlock, 0, as_stream(stream)>>>(o, d, ra, M, normalize,
+                                                                           rays);
+    LAUNCH_CHECK();
+    return SDIRT_OK;
+}
+
+int sdirt_rays_to_aos(sdirt_rays rays, int64_t M, float* o, float* d, void* stream)
+{
+    if (M < 0) return fail(SDIRT_ERR_INVALID_ARGUMENT, "n_rays < 0");
+    if (int rc = check_rays(rays)) return rc;
+    if (M == 0 || (!o && !d)) return SDIRT_OK;
+    k_rays_to_aos<<<grid_for(M, kBlock), kBlock, 0, as_stream(stream)>>>(rays, M, o, d);
+    LAUNCH_CHECK();
+    return SDIRT_OK;
+}
+
+int sdirt_trace(const sdirt_lens* lens, int32_t first, int32_t last, int32_t backward,
+                const int32_t* trips, sdirt_rays rays, int64_t M, uint32_t* conv_mask, void* stream)
+{
+    if (!lens) return fail(SDIRT_ERR_INVALID_ARGUMENT, "null lens");
+    if (first < 0 || last > lens->n_surfaces || first > last)
+        return fail(SDIRT_ERR_INVALID_ARGUMENT, "surface range [%d,%d) outside [0,%d]", first, last,
+                    lens->n_surfaces);
+    if (int rc = check_rays(rays)) return rc;
+    TripTable tt;
+    if (int rc = make_trips(lens, trips, tt)) return rc;
+    if (M <= 0 || first == last) return M < 0 ? fail(SDIRT_ERR_INVALID_ARGUMENT, "n_rays < 0") : SDIRT_OK;
+    const int grid = grid_for(M, kBlock);
+    if (backward)
+        k_trace<false><<<grid, kBlock, 0, as_stream(stream)>>>(lens->dev, lens->n_surfaces, first,
+                                                               last, tt, rays, M, conv_mask);
+    else
+        k_trace<true><<<grid, kBlock, 0, as_stream(stream)>>>(lens->dev, lens->n_surfaces, first,
+                                                              last, tt, rays, M, conv_mask);
+    LAUNCH_CHECK();
+    return SDIRT_OK;
+}
+
+int sdirt_propagate_to(double z, sdirt_rays rays, int64_t M, void* stream)
+{
+    if (int rc = check_rays(rays)) return rc;
+    if (M <= 0) return M < 0 ? fail(SDIRT_ERR_INVALID_ARGUMENT, "n_rays < 0") : SDIRT_OK;
+    k_propagate<<<grid_for(M, kBlock), kBlock, 0, as_stream(stream)>>>((float)z, rays, M);
+    LAUNCH_CHECK();
+    return SDIRT_OK;
+}
+
+int sdirt_center_from_rays(sdirt_rays rays, int64_t S, int64_t N, float* center, int32_t* any_valid,
+                           void* stream)
+{
+    if (int rc = check_rays(rays)) return rc;
+    if (!center || S < 0 || N < 0) return fail(SDIRT_ERR_INVALID_ARGUMENT, "bad argument");
+    if (N == 0) return SDIRT_OK;
+    k_center_from_rays<<<grid_for(N, 64, 1 << 30), 64, 0, as_stream(stream)>>>(rays, S, N, center,
+                                                                               any_valid);
+    LAUNCH_CHECK();
+    return SDIRT_OK;
+}
+
+static int check_ks(int ks)
+{
+    if (ks < 2 || ks > SDIRT_MAX_KS)
+        return fail(SDIRT_ERR_INVALID_ARGUMENT, "ks=%d outside [2,%d]", ks, SDIRT_MAX_KS);
+    return SDIRT_OK;
+}
+
+int sdirt_forward_integral(sdirt_rays rays, int64_t S, int64_t N, double ps, int32_t ks,
+                           const float* center, const sdirt_dp_params* dp, float* l_grid,
+                           float* r_grid, void* stream)
+{
+    if (int rc = check_rays(rays)) return rc;
+    if (int rc = check_ks(ks)) return rc;
+    if (!center || !l_grid || S < 0 || N < 0) return fail(SDIRT_ERR_INVALID_ARGUMENT, "bad argument");
+    if (dp && !(dp->r > 0.0)) return fail(SDIRT_ERR_INVALID_ARGUMENT, "dp->r must be > 0");
+    if (N == 0) return SDIRT_OK;
+    const size_t bytes = sizeof(float) * (size_t)N * ks * ks;
+    HIP_TRY(hipMemsetAsync(l_grid, 0, bytes, as_stream(stream)));
+    if (r_grid) HIP_TRY(hipMemsetAsync(r_grid, 0, bytes, as_stream(stream)));
+    if (S == 0) return SDIRT_OK;
+    k_forward_integral<<<grid_for(S * N, kBlock), kBlock, 0, as_stream(stream)>>>(
+        rays, S, N, make_geom(ps, ks), make_dp(dp), center, l_grid, r_grid);
+    LAUNCH_CHECK();
+    return SDIRT_OK;
+}
+
+int sdirt_psf_normalize(float* psf, int64_t N, int32_t ks, void* stream)
+{
+    if (!psf || N < 0) return fail(SDIRT_ERR_INVALID_ARGUMENT, "bad argument");
+    if (ks < 1) return fail(SDIRT_ERR_INVALID_ARGUMENT, "ks < 1");
+    if (N == 0) return SDIRT_OK;
+    k_psf_normalize<<<(int)N, kBlock, 0, as_stream(stream)>>>(psf, ks * ks);
+    LAUNCH_CHECK();
+    return SDIRT_OK;
+}
+
+int sdirt_chief_center(const sdirt_lens* lens, const float* point_obj, int64_t N, const float* xc,
+                       const float* yc, int64_t Sc, double pupil_z, double d_sensor,
+                       const int32_t* trips, float* center, int32_t* any_valid,
+                       uint32_t* conv_mask, void* stream)
+{
+    if (!lens || !point_obj || !xc || !yc || !center || N < 0 || Sc < 0 || Sc > (1ll << 30))
+        return fail(SDIRT_ERR_INVALID_ARGUMENT, "bad argument");
+    TripTable tt;
+    if (int rc = make_trips(lens, trips, tt)) return rc;
+    if (N == 0) return SDIRT_OK;
+    k_chief_center<<<(int)N, kBlock, 0, as_stream(stream)>>>(
+        lens->dev, lens->n_surfaces, tt, point_obj, xc, yc, (int)Sc, (float)pupil_z,
+        (float)d_sensor, center, any_valid, conv_mask);
+    LAUNCH_CHECK();
+    return SDIRT_OK;
+}
+
+int sdirt_psf_lr(const sdirt_lens* lens, const float* point_obj, int64_t N, const float* x2,
+                 const float* y2, int64_t S, double pupil_z, double d_sensor, double ps, int32_t ks,
+                 const float* center, const sdirt_dp_params* dp, const int32_t* trips,
+                 uint32_t flags, float* l_psf, float* r_psf, uint32_t* conv_mask, void* stream)
+{
+    if (!lens || !point_obj || !x2 || !y2 || !center || !l_psf || N < 0 || S < 0 ||
+        S > (1ll << 30) || N > (1ll << 30))
+        return fail(SDIRT_ERR_INVALID_ARGUMENT, "bad argument");
+    if (int rc = check_ks(ks)) return rc;
+    if (dp && !(dp->r > 0.0)) return fail(SDIRT_ERR_INVALID_ARGUMENT, "dp->r must be > 0");
+    TripTable tt;
+    if (int rc = make_trips(lens, trips, tt)) return rc;
+    if (N == 0) return SDIRT_OK;
+    const bool have_r = r_psf != nullptr;
+    const int tile = ks * ks;
+    const size_t lds = sizeof(float) * tile * (have_r ? 2 : 1);
+
+    // Fill the chip: at least ~4 workgroups per CU; split the spp axis when the
+    // number of points alone cannot (e.g. PSFNet training: N=64, S=20000).
+    int nsplit = 1;
+    const int64_t want_blocks = 256 * 4;
+    if (N < want_blocks && S > 2 * kBlock) {
+        nsplit = (int)((want_blocks + N - 1) / N);
+        const int max_split = (int)((S + 2 * kBlock - 1) / (2 * kBlock));
+        if (nsplit > max_split) nsplit = max_split;
+        if (nsplit < 1) nsplit = 1;
+    }
+    int chunk = (int)((S + nsplit - 1) / nsplit);
+    chunk = ((chunk + kBlock - 1) / kBlock) * kBlock;
+    nsplit = (int)((S + chunk - 1) / (chunk > 0 ? chunk : 1));
+    if (nsplit < 1) nsplit = 1;
+
+    hipStream_t st = as_stream(stream);
+    if (nsplit > 1) {
+        HIP_TRY(hipMemsetAsync(l_psf, 0, sizeof(float) * (size_t)N * tile, st));
+        if (have_r) HIP_TRY(hipMemsetAsync(r_psf, 0, sizeof(float) * (size_t)N * tile, st));
+    }
+    const SplatGeom gm = make_geom(ps, ks);
+    const DevDpParams dpp = make_dp(dp);
+    const int grid = (int)(N * nsplit);
+    if (have_r && dpp.have_r)
+        k_psf_lr<true><<<grid, kBlock, lds, st>>>(lens->dev, lens->n_surfaces, tt, point_obj, x2, y2,
+                                                   (int)S, nsplit, chunk, (float)pupil_z,
+                                                   (float)d_sensor, gm, dpp, center, flags, l_psf,
+                                                   r_psf, conv_mask);
+    else {
+        k_psf_lr<false><<<grid, kBlock, sizeof(float) * tile, st>>>(
+            lens->dev, lens->n_surfaces, tt, point_obj, x2, y2, (int)S, nsplit, chunk,
+            (float)pupil_z, (float)d_sensor, gm, dpp, center, flags, l_psf, nullptr, conv_mask);
+        // param_list=None leaves the R grid all-zero (monte_carlo.py:230-235)
+        if (have_r) HIP_TRY(hipMemsetAsync(r_psf, 0, sizeof(float) * (size_t)N * tile, st));
+    }
+    LAUNCH_CHECK();
+    if (nsplit > 1 && (flags & SDIRT_PSF_NORMALIZE)) {
+        k_psf_normalize<<<(int)N, kBlock, 0, st>>>(l_psf, tile);
+        if (have_r && dpp.have_r) k_psf_normalize<<<(int)N, kBlock, 0, st>>>(r_psf, tile);
+        LAUNCH_CHECK();
+    }
+    return SDIRT_OK;
+}
+
+int sdirt_local_psf_render(const float* img, const float* psf, int32_t B, int32_t C, int32_t H,
+                           int32_t W, int32_t ks, int32_t half_precision, float* out_l, float* out_r,
+                           void* stream)
+{
+    if (!img || !psf || !out_l || !out_r || B < 0 || H < 1 || W < 1 || ks < 1 || (ks & 1) == 0)
+        return fail(SDIRT_ERR_INVALID_ARGUMENT, "bad argument (ks must be odd)");
+    if (B == 0) return SDIRT_OK;
+    const int64_t P = (int64_t)B * H * W;
+    const int grid = (int)((P + kBlock - 1) / kBlock);
+    hipStream_t st = as_stream(stream);
+#define SDIRT_RENDER(CC)                                                                        \
+    do {                                                                                        \
+        if (half_precision)                                                                     \
+            k_local_psf_render<CC, true><<<grid, kBlock, 0, st>>>(img, psf, B, H, W, ks, out_l, out_r); \
+        else                                                                                    \
+            k_local_psf_render<CC, false><<<grid, kBlock, 0, st>>>(img, psf, B, H, W, ks, out_l, out_r); \
+    } while (0)
+    switch (C) {
+    case 1: SDIRT_RENDER(1); break;
+    case 3: SDIRT_RENDER(3); break;
+    case 4: SDIRT_RENDER(4); break;
+    default: return fail(SDIRT_ERR_UNSUPPORTED, "channels=%d (supported: 1, 3, 4)", C);
+    }
+#undef SDIRT_RENDER
+    LAUNCH_CHECK();
+    return SDIRT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,102 @@
+"""Host logic that reproduces the reference's batch-global Newton trip counts.
+
+In the reference, Aspheric._newtons_method iterates
+`while (abs(ft) > 50e-6).any() and it < 10` over the WHOLE ray tensor
+(deeplens/surfaces.py:547): every ray of a call runs the same number of trips
+on a surface, and that number depends on the slowest ray of the batch.  A
+per-ray GPU kernel cannot ask "has any ray in 67 million not converged?" after
+every iteration without a grid-wide synchronisation, so the kernels take the
+trip table as an ARGUMENT and report, per surface, a bitmask OR-ed over all rays
+(bit j: some ray still had |f(t)| > 50e-6 in trip j).  From the mask the host
+can tell whether the table it speculated is exactly the one the reference's
+loop would have produced for this batch:
+
+    T is right for a surface  <=>  bits 1..T-1 are set and (bit T is clear or T == 10),
+    provided every surface upstream was right (their output rays feed this one).
+
+`TripPlanner.run` speculates (cached table from the last call, or a cheap pilot
+launch), launches, verifies, and re-launches only when the verification fails;
+in steady state (same lens, similar batches) that is one launch per call plus
+one K-word readback -- the reference synchronises on every Newton iteration.
+"""
+import numpy as np
+
+NEWTON_MAXITER = 10
+
+
+def first_clear_bit(mask, upto):
+    """Smallest j in 1..upto whose bit is clear in mask, or None."""
+    for j in range(1, upto + 1):
+        if not (mask >> j) & 1:
+            return j
+    return None
+
+
+def verify(trips, masks, order, curved):
+    """Check a speculated trip table against the convergence masks it produced.
+
+    trips[k]  : trips run on surface k
+    masks[k]  : OR over all rays of (1<<j) for trips j where |f| > 50e-6
+    order     : surface indices in traversal order
+    curved[k] : False for planes (no Newton solve, surfaces.py:409)
+
+    Returns (ok, new_trips).  When not ok, new_trips holds the corrected count
+    for the first wrong surface and best guesses (from the same masks) for the
+    surfaces after it.
+    """
+    trips = np.asarray(trips, np.int32).copy()
+    masks = [int(m) for m in masks]
+    new = trips.copy()
+    failed = False
+    for k in order:
+        if not curved[k]:
+            new[k] = 0
+            continue
+        T = int(trips[k])
+        j = first_clear_bit(masks[k], T) if T >= 1 else None
+        if not failed:
+            # the loop always runs once (ft starts at 1e5), so T >= 1
+            if T >= 1 and (j == T or (j is None and T == NEWTON_MAXITER)):
+                continue                      # exactly what the reference would run
+            failed = True
+        # first wrong surface: exact correction when a clear bit was seen, else run
+        # the full 10 trips to learn the whole mask.  Downstream surfaces: their
+        # masks came from slightly different rays, use them as the next guess.
+        new[k] = j if j is not None else NEWTON_MAXITER
+    return (not failed), new
+
+
+class TripPlanner:
+    """Caches one speculated trip table per key and runs launch/verify rounds.
+
+    launch(trips) must enqueue the kernels with that table (after zeroing its
+    mask buffer) and return the masks as a length-K integer array (this is the
+    synchronisation point; a distributed caller reduces the masks over ranks
+    with a bitwise OR before returning them).
+    """
+
+    def __init__(self):
+        self.cache = {}
+        self.launches = 0
+        self.relaunches = 0
+
+    def initial(self, key, curved):
+        t = self.cache.get(key)
+        if t is None or len(t) != len(curved):
+            t = np.where(np.asarray(curved), NEWTON_MAXITER, 0).astype(np.int32)
+        return np.asarray(t, np.int32).copy()
+
+    def run(self, key, curved, order, launch, max_rounds=None):
+        K = len(curved)
+        trips = self.initial(key, curved)
+        rounds = max_rounds if max_rounds is not None else 2 * K + 2
+        for _ in range(rounds):
+            masks = launch(trips)
+            self.launches += 1
+            ok, new = verify(trips, masks, order, curved)
+            if ok:
+                self.cache[key] = trips.copy()
+                return trips
+            self.relaunches += 1
+            trips = new
+        raise RuntimeError("Newton trip-table speculation did not converge")  # pragma: no cover

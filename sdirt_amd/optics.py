@@ -1,0 +1,561 @@
+"""Lensgroup: the reference's PSF-by-ray-tracing API on top of libsdirt_dp.so.
+
+Same method names, argument meaning and defaults as deeplens/optics.py for the
+dual-pixel PSF path (psf / psf_diff / psf_rgb / psf_map / psf_center /
+sample_from_points / trace / trace2sensor / point_source_grid /
+calc_scale_pinhole / entrance_pupil / exit_pupil / refocus / calc_fov /
+read_lens_json).  All per-ray work runs in HIP kernels; this file only
+validates arguments, draws the pupil uniforms from torch's CPU generator in the
+reference's order (optics.py:483-484: that is what makes seeds reproduce),
+keeps the speculated Newton trip tables (newton.py) and launches.
+
+There is no CPU fallback: every method that traces rays raises if
+libsdirt_dp.so is not built or no MI355X is visible.
+"""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import torch
+
+from . import _lib
+from .basics import (DEFAULT_WAVE, DEPTH, EPSILON, GEO_SPP, WAVE_RGB, Material, Ray, dptr,
+                     stream_ptr)
+from .newton import NEWTON_MAXITER, TripPlanner
+from .surfaces import Aspheric
+
+
+def _as_device(device):
+    if device is None:
+        device = "cuda" if torch.cuda.is_available() else "cpu"
+    device = torch.device(device)
+    if device.type == "cuda" and device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device() if torch.cuda.is_available() else 0)
+    return device
+
+
+class _DevLens:
+    """Owner of one sdirt_lens handle (a prescription at one wavelength)."""
+
+    def __init__(self, surfaces, wvln):
+        arr = (_lib.SurfaceDesc * len(surfaces))(*[s.desc(wvln) for s in surfaces])
+        h = C.c_void_p()
+        _lib.check(_lib.lib().sdirt_lens_create(arr, len(surfaces), C.byref(h)))
+        self.handle = h
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                _lib.lib().sdirt_lens_destroy(self.handle)
+                self.handle = None
+        except Exception:      # interpreter shutdown
+            pass
+
+
+class Lensgroup:
+    """optics.py:22-116.  `device` must be a CUDA (ROCm) device for anything that traces."""
+
+    def __init__(self, filename=None, sensor_res=(1024, 1024), use_roc=False,
+                 post_computation=True, device=None):
+        self.device = _as_device(device)
+        self.surfaces = []
+        self.materials = []
+        self.sensor_res = sensor_res
+        self.aper_idx = None
+        self._dev = {}                 # wvln -> _DevLens
+        self._pupil_cache = {}         # entrance(bool) -> (z, r)
+        self.trips = TripPlanner()
+        #: 'reference' = reproduce the reference's batch-global Newton trip counts
+        #: (speculate + verify, newton.py); 'max' = always 10 trips, no host sync.
+        self.trip_policy = "reference"
+        #: optional hook reducing convergence masks over ranks (set by sdirt_amd.dist)
+        self.mask_reduce = None
+        if filename is not None:
+            self.lens_name = filename
+            self.load_file(filename, use_roc, sensor_res, post_computation)
+
+    # ------------------------------------------------------------------ init
+    def load_file(self, filename, use_roc=False, sensor_res=(1024, 1024), post_computation=True):
+        """optics.py:118-142 (JSON only; the .txt reader is undefined in the reference)."""
+        if filename.endswith(".json"):
+            self.read_lens_json(filename)
+        else:
+            raise Exception("File format not supported.")
+        self.find_aperture()
+        self.prepare_sensor(sensor_res)
+        self.diff_surf_range = self.find_diff_surf()
+        if post_computation:
+            self.post_computation()
+
+    def read_lens_json(self, filename="./test.json"):
+        """optics.py:2173-2198.  Also accepts this package's flat schema
+        (sdirt_amd/data/*.json: keys kind/semi_aperture/z/curvature/...)."""
+        with open(filename, "r") as f:
+            data = json.load(f)
+        self.surfaces, self.materials = [], []
+        for sd in data["surfaces"]:
+            if "type" in sd:
+                t = sd["type"]
+                if t == "Aspheric":
+                    s = Aspheric(r=sd["r"], d=sd["d"], c=sd["c"], k=sd["k"], ai=sd["ai"],
+                                 mat1=sd["mat1"], mat2=sd["mat2"])
+                elif t in ("Stop", "Spheric"):
+                    s = Aspheric(r=sd["r"], d=sd["d"], c=sd["c"], mat1=sd["mat1"], mat2=sd["mat2"])
+                else:
+                    raise Exception("Surface type not implemented.")
+            else:
+                ai = sd.get("even_asphere")
+                s = Aspheric(r=sd["semi_aperture"], d=sd["z"], c=sd["curvature"],
+                             k=sd.get("conic", 0.0), ai=ai if sd["kind"] == "asphere" else None,
+                             mat1=sd["glass_before"], mat2=sd["glass_after"])
+            self.surfaces.append(s)
+            self.materials.append(s.mat1)
+        self.materials.append(self.surfaces[-1].mat2)
+        self.r_last = data["r_last"]
+        self.d_sensor = data["d_sensor"]
+        self._invalidate()
+
+    def write_lens_json(self, filename="./test.json"):
+        """optics.py:2145-2170."""
+        data = {"foclen": getattr(self, "foclen", None), "fnum": getattr(self, "fnum", None),
+                "r_last": float(self.r_last), "d_sensor": float(self.d_sensor),
+                "sensor_size": list(self.sensor_size), "surfaces": []}
+        for i, s in enumerate(self.surfaces):
+            sd = s.surf_dict()
+            nxt = self.surfaces[i + 1].d if i < len(self.surfaces) - 1 else self.d_sensor
+            sd["d_next"] = float(nxt) - float(s.d)
+            data["surfaces"].append(sd)
+        with open(filename, "w") as f:
+            json.dump(data, f, indent=4)
+
+    def _invalidate(self):
+        self._dev.clear()
+        self._pupil_cache.clear()
+
+    def find_aperture(self):
+        """optics.py:193-201: first surface with air-like media on both sides."""
+        self.aper_idx = None
+        for i in range(len(self.surfaces) - 1):
+            if self.surfaces[i].mat1.A < 1.0003 and self.surfaces[i].mat2.A < 1.0003:
+                self.aper_idx = i
+                return
+
+    def find_diff_surf(self):
+        if self.aper_idx is None:
+            return range(len(self.surfaces))
+        return list(range(0, self.aper_idx)) + list(range(self.aper_idx + 1, len(self.surfaces)))
+
+    def prepare_sensor(self, sensor_res=(512, 512), sensor_size=(24.0, 36.0)):
+        """optics.py:154-178."""
+        sensor_res = [sensor_res, sensor_res] if isinstance(sensor_res, int) else list(sensor_res)
+        self.sensor_res = sensor_res
+        H, W = sensor_res
+        if sensor_size is None:
+            self.sensor_size = [2 * self.r_last * H / np.sqrt(H ** 2 + W ** 2),
+                                2 * self.r_last * W / np.sqrt(H ** 2 + W ** 2)]
+        else:
+            self.sensor_size = list(sensor_size)
+            self.r_last = np.sqrt(sensor_size[0] ** 2 + sensor_size[1] ** 2) / 2
+        assert self.sensor_size[0] / self.sensor_size[1] == H / W, "Pixel is not square."
+        self.pixel_size = self.sensor_size[0] / sensor_res[0]
+
+    def post_computation(self):
+        """optics.py:181-190."""
+        self.find_aperture()
+        self.hfov = self.calc_fov()
+        self.foclen = self.calc_efl()
+        _, avg_pupilx = self.entrance_pupil()
+        self.fnum = self.foclen / avg_pupilx / 2
+
+    def set_state(self, d_sensor=None, hfov=None, pupil=None, exit_pupil=None):
+        """Pin the geometric-optics scalars (e.g. from a reference fixture) instead
+        of computing them; the reference's own values drift run to run
+        (its paraxial pupil is an ill-conditioned fp32 lstsq, optics.py:1500)."""
+        if d_sensor is not None:
+            self.d_sensor = float(d_sensor)
+        if hfov is not None:
+            self.hfov = float(hfov)
+            self.foclen = self.calc_efl()
+        if pupil is not None:
+            self._pupil_cache[True] = (float(pupil[0]), float(pupil[1]))
+        if exit_pupil is not None:
+            self._pupil_cache[False] = (float(exit_pupil[0]), float(exit_pupil[1]))
+        if pupil is not None and hasattr(self, "foclen"):
+            self.fnum = self.foclen / self._pupil_cache[True][1] / 2
+        return self
+
+    # ----------------------------------------------------------- device side
+    def _require_gpu(self):
+        if self.device.type != "cuda":
+            raise _lib.SdirtError("sdirt_amd traces rays on the GPU only; construct the lens with "
+                                  "device='cuda' (no CPU fallback exists)")
+
+    def dev_lens(self, wvln=DEFAULT_WAVE):
+        self._require_gpu()
+        key = float(wvln if wvln < 10 else wvln * 1e-3)
+        dl = self._dev.get(key)
+        if dl is None:
+            with torch.cuda.device(self.device):
+                dl = _DevLens(self.surfaces, key)
+            self._dev[key] = dl
+        return dl.handle
+
+    def _curved(self):
+        return [s.kind != _lib.KIND_PLANE for s in self.surfaces]
+
+    def _mask_buffer(self):
+        return torch.zeros(_lib.MAX_SURFACES, dtype=torch.int32, device=self.device)
+
+    def _read_masks(self, mask):
+        m = mask[:len(self.surfaces)]
+        if self.mask_reduce is not None:
+            m = self.mask_reduce(m)
+        return m.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+
+    def _run_with_trips(self, key, order, enqueue):
+        """enqueue(trips_ctypes, mask_ptr) launches the kernels.  Returns the trip
+        table that was finally used."""
+        K = len(self.surfaces)
+        curved = self._curved()
+        if self.trip_policy != "reference":
+            trips = np.where(curved, NEWTON_MAXITER, 0).astype(np.int32)
+            enqueue((C.c_int32 * K)(*trips.tolist()), None)
+            return trips
+        mask = self._mask_buffer()
+
+        def launch(trips):
+            mask.zero_()
+            enqueue((C.c_int32 * K)(*[int(t) for t in trips]), dptr(mask))
+            return self._read_masks(mask)
+
+        return self.trips.run(key, curved, list(order), launch)
+
+    # ---------------------------------------------------------------- sampling
+    @torch.no_grad()
+    def sample_from_points(self, o=[[0, 0, -10000]], spp=256, wvln=DEFAULT_WAVE,
+                           shrink_pupil=False, normalized=False):
+        """optics.py:460-494: rays [spp, N] from object-space points to random pupil points."""
+        self._require_gpu()
+        if not torch.is_tensor(o):
+            o = torch.tensor(o)
+        po = o.to(self.device, torch.float32).reshape(-1, 3).contiguous()
+        pupilz, pupilr = self.entrance_pupil(shrink_pupil=shrink_pupil)
+        x2, y2 = self._pupil_samples(spp, pupilr)
+        ray = Ray.empty((spp, po.shape[0]), wvln, self.device)
+        _lib.check(_lib.lib().sdirt_sample_rays(dptr(po), po.shape[0], dptr(x2), dptr(y2), spp,
+                                                float(pupilz), ray.c_rays(),
+                                                stream_ptr(self.device)))
+        return ray
+
+    def _pupil_samples(self, spp, pupil_r):
+        """optics.py:483-488.  The two uniform vectors come from torch's CPU
+        default generator in the reference's order; the disc mapping runs on the GPU."""
+        u = torch.stack((torch.rand(spp), torch.rand(spp))).to(self.device)
+        xy = torch.empty((2, spp), dtype=torch.float32, device=self.device)
+        _lib.check(_lib.lib().sdirt_pupil_samples(dptr(u[0]), dptr(u[1]), spp, float(pupil_r),
+                                                  dptr(xy[0]), dptr(xy[1]),
+                                                  stream_ptr(self.device)))
+        return xy[0], xy[1]
+
+    # ----------------------------------------------------------------- tracing
+    def trace(self, ray, lens_range=None, record=False, forward=None):
+        """optics.py:601-627: in place; returns (ray, valid, oss).  Direction is
+        taken from the first ray's d_z like the reference unless `forward` is given."""
+        self._require_gpu()
+        if record:
+            raise NotImplementedError("record=True (ray-path plotting) is outside the PSF path")
+        K = len(self.surfaces)
+        if lens_range is None:
+            first, last = 0, K
+        else:
+            lr = list(lens_range)
+            first, last = (lr[0], lr[-1] + 1) if lr else (0, 0)
+            assert lr == list(range(first, last)), "lens_range must be contiguous"
+        if forward is None:
+            forward = bool(ray.soa[5, 0].item() > 0)             # optics.py:618
+        order = list(range(first, last)) if forward else list(range(last - 1, first - 1, -1))
+        handle = self.dev_lens(ray.wvln)
+
+        def enqueue(trips, mask_ptr):
+            _lib.check(_lib.lib().sdirt_trace(handle, first, last, 0 if forward else 1, trips,
+                                              ray.c_rays(), ray.numel, mask_ptr,
+                                              stream_ptr(self.device)))
+
+        if self.trip_policy == "reference":
+            # the trace is in place: keep the input to be able to re-launch
+            saved = ray.soa.clone()
+            calls = [0]
+
+            def enqueue_fresh(trips, mask_ptr):
+                if calls[0]:
+                    ray.soa.copy_(saved)
+                calls[0] += 1
+                enqueue(trips, mask_ptr)
+            key = ("trace", round(float(ray.wvln), 6), first, last, forward)
+            self._run_with_trips(key, order, enqueue_fresh)
+        else:
+            self._run_with_trips(None, order, enqueue)
+        valid = ray.ra == 1
+        return ray, valid, None
+
+    def trace2sensor(self, ray, record=False, ignore_invalid=False):
+        """optics.py:638-664."""
+        ray, _, _ = self.trace(ray, record=record)
+        return ray.propagate_to(self.d_sensor)
+
+    # --------------------------------------------------------------------- PSF
+    def point_source_grid(self, depth, grid=9, normalized=True, quater=False, center=False):
+        """optics.py:816-861."""
+        if grid == 1:
+            x, y = torch.tensor([[0.0]]), torch.tensor([[0.0]])
+            assert not quater, "Quater should be False when grid is 1."
+        elif center:
+            hb = 1 / 2 / (grid - 1)
+            x, y = torch.meshgrid(torch.linspace(-1 + hb, 1 - hb, grid),
+                                  torch.linspace(1 - hb, -1 + hb, grid), indexing="xy")
+        else:
+            x, y = torch.meshgrid(torch.linspace(-0.98, 0.98, grid),
+                                  torch.linspace(0.98, -0.98, grid), indexing="xy")
+        z = torch.full((grid, grid), float(depth))
+        ps = torch.stack([x, y, z], dim=-1)
+        if quater:
+            b = grid // 2 if grid % 2 == 0 else grid // 2 + 1
+            ps = ps[0:b, 0:b, :]
+        if not normalized:
+            scale = self.calc_scale_pinhole(depth)
+            ps[..., 0] *= scale * self.sensor_size[0] / 2
+            ps[..., 1] *= scale * self.sensor_size[1] / 2
+        return ps
+
+    def _points_to_object(self, points):
+        pts = points.to(self.device, torch.float32).contiguous()
+        out = torch.empty_like(pts)
+        _lib.check(_lib.lib().sdirt_points_to_object(
+            dptr(pts), pts.shape[0], float(np.tan(self.hfov)), float(self.r_last),
+            float(self.sensor_size[1]), float(self.sensor_size[0]), dptr(out),
+            stream_ptr(self.device)))
+        return out
+
+    @torch.no_grad()
+    def psf_center(self, point, method="chief_ray"):
+        """optics.py:889-914: [N,3] object-space points -> [N,2] PSF centres (green light)."""
+        if method == "pinhole":
+            scale = self.calc_scale_pinhole(point[..., 2])
+            return -point[..., :2] / scale
+        if method != "chief_ray":
+            raise Exception("Unsupported method.")
+        self._require_gpu()
+        po = point.to(self.device, torch.float32).reshape(-1, 3).contiguous()
+        pupilz, pupilr = self.entrance_pupil(shrink_pupil=True)
+        xc, yc = self._pupil_samples(GEO_SPP, pupilr)
+        center = torch.empty((po.shape[0], 2), dtype=torch.float32, device=self.device)
+        self._chief_center(po, xc, yc, pupilz, center)
+        return center
+
+    def _chief_center(self, po, xc, yc, pupilz, center):
+        anyv = torch.zeros(1, dtype=torch.int32, device=self.device)
+        handle = self.dev_lens(DEFAULT_WAVE)                      # optics.py:900: always green
+
+        def enqueue(trips, mask_ptr):
+            _lib.check(_lib.lib().sdirt_chief_center(
+                handle, dptr(po), po.shape[0], dptr(xc), dptr(yc), xc.shape[0], float(pupilz),
+                float(self.d_sensor), trips, dptr(center), dptr(anyv), mask_ptr,
+                stream_ptr(self.device)))
+        self._run_with_trips(("center",), range(len(self.surfaces)), enqueue)
+        if self.trip_policy == "reference":
+            assert int(anyv.item()) == 1, "No sampled rays is valid."   # optics.py:902
+        return center
+
+    def psf(self, points, ks=31, wvln=DEFAULT_WAVE, spp=GEO_SPP, center=True):
+        """optics.py:916-931."""
+        return self.psf_diff(points=points, wvln=wvln, ks=ks, spp=spp, center=center)
+
+    def psf_diff(self, points, wvln=DEFAULT_WAVE, ks=31, spp=GEO_SPP, center=True,
+                 param_list=None):
+        """optics.py:934-996: normalised points [N,3] (or [3]) -> max-normalised
+        PSF [N,ks,ks] (or [ks,ks]) of the left sub-pixel (right if param_list[4] != 'l')."""
+        dp, direct = None, "l"
+        if param_list is not None:
+            h, f, w, r, direct = param_list
+            dp = (h, f, w, r)
+        L, R = self.psf_lr(points, ks=ks, wvln=wvln, spp=spp, center=center, dp=dp,
+                           want_r=(param_list is not None and direct != "l"),
+                           _default_r_zero=(param_list is None))
+        return L if direct == "l" else R
+
+    @torch.no_grad()
+    def psf_lr(self, points, ks=31, wvln=DEFAULT_WAVE, spp=GEO_SPP, center=True,
+               dp=(0.78, 1.44, 0.3, 0.5), normalize=True, want_r=True, _default_r_zero=False):
+        """Left AND right dual-pixel PSFs of one ray-traced batch: (L, R), each
+        [N,ks,ks] (or [ks,ks] for a single point), max-normalised separately as
+        optics.py:983-987 would normalise each of them.  dp = (h, f, w, r) of
+        monte_carlo.py:157-164."""
+        self._require_gpu()
+        if not torch.is_tensor(points):
+            points = torch.tensor(points)
+        single_point = points.dim() == 1
+        if single_point:
+            points = points.unsqueeze(0)
+        N = points.shape[0]
+        po = self._points_to_object(points)
+        # RNG order of the reference: primary pupil samples first (optics.py:963),
+        # then the chief-ray samples inside psf_center (optics.py:969).
+        pupilz, pupilr = self.entrance_pupil()
+        x2, y2 = self._pupil_samples(spp, pupilr)
+        cen = torch.empty((N, 2), dtype=torch.float32, device=self.device)
+        if center:
+            _, pupilr_c = self.entrance_pupil(shrink_pupil=True)
+            xc, yc = self._pupil_samples(GEO_SPP, pupilr_c)
+            self._chief_center(po, xc, yc, pupilz, cen)
+        else:
+            pts = points.to(self.device, torch.float32)
+            cen[:, 0] = pts[:, 0] * (self.sensor_size[1] / 2)      # optics.py:973-975
+            cen[:, 1] = pts[:, 1] * (self.sensor_size[0] / 2)
+        L = torch.empty((N, ks, ks), dtype=torch.float32, device=self.device)
+        need_r = want_r and not _default_r_zero
+        R = torch.empty_like(L) if need_r else None
+        dpp = None if (dp is None or _default_r_zero) else _lib.DpParams(*[float(v) for v in dp])
+        handle = self.dev_lens(wvln)
+        flags = _lib.PSF_NORMALIZE if normalize else 0
+
+        def enqueue(trips, mask_ptr):
+            _lib.check(_lib.lib().sdirt_psf_lr(
+                handle, dptr(po), N, dptr(x2), dptr(y2), spp, float(pupilz), float(self.d_sensor),
+                float(self.pixel_size), ks, dptr(cen), C.byref(dpp) if dpp is not None else None,
+                trips, flags, dptr(L), dptr(R), mask_ptr, stream_ptr(self.device)))
+        wkey = round(float(wvln if wvln < 10 else wvln * 1e-3), 6)
+        self._run_with_trips(("psf", wkey), range(len(self.surfaces)), enqueue)
+        if R is None and want_r:
+            R = torch.zeros_like(L)
+        if single_point:
+            L = L.squeeze(0)
+            R = R.squeeze(0) if R is not None else None
+        return L, R
+
+    def psf_rgb(self, points, ks=31, spp=GEO_SPP, center=True, param_list=None):
+        """optics.py:999-1015: [N,3,ks,ks] (or [3,ks,ks])."""
+        psfs = [self.psf_diff(points=points, wvln=w, ks=ks, spp=spp, center=center,
+                              param_list=param_list) for w in WAVE_RGB]
+        return torch.stack(psfs, dim=-3)
+
+    def psf_map(self, depth=DEPTH, grid=7, ks=51, spp=GEO_SPP, center=True):
+        """optics.py:1018-1041: [3, grid*ks, grid*ks] mosaic (torchvision make_grid, padding 0)."""
+        points = self.point_source_grid(depth=depth, grid=grid).reshape(-1, 3)
+        psfs = self.psf_rgb(points=points, ks=ks, center=center, spp=spp)   # [grid^2,3,ks,ks]
+        p = psfs.reshape(grid, grid, 3, ks, ks).permute(2, 0, 3, 1, 4)
+        return p.reshape(3, grid * ks, grid * ks)
+
+    # ------------------------------------------------------- geometrical optics
+    def calc_scale_pinhole(self, depth):
+        """optics.py:1302-1306."""
+        return -depth * np.tan(self.hfov) / self.r_last
+
+    def calc_efl(self):
+        """optics.py:1109-1114."""
+        return self.r_last / np.tan(self.hfov)
+
+    @torch.no_grad()
+    def calc_fov(self):
+        """optics.py:1203-1233: 100 rays from the sensor edge through the shrunk
+        exit pupil, traced backward; mean exit slope -> half diagonal FoV."""
+        M = 100
+        pupilz, pupilx = self.exit_pupil(shrink_pupil=True)
+        o1 = torch.tensor([self.r_last, 0, self.d_sensor]).repeat(M, 1).to(torch.float32)
+        x2 = torch.linspace(-pupilx, pupilx, M)
+        o2 = torch.stack((x2, torch.full_like(x2, 0), torch.full_like(x2, pupilz)), dim=-1)
+        ray = Ray(o1, o2 - o1, device=self.device)
+        ray, _, _ = self.trace(ray, forward=False)
+        d, ra = ray.d.cpu(), ray.ra.cpu()
+        tan_fov = d[..., 0] / d[..., 2]
+        fov = torch.atan(torch.sum(tan_fov * ra) / torch.sum(ra))
+        if torch.isnan(fov):
+            print("computed fov is NaN, use 0.5 rad instead.")
+            return 0.5
+        return fov.item()
+
+    @torch.no_grad()
+    def refocus(self, depth=DEPTH):
+        """optics.py:1170-1196: move the sensor to the least-squares focus of green
+        rays from an on-axis point at `depth`."""
+        s0 = self.surfaces[0]
+        x2, y2 = self._pupil_samples(GEO_SPP, s0.r)              # surfaces.py:189-199
+        o = torch.stack((x2, y2, torch.full_like(x2, float(s0.d))), 1)
+        d = o - torch.tensor([0, 0, depth], dtype=torch.float32, device=self.device)
+        ray = Ray(o, d, wvln=DEFAULT_WAVE, device=self.device)
+        ray, _, _ = self.trace(ray, forward=True)
+        o_, d_, ra = ray.o.cpu(), ray.d.cpu(), ray.ra.cpu()
+        t = (d_[..., 0] * o_[..., 0] + d_[..., 1] * o_[..., 1]) / (d_[..., 0] ** 2 + d_[..., 1] ** 2)
+        t = t * ra
+        focus_d = (o_[..., 2] - d_[..., 2] * t).numpy()
+        focus_d = focus_d[ra.numpy() > 0]
+        focus_d = focus_d[~np.isnan(focus_d) & (focus_d > 0)]
+        d_sensor_new = float(np.mean(focus_d))
+        assert d_sensor_new > 0, "sensor position is negative."
+        self.d_sensor = d_sensor_new
+        self.post_computation()
+
+    def exit_pupil(self, shrink_pupil=False):
+        """optics.py:1328-1332."""
+        return self.entrance_pupil(entrance=False, shrink_pupil=shrink_pupil)
+
+    def entrance_pupil(self, M=32, entrance=True, shrink_pupil=False):
+        """optics.py:1379-1396 (z, r) of the paraxial pupil; the value is computed
+        once per lens and cached (the reference re-traces it on every call)."""
+        if self.aper_idx is None:
+            s = self.surfaces[0] if entrance else self.surfaces[-1]
+            return float(s.d), s.r
+        if entrance not in self._pupil_cache:
+            self._pupil_cache[entrance] = self.calc_entrance_pupil_paraxial(entrance=entrance)
+        z, r = self._pupil_cache[entrance]
+        if shrink_pupil:
+            r = r * 0.25
+        return z, r
+
+    @torch.no_grad()
+    def calc_entrance_pupil_paraxial(self, entrance=True):
+        """optics.py:1335-1376: 16 paraxial rays from a point 1e-3 mm off-axis on the
+        stop, traced out of the lens; the pairwise intersections of the emerging
+        lines (in the x-z plane) give the pupil position and magnification.  The
+        reference solves the 120 2x2 systems with an fp32 lstsq; here they are
+        solved in closed form in float64 from the same fp32 rays."""
+        aper = self.surfaces[self.aper_idx]
+        aper_z, aper_r, delta_r = float(aper.d), aper.r, 1e-3
+        ray_o = torch.tensor([[delta_r, 0, aper_z]]).repeat(16, 1)
+        phi = torch.linspace(-0.1, 0.1, 16) / 180.0 * torch.pi
+        sgn = -1.0 if entrance else 1.0
+        d = torch.stack((torch.sin(phi), torch.zeros_like(phi), sgn * torch.cos(phi)), dim=-1)
+        ray = Ray(ray_o, d, device=self.device)
+        if entrance:
+            ray, _, _ = self.trace(ray, lens_range=range(0, self.aper_idx), forward=False)
+        else:
+            ray, _, _ = self.trace(ray, lens_range=range(self.aper_idx + 1, len(self.surfaces)),
+                                   forward=True)
+        o_, d_, ra = ray.o.cpu().numpy(), ray.d.cpu().numpy(), ray.ra.cpu().numpy()
+        keep = ra != 0
+        O = np.stack([o_[keep][:, 0], o_[keep][:, 2]], -1).astype(np.float64)
+        D = np.stack([d_[keep][:, 0], d_[keep][:, 2]], -1).astype(np.float64)
+        P = intersect_lines_2d(O, D)
+        if len(P) == 0:
+            print("No intersection points found, use the first surface as pupil.")
+            return float(self.surfaces[0].d), self.surfaces[0].r
+        avg_r = float(abs(np.float32(P[:, 0].mean()) / delta_r * aper_r))
+        avg_z = float(np.float32(P[:, 1].mean()))
+        return avg_z, avg_r
+
+
+def intersect_lines_2d(origins, directions):
+    """optics.py:1470-1515: pairwise intersections of N 2-D lines, [N(N-1)/2, 2].
+    Solves Oi + s Di = Oj + t Dj exactly (float64) and averages both evaluations."""
+    n = origins.shape[0]
+    ii, jj = np.triu_indices(n, k=1)
+    Oi, Oj, Di, Dj = origins[ii], origins[jj], directions[ii], directions[jj]
+    b = Oj - Oi
+    det = Di[:, 0] * (-Dj[:, 1]) - (-Dj[:, 0]) * Di[:, 1]
+    ok = det != 0
+    Oi, Oj, Di, Dj, b, det = Oi[ok], Oj[ok], Di[ok], Dj[ok], b[ok], det[ok]
+    s = (b[:, 0] * (-Dj[:, 1]) - (-Dj[:, 0]) * b[:, 1]) / det
+    t = (Di[:, 0] * b[:, 1] - Di[:, 1] * b[:, 0]) / det
+    Pi = Oi + s[:, None] * Di
+    Pj = Oj + t[:, None] * Dj
+    return (Pi + Pj) / 2

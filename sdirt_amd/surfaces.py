@@ -1,0 +1,73 @@
+"""Surface records of a lens prescription.
+
+The reference models every surface of its JSON lenses as `Aspheric`
+(deeplens/surfaces.py:281-331) and picks the plane / sphere / asphere code path
+at trace time (surfaces.py:409,456,491).  Here a surface is a plain record; the
+branch is decided once (`kind`) and the intersection / refraction math runs in
+the HIP kernels (sdirt_amd/csrc/sdirt_device.hpp).
+"""
+import numpy as np
+
+from . import _lib
+from .basics import Material
+
+KIND_NAMES = {_lib.KIND_PLANE: "plane", _lib.KIND_SPHERE: "sphere", _lib.KIND_ASPHERE: "asphere"}
+
+
+class Aspheric:
+    """r: semi-aperture (python float), d: vertex z, c: curvature, k: conic,
+    ai: even-asphere coefficients [ai2, ai4, ...] or None (all fp32, as the
+    reference stores them in fp32 tensors)."""
+
+    def __init__(self, r, d, c=0.0, k=0.0, ai=None, mat1=None, mat2=None, device=None):
+        self.r = float(r)
+        self.d = np.float32(d)
+        self.c = np.float32(c)
+        self.k = np.float32(k)
+        if ai is not None:
+            if len(ai) > _lib.MAX_AI:
+                raise ValueError(f"at most {_lib.MAX_AI} aspheric terms are supported")
+            self.ai = np.asarray(ai, dtype=np.float32)
+            self.ai_degree = len(ai)
+        else:
+            self.ai = None
+            self.ai_degree = 0
+        self.mat1 = mat1 if isinstance(mat1, Material) else Material(mat1)
+        self.mat2 = mat2 if isinstance(mat2, Material) else Material(mat2)
+
+    @property
+    def kind(self):
+        if float(self.c) == 0.0:                                  # surfaces.py:409
+            return _lib.KIND_PLANE
+        if self.ai is None and float(self.k) == 0.0:              # surfaces.py:456
+            return _lib.KIND_SPHERE
+        return _lib.KIND_ASPHERE
+
+    def desc(self, wvln):
+        """sdirt_surface_desc at one wavelength."""
+        s = _lib.SurfaceDesc()
+        s.kind = self.kind
+        s.ai_degree = self.ai_degree if self.kind == _lib.KIND_ASPHERE else 0
+        s.r = self.r
+        s.d, s.c, s.k = float(self.d), float(self.c), float(self.k)
+        for i in range(s.ai_degree):
+            s.ai[i] = float(self.ai[i])
+        s.n1 = float(self.mat1.ior(wvln))
+        s.n2 = float(self.mat2.ior(wvln))
+        return s
+
+    def surf_dict(self):
+        """Same keys as the reference's JSON surfaces (optics.py:2155-2167)."""
+        kind = self.kind
+        d = {"type": {0: "Stop", 1: "Spheric", 2: "Aspheric"}[kind], "r": self.r,
+             "c": float(self.c), "d": float(self.d), "mat1": self.mat1.name,
+             "mat2": self.mat2.name}
+        if kind == _lib.KIND_ASPHERE:
+            d["k"] = float(self.k)
+            d["ai"] = [float(a) for a in (self.ai if self.ai is not None else [])]
+        return d
+
+    def __repr__(self):
+        return (f"Aspheric({KIND_NAMES[self.kind]}, r={self.r}, d={float(self.d)}, "
+                f"c={float(self.c)}, k={float(self.k)}, ai={self.ai}, "
+                f"{self.mat1.name}->{self.mat2.name})")

@@ -1,0 +1,214 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle and the
+reference fixtures.  Every test here needs an MI355X: run with `-m gpu`.
+
+Bars:
+  * ray level, same input rays and trip table: HIP == oracle BIT-EXACT
+    (both are IEEE fp32 evaluations of the same op sequence);
+  * splat grids: <= 2e-6 of the peak (atomic summation order; ocml vs libm acos/sin);
+  * against the reference fixtures: trip counts and validity flags EQUAL,
+    sensor positions within 1e-5 mm (torch's MKL sqrt/acos are not correctly
+    rounded, see oracle header), PSFs within the per-test tolerance stated there.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, load_state, make_lens, ulp_diff
+
+pytestmark = pytest.mark.gpu
+DP = [0.78, 1.44, 0.3, 0.5]
+DEV = "cuda:0"
+
+
+def t(a):
+    return torch.tensor(np.ascontiguousarray(a), device=DEV)
+
+
+def rays_from_fixture(o, d, wvln=0.589):
+    from sdirt_amd import Ray
+    r = Ray.empty(o.shape[:-1], wvln, torch.device(DEV))
+    r.o = t(o)
+    r.d = t(d)          # already normalised by the reference: set raw, do not renormalise
+    r.ra = torch.ones(o.shape[:-1], device=DEV)
+    r.obliq = torch.ones(o.shape[:-1], device=DEV)
+    return r
+
+
+@pytest.mark.parametrize("lens_name,fx", [("rf50mm", "f1_rf50_c1"), ("rf50mm", "f2_rf50_pts4"),
+                                          ("rf35mm", "f3_rf35_pts4")])
+def test_staged_trace_bit_exact_vs_oracle_and_close_to_reference(oracle, lens_name, fx):
+    st, g = load_state(lens_name), load_golden(fx)
+    lens = make_lens(lens_name, DEV, st)
+    ray = rays_from_fixture(g["ray_o0"], g["ray_d0"])
+    ray, valid, _ = lens.trace(ray)
+    used = lens.trips.cache[("trace", 0.589, 0, len(lens.surfaces), True)]
+    # the speculate+verify loop must land on the reference's global trip counts
+    assert np.array_equal(used, g["trips"])
+    surf = oracle.surfaces_from_state(st, 0.589)
+    S, N = g["ray_d0"].shape[:2]
+    ref = oracle.trace(surf, g["ray_o0"], g["ray_d0"], np.ones((S, N), np.float32), trips=g["trips"])
+    o, d, ra = ray.o.cpu().numpy(), ray.d.cpu().numpy(), ray.ra.cpu().numpy()
+    assert np.array_equal(ra, ref["ra"]) and np.array_equal(ra, g["surf_ra"][-1])
+    assert np.array_equal(o, ref["o"]), f"max ulp {ulp_diff(o, ref['o']).max()}"
+    assert np.array_equal(d, ref["d"]), f"max ulp {ulp_diff(d, ref['d']).max()}"
+    assert np.array_equal(ray.obliq.cpu().numpy(), ref["obliq"])
+    # against the reference itself
+    assert np.abs(o - g["surf_o"][-1]).max() < 1e-5
+    assert np.abs(d - g["surf_d"][-1]).max() < 2e-6
+    assert np.array_equal(valid.cpu().numpy(), g["surf_ra"][-1] == 1)
+
+
+def test_sampling_matches_reference(oracle):
+    st, g = load_state("rf50mm"), load_golden("f2_rf50_pts4")
+    lens = make_lens("rf50mm", DEV, st)
+    from sdirt_amd import _lib
+    from sdirt_amd.basics import Ray, dptr, stream_ptr
+    po = lens._points_to_object(t(g["points"]))
+    assert np.array_equal(po.cpu().numpy(), g["ray_o0"][0])       # bit-exact object points
+    S = int(g["spp"])
+    xy = torch.empty((2, S), device=DEV)
+    _lib.check(_lib.lib().sdirt_pupil_samples(dptr(t(g["u_theta"])), dptr(t(g["u_r2"])), S,
+                                              st["pupil_r"], dptr(xy[0]), dptr(xy[1]),
+                                              stream_ptr(torch.device(DEV))))
+    ray = Ray.empty((S, 4), 0.589, torch.device(DEV))
+    _lib.check(_lib.lib().sdirt_sample_rays(dptr(po), 4, dptr(xy[0]), dptr(xy[1]), S,
+                                            st["pupil_z"], ray.c_rays(),
+                                            stream_ptr(torch.device(DEV))))
+    d = ray.d.cpu().numpy()
+    assert ulp_diff(d, g["ray_d0"]).max() <= 4          # sin/cos differ by <= 1 ulp
+    assert np.array_equal(ray.o.cpu().numpy(), g["ray_o0"])
+    # with the oracle's pupil points the normalised directions are bit-exact
+    x2, y2 = oracle.pupil_samples(g["u_theta"], g["u_r2"], st["pupil_r"])
+    _lib.check(_lib.lib().sdirt_sample_rays(dptr(po), 4, dptr(t(x2)), dptr(t(y2)), S,
+                                            st["pupil_z"], ray.c_rays(),
+                                            stream_ptr(torch.device(DEV))))
+    _, d_or, _, _ = oracle.sample_rays(g["ray_o0"][0], x2, y2, st["pupil_z"])
+    assert np.array_equal(ray.d.cpu().numpy(), d_or)
+
+
+@pytest.mark.parametrize("lens_name,fx", [("rf50mm", "f2_rf50_pts4"), ("rf35mm", "f3_rf35_pts4")])
+def test_chief_center(oracle, lens_name, fx):
+    st, g = load_state(lens_name), load_golden(fx)
+    lens = make_lens(lens_name, DEV, st)
+    x2, y2 = oracle.pupil_samples(g["uc_theta"], g["uc_r2"], st["pupil_r"] * 0.25)
+    po = t(g["cen_o0"][0])
+    cen = torch.empty((po.shape[0], 2), device=DEV)
+    lens._chief_center(po, t(x2), t(y2), st["pupil_z"], cen)
+    assert np.array_equal(lens.trips.cache[("center",)], g["trips_center"])
+    assert np.abs(cen.cpu().numpy() - g["center"]).max() < 4e-6       # mm; pixel is 46.9e-3 mm
+    # oracle with the same pupil points and trips
+    surf = oracle.surfaces_from_state(st, 0.589)
+    o, d, ra, ob = oracle.sample_rays(g["cen_o0"][0], x2, y2, st["pupil_z"])
+    tr = oracle.trace(surf, o, d, ra, trips=g["trips_center"])
+    c_or, ok = oracle.center_from_rays(oracle.propagate_to(st["d_sensor"], tr["o"], tr["d"]), tr["ra"])
+    assert ok and ulp_diff(cen.cpu().numpy(), c_or).max() <= 1
+
+
+@pytest.mark.parametrize("tag,dp", [("", None), ("_dp_l", DP), ("_bigr", [0.78, 1.44, 0.3, 0.6])])
+def test_forward_integral_from_reference_rays(oracle, tag, dp):
+    from sdirt_amd import forward_integral_lr
+    st, g0 = load_state("rf50mm"), load_golden("f2_rf50_pts4")
+    g = load_golden("f2_rf50_pts4" + tag) if tag else g0
+    ray = rays_from_fixture(g0["surf_o"][-1], g0["surf_d"][-1])
+    ray.ra = t(g0["surf_ra"][-1])
+    ray.propagate_to(st["d_sensor"])
+    pl = None if dp is None else dp + ["l"]
+    lg, rg = forward_integral_lr(ray, st["pixel_size"], int(g["ks"]), t(g["center"]), pl)
+    peak = g["grid_l"].max()
+    assert np.abs(lg.cpu().numpy() - g["grid_l"]).max() <= 2e-6 * peak
+    if dp is None:
+        assert not rg.any()
+    else:
+        assert np.abs(rg.cpu().numpy() - g["grid_r"]).max() <= 2e-6 * g["grid_r"].max()
+
+
+def test_splat_synthetic_and_edges(oracle):
+    from sdirt_amd import (assign_points_to_pixels_big_r, assign_points_to_pixels_small_r,
+                           forward_integral_lr)
+    g = load_golden("f5_splat")
+    ks, ps = int(g["ks"]), float(g["ps"])
+    rng = [(-ks / 2 + 0.5) * ps, (ks / 2 - 0.5) * ps]
+    for tag, fn in (("small", assign_points_to_pixels_small_r),
+                    ("small_r04", assign_points_to_pixels_small_r),
+                    ("big", assign_points_to_pixels_big_r)):
+        pl = list(g[f"{tag}_param"]) + ["l"]
+        l, r = fn(points=t(g["points"]), ks=ks, x_range=rng, y_range=rng, ra=t(g["ra"]),
+                  x_tan=t(g["x_tan"]), param_list=pl)
+        assert np.abs(l.cpu().numpy() - g[f"{tag}_l"]).max() <= 2e-6 * g[f"{tag}_l"].max()
+        assert np.abs(r.cpu().numpy() - g[f"{tag}_r"]).max() <= 2e-6 * g[f"{tag}_r"].max()
+        l2, r2 = fn(points=t(g["points"]), ks=ks, x_range=rng, y_range=rng, ra=t(g["ra"]),
+                    x_tan=t(g["x_tan"]), param_list=pl[:4] + ["r"])
+        assert torch.equal(l2, r) or torch.allclose(l2, r, atol=1e-5)    # swapped return order
+    l, r = assign_points_to_pixels_small_r(points=t(g["points"]), ks=ks, x_range=rng, y_range=rng,
+                                           ra=t(g["ra"]), x_tan=t(g["x_tan"]), param_list=None)
+    assert np.abs(l.cpu().numpy() - g["default_l"]).max() <= 2e-6 * g["default_l"].max()
+    assert not r.any()
+    # window edges / dead rays / negative slopes
+    e = load_golden("f6_window_edges")
+    ray = rays_from_fixture(e["o"], e["d"])
+    ray.ra = t(e["ra"])
+    lg, rg = forward_integral_lr(ray, float(e["ps"]), int(e["ks"]), t(e["center"]), DP + ["l"])
+    assert np.abs(lg.cpu().numpy() - e["grid_l"]).max() <= 2e-6 * e["grid_l"].max()
+    assert np.abs(rg.cpu().numpy() - e["grid_r"]).max() <= 2e-6 * e["grid_r"].max()
+
+
+@pytest.mark.parametrize("lens_name,fx,seed", [("rf50mm", "f1_rf50_c1", 0),
+                                               ("rf50mm", "f2_rf50_pts4", 1),
+                                               ("rf35mm", "f3_rf35_pts4", 2)])
+def test_psf_end_to_end_same_seed(oracle, lens_name, fx, seed):
+    """Lensgroup.psf with the reference's seed: same RNG draws, own pupil mapping,
+    own centre, fused kernel.  Few rays per pixel (spp 64..256), so one ray that
+    lands 1e-5 mm away moves a pixel by ~1e-4 of the peak: tolerance 3e-4*peak
+    (SURVEY.md §7 hard parts 1-2); the 4096-spp test below is the tight one."""
+    st, g = load_state(lens_name), load_golden(fx)
+    lens = make_lens(lens_name, DEV, st)
+    torch.manual_seed(seed)
+    psf = lens.psf(torch.tensor(g["points"]), ks=int(g["ks"]), spp=int(g["spp"]))
+    assert psf.shape == g["psf"].shape
+    assert np.array_equal(lens.trips.cache[("psf", 0.589)], g["trips"])
+    assert np.abs(psf.cpu().numpy() - g["psf"]).max() <= 3e-4
+    # the fused kernel against the oracle on identical pupil points: tight
+    x2, y2 = oracle.pupil_samples(g["u_theta"], g["u_r2"], st["pupil_r"])
+    xc, yc = oracle.pupil_samples(g["uc_theta"], g["uc_r2"], st["pupil_r"] * 0.25)
+    lo, ro, co, ok = oracle.psf(st, g["points"], x2, y2, xc, yc, int(g["ks"]), dp=DP)
+    po = lens._points_to_object(torch.tensor(g["points"]))
+    from sdirt_amd import _lib
+    from sdirt_amd.basics import dptr, stream_ptr
+    import ctypes as C
+    N, ks = len(g["points"]), int(g["ks"])
+    L = torch.empty((N, ks, ks), device=DEV); R = torch.empty_like(L)
+    trips = (C.c_int32 * len(g["trips"]))(*[int(v) for v in g["trips"]])
+    dpp = _lib.DpParams(*DP)
+    _lib.check(_lib.lib().sdirt_psf_lr(lens.dev_lens(0.589), dptr(po), N, dptr(t(x2)), dptr(t(y2)),
+                                       len(x2), st["pupil_z"], st["d_sensor"], st["pixel_size"], ks,
+                                       dptr(t(co)), C.byref(dpp), trips, 1, dptr(L), dptr(R), None,
+                                       stream_ptr(torch.device(DEV))))
+    # oracle ran its own (reference-rule) trip counts == fixture trips (checked in CPU tests)
+    assert np.abs(L.cpu().numpy() - lo).max() <= 2e-6
+    assert np.abs(R.cpu().numpy() - ro).max() <= 2e-6
+
+
+def test_mini_config2_4096spp(oracle):
+    """Miniature BASELINE config 2 (3x3x3 volume, 4096 spp, ks 65), L and R."""
+    st, g = load_state("rf50mm"), load_golden("f8_rf50_mini_c2")
+    gr = load_golden("f8_rf50_mini_c2_r")
+    lens = make_lens("rf50mm", DEV, st)
+    torch.manual_seed(8)
+    L, R = lens.psf_lr(torch.tensor(g["points"]), ks=65, spp=4096, dp=DP)
+    assert np.array_equal(lens.trips.cache[("psf", 0.589)], g["trips"])
+    assert np.array_equal(lens.trips.cache[("center",)], g["trips_center"])
+    dl = np.abs(L.cpu().numpy() - g["psf"]).max()
+    dr = np.abs(R.cpu().numpy() - gr["psf"]).max()
+    print("mini-C2 max |dPSF| / peak: L", dl, "R", dr)
+    assert dl <= 1e-4 and dr <= 1e-4
+    # the bulk of the pixels agree far better than the worst one
+    assert np.median(np.abs(L.cpu().numpy() - g["psf"])[g["psf"] > 1e-3]) <= 1e-5
+
+
+def test_rgb(oracle):
+    st, g = load_state("rf50mm"), load_golden("f4_rf50_rgb")
+    lens = make_lens("rf50mm", DEV, st)
+    torch.manual_seed(3)
+    psf = lens.psf_rgb(torch.tensor(g["points"]), ks=17, spp=64)
+    assert psf.shape == g["psf"].shape
+    assert np.abs(psf.cpu().numpy() - g["psf"]).max() <= 5e-4
