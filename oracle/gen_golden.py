@@ -101,6 +101,7 @@ class Recorder:
         self.grids = []         # (l_grid, r_grid) per assign_points call
         self.sampled = []       # (o, d) after Ray.__init__ in sample_from_points
         self.centers = []
+        self.pupil = []         # (x2, y2) as the reference computed them (optics.py:485-488)
         self._cur = None
 
     def __enter__(self):
@@ -113,6 +114,15 @@ class Recorder:
         self._br = ref_mc.assign_points_to_pixels_big_r
         self._sfp = ref_optics.Lensgroup.sample_from_points
         self._pc = ref_optics.Lensgroup.psf_center
+        self._stack = torch.stack
+
+        def stack(tensors, *a, **k):
+            # optics.py:488: o2 = torch.stack((x2, y2, z2), 1) -- the only 3-tuple of
+            # 1-D tensors stacked along dim 1 on this path
+            if (len(a) == 1 and a[0] == 1 and len(tensors) == 3
+                    and all(t.dim() == 1 for t in tensors)):
+                rec.pupil.append((tensors[0].numpy().copy(), tensors[1].numpy().copy()))
+            return rec._stack(tensors, *a, **k)
 
         def rand(*a, **k):
             out = rec._rand(*a, **k)
@@ -163,6 +173,7 @@ class Recorder:
             return c
 
         torch.rand = rand
+        torch.stack = stack
         ref_surfaces.Aspheric.ray_reaction = ray_reaction
         ref_surfaces.Aspheric._valid_loose = valid_loose
         ref_optics.Lensgroup.trace = trace
@@ -176,6 +187,7 @@ class Recorder:
 
     def __exit__(self, *exc):
         torch.rand = self._rand
+        torch.stack = self._stack
         ref_surfaces.Aspheric.ray_reaction = self._rr
         ref_surfaces.Aspheric._valid_loose = self._vl
         ref_optics.Lensgroup.trace = self._tr
@@ -203,6 +215,8 @@ def run_psf_case(lens, points, ks, spp, wvln, seed, param_list=None, full=True):
     assert len(rec.rand) == 4 and len(rec.traces) == 2
     out["u_theta"], out["u_r2"], out["uc_theta"], out["uc_r2"] = rec.rand
     out["center"] = rec.centers[0]
+    assert len(rec.pupil) == 2
+    (out["pupil_x2"], out["pupil_y2"]), (out["pupil_xc"], out["pupil_yc"]) = rec.pupil
     main, cen = rec.traces
     out["trips"] = np.asarray(main["trips"], np.int32)
     out["trips_center"] = np.asarray(cen["trips"], np.int32)
@@ -294,6 +308,10 @@ def main():
         d["rand"] = np.stack([r for r in rec.rand if r.shape[0] == 64])       # [6,64]
         d["rand_center"] = np.stack([r for r in rec.rand if r.shape[0] == 2048])
         d["centers"] = np.stack(rec.centers)
+        d["pupil_x"] = np.stack([p[0] for p in rec.pupil if p[0].shape[0] == 64])     # [3,64]
+        d["pupil_y"] = np.stack([p[1] for p in rec.pupil if p[0].shape[0] == 64])
+        d["pupil_xc"] = np.stack([p[0] for p in rec.pupil if p[0].shape[0] == 2048])  # [3,2048]
+        d["pupil_yc"] = np.stack([p[1] for p in rec.pupil if p[0].shape[0] == 2048])
         d["trips"] = np.stack([np.asarray(t["trips"], np.int32) for t in rec.traces])
         return d
     save(out_dir, "f4_rf50_rgb", twice(rgb))

@@ -361,8 +361,10 @@ void or_pupil_samples(const float* u_theta, const float* u_r2, int64_t S, double
     for (int64_t s = 0; s < S; ++s) {
         float theta = (u_theta[s] * 2.0f) * pi;
         float r = sqrtf(u_r2[s] * pr2);
-        x2[s] = r * cosf(theta);
-        y2[s] = r * sinf(theta);
+        /* torch.cos/sin on CPU are MKL VML (<1 ulp, not always correctly rounded);
+         * the correctly rounded value (via double) agrees with them most often */
+        x2[s] = r * (float)cos((double)theta);
+        y2[s] = r * (float)sin((double)theta);
     }
 }
 

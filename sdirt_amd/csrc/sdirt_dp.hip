@@ -193,8 +193,12 @@ __global__ void k_pupil_samples(const float* __restrict__ ut, const float* __res
     if (s >= S) return;
     const float theta = (ut[s] * 2.0f) * (float)3.141592653589793;   // optics.py:483
     const float r = __builtin_sqrtf(ur[s] * pr2);                     // optics.py:484
-    x2[s] = r * __ocml_cos_f32(theta);
-    y2[s] = r * __ocml_sin_f32(theta);
+    // torch.cos/sin on CPU (MKL VML) are <1 ulp; the correctly rounded values,
+    // obtained here through fp64, agree with them far more often than a 1-2 ulp
+    // fp32 libm would, and that matters: d = o2 - o cancels against |o| ~ 1e4 mm
+    // (DESIGN.md §5).  O(spp) work, shared by all points -- cost is nil.
+    x2[s] = r * (float)__ocml_cos_f64((double)theta);
+    y2[s] = r * (float)__ocml_sin_f64((double)theta);
 }
 
 __device__ __forceinline__ Ray make_ray(float px, float py, float pz, float x2, float y2, float z2)

@@ -386,11 +386,17 @@ class Lensgroup:
 
     @torch.no_grad()
     def psf_lr(self, points, ks=31, wvln=DEFAULT_WAVE, spp=GEO_SPP, center=True,
-               dp=(0.78, 1.44, 0.3, 0.5), normalize=True, want_r=True, _default_r_zero=False):
+               dp=(0.78, 1.44, 0.3, 0.5), normalize=True, want_r=True, _default_r_zero=False,
+               pupil_xy=None, center_pupil_xy=None):
         """Left AND right dual-pixel PSFs of one ray-traced batch: (L, R), each
         [N,ks,ks] (or [ks,ks] for a single point), max-normalised separately as
         optics.py:983-987 would normalise each of them.  dp = (h, f, w, r) of
-        monte_carlo.py:157-164."""
+        monte_carlo.py:157-164.
+
+        pupil_xy / center_pupil_xy: optional explicit pupil sample points
+        (x2[spp], y2[spp]) for the primary and the chief-ray pass; when given,
+        no random numbers are drawn for that pass (used for ray-level parity
+        hand-off and for quasi-random sampling)."""
         self._require_gpu()
         if not torch.is_tensor(points):
             points = torch.tensor(points)
@@ -402,11 +408,20 @@ class Lensgroup:
         # RNG order of the reference: primary pupil samples first (optics.py:963),
         # then the chief-ray samples inside psf_center (optics.py:969).
         pupilz, pupilr = self.entrance_pupil()
-        x2, y2 = self._pupil_samples(spp, pupilr)
+        if pupil_xy is None:
+            x2, y2 = self._pupil_samples(spp, pupilr)
+        else:
+            x2, y2 = [torch.as_tensor(v).to(self.device, torch.float32).contiguous()
+                      for v in pupil_xy]
+            spp = x2.shape[0]
         cen = torch.empty((N, 2), dtype=torch.float32, device=self.device)
         if center:
             _, pupilr_c = self.entrance_pupil(shrink_pupil=True)
-            xc, yc = self._pupil_samples(GEO_SPP, pupilr_c)
+            if center_pupil_xy is None:
+                xc, yc = self._pupil_samples(GEO_SPP, pupilr_c)
+            else:
+                xc, yc = [torch.as_tensor(v).to(self.device, torch.float32).contiguous()
+                          for v in center_pupil_xy]
             self._chief_center(po, xc, yc, pupilz, cen)
         else:
             pts = points.to(self.device, torch.float32)
