@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""bench.py -- rays/sec and PSFs/sec of the dual-pixel ray-traced PSF path.
+
+Workload (BASELINE.json configs[1]): rf50mm refocused to 1 m (F/4 stop),
+32x32x16 (x, y, z) PSF volume = 16384 point sources per GPU, 4096 primary rays
+per point, 65x65 LEFT and RIGHT PSFs, lambda = 0.589 um.  One "step" = one
+Lensgroup.psf_lr call over the rank's 16384 points: draw the pupil uniforms
+(torch CPU generator, the reference's order), chief-ray centre pass (2048 rays
+per point), fused sample->trace->splat->normalise kernel, verification of the
+batch-global Newton trip counts, and -- for N > 1 -- the RCCL all-gather of the
+PSF shards.  Weak scaling: every rank renders its own 16384-point slab of a
+32x32x(16*N) volume.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line (see the driver contract); `roofline` describes the
+dominant kernel (k_psf_lr), `cpu_baseline` times oracle/ (a C port of the
+reference's CPU path, OpenMP over the host cores) on a bounded sample of the
+same workload.  oracle/ is only loaded for that baseline leg.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+# libgomp reads this when it initialises: idle OpenMP threads of the CPU-baseline
+# leg must sleep, not spin, inside a CPU-quota'd container
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+KS, SPP, GRID_XY, GRID_Z = 65, 4096, 32, 16
+DP = (0.78, 1.44, 0.3, 0.5)
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s HBM3E
+
+
+def volume_points(world):
+    """The reference's test grid (psfnet.py:220-226) x depths z2depth(linspace(0,1))
+    (psfnet.py:36-37,724-726): [32*32*16*world, 3], z-major so that a rank's
+    contiguous shard is a slab of depth planes."""
+    g = GRID_XY
+    x, y = torch.meshgrid(torch.linspace(-1 + 1 / (2 * g), 1 - 1 / (2 * g), g),
+                          torch.linspace(1 - 1 / (2 * g), -1 + 1 / (2 * g), g), indexing="xy")
+    z = torch.linspace(0, 1, GRID_Z * world)
+    depth = z * (-20000.0 - (-200.0)) + (-200.0)
+    pts = torch.stack([x.reshape(1, -1).expand(len(z), -1), y.reshape(1, -1).expand(len(z), -1),
+                       depth.reshape(-1, 1).expand(-1, g * g)], dim=-1)
+    return pts.reshape(-1, 3).contiguous()
+
+
+def build_lens(device):
+    """rf50mm as 1_fit_psfnet.py:21-25 sets it up: sensor at 62.25 mm
+    (psfnet.py:44-45), then refocus to 1 m -- all with this package's own
+    geometric optics running on the GPU."""
+    from sdirt_amd import Lensgroup
+    lens = Lensgroup(os.path.join(ROOT, "sdirt_amd", "data", "rf50mm.json"),
+                     sensor_res=(512, 768), post_computation=False, device=device)
+    lens.d_sensor = 62.25
+    torch.manual_seed(0)
+    lens.post_computation()
+    lens.refocus(-1000 + lens.d_sensor)
+    return lens
+
+
+def available_cores():
+    """Cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, math.ceil(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def cpu_baseline(lens, points, budget_s=15.0):
+    """Times the CPU oracle (C port of the reference path, OpenMP) on every k-th
+    point of the same volume with the same 4096-spp sample set."""
+    from oracle import oracle as orc
+    st = dict(hfov=lens.hfov, r_last=float(lens.r_last), sensor_size=list(lens.sensor_size),
+              pupil_z=lens.entrance_pupil()[0], pupil_r=lens.entrance_pupil()[1],
+              d_sensor=lens.d_sensor, pixel_size=lens.pixel_size, surfaces=[])
+    for s in lens.surfaces:
+        st["surfaces"].append(dict(kind={0: "plane", 1: "sphere", 2: "asphere"}[s.kind], r=s.r,
+                                   d=float(s.d), c=float(s.c), k=float(s.k),
+                                   ai=[float(a) for a in (s.ai if s.ai is not None else [])],
+                                   n1={repr(0.589): s.mat1.ior(0.589)},
+                                   n2={repr(0.589): s.mat2.ior(0.589)}))
+    cores = available_cores()
+    orc.set_num_threads(cores)
+    rng = np.random.default_rng(0)
+    x2, y2 = orc.pupil_samples(rng.random(SPP, dtype=np.float32), rng.random(SPP, dtype=np.float32),
+                               st["pupil_r"])
+    xc, yc = orc.pupil_samples(rng.random(2048, dtype=np.float32),
+                               rng.random(2048, dtype=np.float32), st["pupil_r"] * 0.25)
+    pts = points.numpy()
+
+    def run(n):
+        sel = pts[:: max(1, len(pts) // n)][:n]
+        t0 = time.perf_counter()
+        orc.psf(st, sel, x2, y2, xc, yc, KS, dp=list(DP))
+        return len(sel), time.perf_counter() - t0
+    n0, t0 = run(64)                                    # calibration (also warms the threads)
+    n = int(min(len(pts), max(64, n0 * budget_s / max(t0, 1e-3))))
+    n = min(n, 4096)                                    # bound memory: [S, n, 3] fp32 x 2
+    n1, t1 = run(n)
+    return {"value": n1 * SPP / t1, "unit": "rays/s", "cores": cores, "kind": "port",
+            "psfs_per_s": n1 / t1,
+            "sample": f"{n1} of the {len(pts)} point sources (every {max(1, len(pts) // n)}-th), "
+                      f"4096 spp + 2048 chief-ray rays each, ks 65, L+R, {t1:.1f} s; "
+                      "oracle/sdirt_oracle.c with OpenMP"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-gather", action="store_true",
+                    help="skip the all-gather of the PSF shards (N > 1)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback exists)"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from sdirt_amd import dist as sd
+    lens = build_lens(device)
+    points_all = volume_points(world)
+    n_total = points_all.shape[0]
+    a, b = sd.shard_bounds(n_total, world)[rank]
+    points_local = points_all[a:b].to(device)
+    n_local = b - a
+
+    if world > 1:
+        sharded = sd.ShardedPSF.from_lens(lens, KS, dp=DP)
+        gather_buf = torch.empty((n_total, 2, KS, KS), dtype=torch.float32, device=device)
+
+    def step():
+        if world == 1:
+            return lens.psf_lr(points_local, ks=KS, spp=SPP, dp=DP)
+        u = sd.broadcast_uniforms(SPP, device)
+        L, R = sharded.render(points_local, u)
+        if not args.no_gather:
+            sd.all_gather_shards(torch.stack((L, R), dim=1), n_total, world, out=gather_buf)
+        return L, R
+
+    def fence():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        step()
+    lens.kernel_events = {}
+    relaunch0 = lens.trips.relaunches
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    ev = lens.kernel_events
+    lens.kernel_events = None
+    k_ms = {k: float(np.mean([e0.elapsed_time(e1) for e0, e1 in v])) for k, v in ev.items()}
+    n_launch = {k: len(v) for k, v in ev.items()}
+
+    if rank == 0:
+        rays = n_total * SPP * args.steps
+        # algorithmic HBM bytes of ONE k_psf_lr launch: read the points,
+        # centres and pupil samples once, write the L and R tiles once.
+        alg_bytes = n_local * (12 + 8) + SPP * 8 + 2 * n_local * KS * KS * 4
+        ach = alg_bytes / (k_ms["psf_lr"] * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(pmc):
+            with open(pmc) as f:
+                traffic = json.load(f).get("k_psf_lr_hbm_bytes_per_launch")
+        res = {
+            "metric": "rays/sec rf50mm 65x65 DP-PSF @4096spp", "value": rays / dt,
+            "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "psfs_per_sec": n_total * args.steps / dt,
+            "config": {"workload": f"rf50mm 32x32x{GRID_Z * world} (x,y,z) PSF volume, "
+                                   f"{n_local} points/GPU, 4096 spp (+2048 chief-ray rays/point), "
+                                   "65x65 L+R PSFs, lambda 0.589um, focus 1 m F/4",
+                       "points_per_gpu": n_local, "spp": SPP, "ks": KS,
+                       "parallelism": f"points sharded over {world} GPU(s)"
+                                      + ("" if world == 1 or args.no_gather
+                                         else " + RCCL all-gather of the PSF volume"),
+                       "newton_trip_policy": lens.trip_policy,
+                       "relaunches_in_timed_region": lens.trips.relaunches - relaunch0},
+            "kernels_ms": k_ms, "kernel_launches": n_launch,
+            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "k_psf_lr", "algorithmic_bytes_per_launch": alg_bytes,
+                         "note": "scalar-per-ray fp32 math: the kernel is VALU-bound by "
+                                 "construction (~9 k VALU instr/ray), see DESIGN.md §3"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(lens, points_all)
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -545,12 +545,19 @@ void or_assign_points_to_pixels(const float* points, const float* ra, const floa
     const float ksm1 = (float)(ks - 1);
     memset(l_grid, 0, sizeof(float) * ks * ks);
     memset(r_grid, 0, sizeof(float) * ks * ks);
+    /* per-ray quantities once, then the four serial scatter passes */
+    float* wl = (float*)malloc(sizeof(float) * S * 2);
+    float* wr_ = wl + S;
+    for (int64_t s = 0; s < S; ++s) {
+        float sl, sr;
+        if (big) dp_weights_big(&p, r_d, x_tan[s * stride], &sl, &sr);
+        else dp_weights_small(&p, x_tan[s * stride], &sl, &sr);
+        wl[s] = sl; wr_[s] = sr;
+    }
     for (int tap = 0; tap < 4; ++tap)
         for (int64_t s = 0; s < S; ++s) {
             const float px = points[2 * s * stride], py = points[2 * s * stride + 1];
-            float sl, sr;
-            if (big) dp_weights_big(&p, r_d, x_tan[s * stride], &sl, &sr);
-            else dp_weights_small(&p, x_tan[s * stride], &sl, &sr);
+            const float sl = wl[s], sr = wr_[s];
             float pn0 = (py - ymaxf) / dyr;              /* row  (:210) */
             float pn1 = (px - xminf) / dxr;              /* col  (:211) */
             float pf0 = pn0 * ksm1, pf1 = pn1 * ksm1;
@@ -572,6 +579,7 @@ void or_assign_points_to_pixels(const float* points, const float* ra, const floa
             l_grid[rr_ * ks + cc_] += wra * sl;
             if (have) r_grid[rr_ * ks + cc_] += wra * sr;
         }
+    free(wl);
 }
 
 /* monte_carlo.py:9-68.  Sensor-plane rays o,d [S][N][3], ra [S][N]; centre [N][2]

@@ -28,8 +28,16 @@ def default_device():
     return torch.device("cuda:0") if torch.cuda.is_available() else torch.device("cpu")
 
 
+def require_gpu(device):
+    if torch.device(device).type != "cuda":
+        raise _lib.SdirtError(f"sdirt_amd runs on the GPU only (device='{device}' given); "
+                              "there is no CPU fallback")
+
+
 def stream_ptr(device=None):
     """hipStream_t of torch's current stream as an integer for ctypes."""
+    if device is not None:
+        require_gpu(device)
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
@@ -130,6 +138,7 @@ class Ray:
 
     # -- construction helpers -------------------------------------------------
     def _init_empty(self, shape, wvln, device):
+        require_gpu(device)
         self.shape = tuple(int(s) for s in shape)
         self.numel = int(np.prod(self.shape)) if len(self.shape) else 1
         self.wvln = wvln if wvln < 10 else wvln * 1e-3      # basics.py:235

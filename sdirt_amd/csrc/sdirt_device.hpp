@@ -82,7 +82,7 @@ __device__ __forceinline__ void normalize3(float& x, float& y, float& z)
 
 // r2 ** n as torch evaluates it on CPU: n==2 -> x*x, n==3 -> (x*x)*x, n>=4 a
 // <=1 ulp vector pow; for n>=4 we return the correctly rounded exact power
-// (product in fp64, rounded once) -- identical to oracle/sdirt_oracle.c:powi.
+// (product in fp64, rounded once).
 __device__ __forceinline__ float powi(float x, int n)
 {
     if (n == 1) return x;

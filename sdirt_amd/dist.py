@@ -1,0 +1,123 @@
+"""One process per GPU: shard a PSF volume over ranks, gather it back over RCCL.
+
+The reference has no multi-GPU PSF path (1_fit_psfnet.py:7 pins one GPU).
+Point sources are independent, so the (x, y, z) grid is partitioned
+contiguously over the ranks; what the ranks must share to stay equal to ONE
+reference call over the whole grid is
+
+  * the pupil sample set (one set for all points, optics.py:482-490): rank 0
+    draws the uniforms from torch's CPU generator, they are broadcast;
+  * the batch-global Newton trip counts (surfaces.py:547): the per-surface
+    convergence masks are OR-reduced over the ranks before the trip table is
+    verified (newton.py), so every rank takes the same decision;
+  * optionally the result: one all-gather of the [N/world, 2, ks, ks] shards
+    (`torch.distributed` backend "nccl" is RCCL on ROCm; xGMI is point-to-point,
+    a gather of a few hundred MB per rank keeps all 7 links of a GPU busy).
+
+Nothing here touches the data path on a single GPU.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .basics import GEO_SPP
+
+
+def shard_bounds(n, world):
+    """Contiguous, balanced partition of range(n): list of (start, stop)."""
+    return [(n * r // world, n * (r + 1) // world) for r in range(world)]
+
+
+def reduce_masks_or(mask, group=None):
+    """Bitwise OR of int32 masks over ranks.  NCCL/RCCL has no BOR: expand the
+    (at most 11 used) bits into 0/1 lanes and take MAX."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return mask
+    bits = torch.arange(0, 11, device=mask.device, dtype=torch.int32)
+    lanes = ((mask.to(torch.int32).unsqueeze(-1) >> bits) & 1).contiguous()
+    dist.all_reduce(lanes, op=dist.ReduceOp.MAX, group=group)
+    return (lanes << bits).sum(-1).to(mask.dtype)
+
+
+def broadcast_uniforms(spp, device, n_center=GEO_SPP, group=None, src=0):
+    """Rank `src` draws rand(spp) x2 then rand(n_center) x2 from the CPU default
+    generator -- the reference's draw order inside one psf_diff call
+    (optics.py:483-484 twice) -- every rank receives the same numbers."""
+    total = 2 * spp + 2 * n_center
+    if dist.get_rank(group) == src:
+        u = torch.cat([torch.rand(spp), torch.rand(spp), torch.rand(n_center),
+                       torch.rand(n_center)]).to(device)
+    else:
+        u = torch.empty(total, dtype=torch.float32, device=device)
+    if dist.get_world_size(group) > 1:
+        dist.broadcast(u, src=src, group=group)
+    return u[:spp], u[spp:2 * spp], u[2 * spp:2 * spp + n_center], u[2 * spp + n_center:]
+
+
+def all_gather_shards(local, n_total, world, group=None, out=None):
+    """local: [n_local, ...] shard of a contiguous partition (shard_bounds) ->
+    [n_total, ...] on every rank.  Shards are padded to the largest one so a
+    single all_gather_into_tensor moves everything."""
+    bounds = shard_bounds(n_total, world)
+    width = max(b - a for a, b in bounds)
+    tail = tuple(local.shape[1:])
+    if local.shape[0] != width:
+        pad = torch.zeros((width,) + tail, dtype=local.dtype, device=local.device)
+        pad[:local.shape[0]] = local
+        local = pad
+    if out is None or out.shape != (world * width,) + tail:
+        out = torch.empty((world * width,) + tail, dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+    if all(b - a == width for a, b in bounds):
+        return out
+    return torch.cat([out[r * width:r * width + (b - a)] for r, (a, b) in enumerate(bounds)])
+
+
+class ShardedPSF:
+    """psf_lr over a point grid partitioned across the ranks of `group`.
+
+    render(points_local, u) -> (L, R) is normally Lensgroup-backed
+    (`from_lens`); tests substitute a CPU stand-in to exercise the partition /
+    broadcast / gather logic under gloo.
+    """
+
+    def __init__(self, render, device, group=None):
+        self.render, self.device, self.group = render, torch.device(device), group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+
+    @classmethod
+    def from_lens(cls, lens, ks, wvln=0.589, dp=(0.78, 1.44, 0.3, 0.5), group=None):
+        from . import _lib
+        from .basics import dptr, stream_ptr
+        lens.mask_reduce = lambda m: reduce_masks_or(m, group)
+
+        def disc(u_t, u_r, radius):
+            xy = torch.empty((2, u_t.shape[0]), dtype=torch.float32, device=lens.device)
+            _lib.check(_lib.lib().sdirt_pupil_samples(dptr(u_t), dptr(u_r), u_t.shape[0],
+                                                      float(radius), dptr(xy[0]), dptr(xy[1]),
+                                                      stream_ptr(lens.device)))
+            return xy[0], xy[1]
+
+        def render(points_local, u):
+            _, pr = lens.entrance_pupil()
+            return lens.psf_lr(points_local, ks=ks, wvln=wvln, dp=dp,
+                               pupil_xy=disc(u[0], u[1], pr),
+                               center_pupil_xy=disc(u[2], u[3], pr * 0.25))
+        return cls(render, lens.device, group)
+
+    def local_slice(self, n_total):
+        return shard_bounds(n_total, self.world)[self.rank]
+
+    def psf_volume(self, points, spp, gather=True):
+        """points [N,3] (the same on every rank) -> (L, R) of all N points when
+        gather, else of this rank's shard."""
+        n_total = points.shape[0]
+        a, b = self.local_slice(n_total)
+        u = broadcast_uniforms(spp, self.device, group=self.group)
+        L, R = self.render(points[a:b], u)
+        if not gather or self.world == 1:
+            return L, R
+        both = torch.stack((L, R), dim=1)                   # [n_local, 2, ks, ks]
+        full = all_gather_shards(both, n_total, self.world, self.group)
+        return full[:, 0], full[:, 1]

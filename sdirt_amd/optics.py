@@ -53,6 +53,27 @@ class _DevLens:
             pass
 
 
+class _EventBracket:
+    """Records a (start, end) HIP event pair on torch's current stream -- the
+    stream the kernels are launched on -- when profiling is switched on."""
+
+    def __init__(self, sink, name, device):
+        self.sink, self.name, self.device = sink, name, device
+
+    def __enter__(self):
+        if self.sink is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record(torch.cuda.current_stream(self.device))
+        return self
+
+    def __exit__(self, *exc):
+        if self.sink is not None:
+            self.e1.record(torch.cuda.current_stream(self.device))
+            self.sink.setdefault(self.name, []).append((self.e0, self.e1))
+        return False
+
+
 class Lensgroup:
     """optics.py:22-116.  `device` must be a CUDA (ROCm) device for anything that traces."""
 
@@ -71,6 +92,9 @@ class Lensgroup:
         self.trip_policy = "reference"
         #: optional hook reducing convergence masks over ranks (set by sdirt_amd.dist)
         self.mask_reduce = None
+        #: when a dict, kernel launches are bracketed with HIP events on the launch
+        #: stream: {'psf_lr': [(start, end), ...], 'chief_center': [...]}  (bench.py)
+        self.kernel_events = None
         if filename is not None:
             self.lens_name = filename
             self.load_file(filename, use_roc, sensor_res, post_computation)
@@ -200,6 +224,9 @@ class Lensgroup:
                 dl = _DevLens(self.surfaces, key)
             self._dev[key] = dl
         return dl.handle
+
+    def _timed(self, name):
+        return _EventBracket(self.kernel_events, name, self.device)
 
     def _curved(self):
         return [s.kind != _lib.KIND_PLANE for s in self.surfaces]
@@ -358,10 +385,11 @@ class Lensgroup:
         handle = self.dev_lens(DEFAULT_WAVE)                      # optics.py:900: always green
 
         def enqueue(trips, mask_ptr):
-            _lib.check(_lib.lib().sdirt_chief_center(
-                handle, dptr(po), po.shape[0], dptr(xc), dptr(yc), xc.shape[0], float(pupilz),
-                float(self.d_sensor), trips, dptr(center), dptr(anyv), mask_ptr,
-                stream_ptr(self.device)))
+            with self._timed("chief_center"):
+                _lib.check(_lib.lib().sdirt_chief_center(
+                    handle, dptr(po), po.shape[0], dptr(xc), dptr(yc), xc.shape[0], float(pupilz),
+                    float(self.d_sensor), trips, dptr(center), dptr(anyv), mask_ptr,
+                    stream_ptr(self.device)))
         self._run_with_trips(("center",), range(len(self.surfaces)), enqueue)
         if self.trip_policy == "reference":
             assert int(anyv.item()) == 1, "No sampled rays is valid."   # optics.py:902
@@ -435,10 +463,12 @@ class Lensgroup:
         flags = _lib.PSF_NORMALIZE if normalize else 0
 
         def enqueue(trips, mask_ptr):
-            _lib.check(_lib.lib().sdirt_psf_lr(
-                handle, dptr(po), N, dptr(x2), dptr(y2), spp, float(pupilz), float(self.d_sensor),
-                float(self.pixel_size), ks, dptr(cen), C.byref(dpp) if dpp is not None else None,
-                trips, flags, dptr(L), dptr(R), mask_ptr, stream_ptr(self.device)))
+            with self._timed("psf_lr"):
+                _lib.check(_lib.lib().sdirt_psf_lr(
+                    handle, dptr(po), N, dptr(x2), dptr(y2), spp, float(pupilz),
+                    float(self.d_sensor), float(self.pixel_size), ks, dptr(cen),
+                    C.byref(dpp) if dpp is not None else None, trips, flags, dptr(L), dptr(R),
+                    mask_ptr, stream_ptr(self.device)))
         wkey = round(float(wvln if wvln < 10 else wvln * 1e-3), 6)
         self._run_with_trips(("psf", wkey), range(len(self.surfaces)), enqueue)
         if R is None and want_r:

@@ -1,0 +1,219 @@
+"""Host-side logic of sdirt_amd (no GPU): lens loading and materials, the Newton
+trip-table speculation/verification, the C-ABI surface of libsdirt_dp.so, error
+behaviour without a device."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import DATA, ROOT, load_state
+
+REF_JSON = "/root/reference/lenses/{}/lens_web.json"
+
+
+@pytest.mark.parametrize("name", ["rf50mm", "rf35mm"])
+def test_lens_loader_and_materials(name):
+    from sdirt_amd import Lensgroup
+    st = load_state(name)
+    lens = Lensgroup(os.path.join(DATA, f"{name}.json"), sensor_res=(512, 768),
+                     post_computation=False, device="cpu")
+    assert lens.aper_idx == st["aper_idx"]                        # optics.py:193-201
+    assert lens.pixel_size == st["pixel_size"] and float(lens.r_last) == st["r_last"]
+    assert len(lens.surfaces) == len(st["surfaces"])
+    kinds = {0: "plane", 1: "sphere", 2: "asphere"}
+    for s, ref in zip(lens.surfaces, st["surfaces"]):
+        assert kinds[s.kind] == ref["kind"]
+        assert s.r == ref["r"] and float(s.d) == ref["d"] and float(s.c) == ref["c"]
+        assert float(s.k) == ref["k"]
+        assert [float(a) for a in (s.ai if s.ai is not None else [])] == ref["ai"]
+        for w, n1 in ref["n1"].items():                           # Material.ior, float64 equal
+            assert s.mat1.ior(float(w)) == n1
+            assert s.mat2.ior(float(w)) == ref["n2"][w]
+    # the reference's own JSON schema loads to the same prescription (container only)
+    if os.path.exists(REF_JSON.format(name)):
+        l2 = Lensgroup(REF_JSON.format(name), sensor_res=(512, 768), post_computation=False,
+                       device="cpu")
+        for a, b in zip(lens.surfaces, l2.surfaces):
+            assert a.surf_dict() == b.surf_dict()
+    d = lens.surfaces[0].desc(0.589)
+    assert d.kind == 1 and d.n1 == 1.0 and d.n2 == st["surfaces"][0]["n2"]["0.589"]
+
+
+def test_material_models():
+    from sdirt_amd import Material
+    from sdirt_amd.basics import register_material
+    assert Material("air").ior(0.589) == 1.0 and Material(None).ior(0.45) == 1.0
+    m = Material("1.5168/64.17")
+    assert abs(m.ior(0.5893) - 1.5168) < 1e-9                     # Cauchy through n_d
+    assert m.ior(0.486) > m.ior(0.656)                            # normal dispersion
+    assert m.ior(589.3) == m.ior(0.5893)                          # nm input (basics.py:324)
+    register_material("testglass", "sellmeier", [1.0396, 6.0006e-3, 2.3179e-1, 2.0017e-2, 1.0104, 103.56])
+    assert abs(Material("testglass").ior(0.5876) - 1.5168) < 2e-4
+    with pytest.raises(ValueError):
+        Material("unobtainium")
+
+
+def test_point_source_grid_and_scale():
+    from sdirt_amd import Lensgroup
+    st = load_state("rf50mm")
+    lens = Lensgroup(os.path.join(DATA, "rf50mm.json"), sensor_res=(512, 768),
+                     post_computation=False, device="cpu").set_state(hfov=st["hfov"])
+    g = lens.point_source_grid(depth=-1000.0, grid=5)
+    assert g.shape == (5, 5, 3) and float(g[0, 0, 0]) == pytest.approx(-0.98)
+    assert float(g[0, 0, 1]) == pytest.approx(0.98) and (g[..., 2] == -1000).all()
+    gc = lens.point_source_grid(depth=-1000.0, grid=5, center=True)
+    assert float(gc[0, 0, 0]) == pytest.approx(-1 + 1 / 8)
+    assert lens.point_source_grid(depth=-5.0, grid=1).shape == (1, 1, 3)
+    assert lens.calc_scale_pinhole(-1000.0) == pytest.approx(1000 * np.tan(st["hfov"]) / st["r_last"])
+    assert lens.calc_efl() == pytest.approx(st["foclen"], rel=1e-12)
+
+
+def test_intersect_lines_2d():
+    from sdirt_amd.optics import intersect_lines_2d
+    o = np.array([[0.0, 0.0], [2.0, 0.0], [0.0, 3.0]])
+    d = np.array([[1.0, 1.0], [-1.0, 1.0], [1.0, 0.0]])
+    p = intersect_lines_2d(o, d)
+    assert p.shape == (3, 2)
+    assert np.allclose(p[0], [1, 1]) and np.allclose(p[1], [3, 3]) and np.allclose(p[2], [-1, 3])
+    assert len(intersect_lines_2d(o[:2], np.array([[1.0, 0.0], [2.0, 0.0]]))) == 0   # parallel
+
+
+# ------------------------------------------------------------------ newton.py
+def masks_for(trips, need):
+    """Mask a kernel would report: bit j set while the slowest ray has not converged."""
+    out = []
+    for T, t in zip(trips, need):
+        m = 0
+        for j in range(1, int(T) + 1):
+            if j < t or t > 10:
+                m |= 1 << j
+        out.append(m)
+    return out
+
+
+def test_verify_accepts_exact_table_and_corrects_wrong_ones():
+    from sdirt_amd.newton import verify
+    curved = [True, True, False, True]
+    need = [10, 3, 0, 4]
+    ok, new = verify([10, 3, 0, 4], masks_for([10, 3, 0, 4], need), range(4), curved)
+    assert ok and list(new) == [10, 3, 0, 4]
+    # too many trips on surface 1: the first clear bit is the reference's count
+    ok, new = verify([10, 6, 0, 4], masks_for([10, 6, 0, 4], need), range(4), curved)
+    assert not ok and new[1] == 3
+    # too few: ask for the full mask
+    ok, new = verify([10, 2, 0, 4], masks_for([10, 2, 0, 4], need), range(4), curved)
+    assert not ok and new[1] == 10
+    # never converging surface stays at the cap and is accepted (rule `it < 10`)
+    ok, new = verify([10, 3, 0, 4], masks_for([10, 3, 0, 4], [11, 3, 0, 4]), range(4), curved)
+    assert ok
+    # reversed traversal order (backward tracing)
+    ok, new = verify([4, 0, 3], masks_for([4, 0, 3], [4, 0, 3]), [2, 1, 0], [True, False, True])
+    assert ok
+
+
+def test_trip_planner_converges_and_caches():
+    from sdirt_amd.newton import TripPlanner
+    curved = [True] * 5 + [False] + [True] * 6
+    need = [10, 3, 4, 3, 4, 0, 3, 3, 4, 4, 2, 3]                  # fixture f2's reference trips
+    calls = []
+
+    def launch(trips):
+        calls.append(list(trips))
+        return masks_for(trips, need)
+    pl = TripPlanner()
+    got = pl.run("k", curved, range(12), launch)
+    assert list(got) == need and len(calls) == 2                  # cold: one discovery + one verify
+    got = pl.run("k", curved, range(12), launch)
+    assert list(got) == need and len(calls) == 3                  # warm: single launch
+    # batch changes (one surface now needs one trip more): one corrective relaunch
+    need[2] = 5
+    got = pl.run("k", curved, range(12), launch)
+    assert list(got) == need and len(calls) <= 6
+
+
+# ------------------------------------------------------------------ C ABI
+def header_symbols():
+    txt = open(os.path.join(ROOT, "include", "sdirt_dp.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return set(re.findall(r"\b(sdirt_[a-z0-9_]+)\s*\(", txt))
+
+
+def test_library_exports_every_declared_symbol():
+    from sdirt_amd import _lib
+    syms = header_symbols()
+    assert len(syms) >= 19
+    assert syms == set(_lib.SIGNATURES), syms ^ set(_lib.SIGNATURES)
+    h = _lib.lib()                                                # loads, or raises loudly
+    for s in syms:
+        assert hasattr(h, s), f"libsdirt_dp.so does not export {s}"
+    assert h.sdirt_abi_version() == 1
+
+
+def test_ctypes_structs_match_the_c_header(tmp_path):
+    """Compile include/sdirt_dp.h as plain C and compare struct layouts with the ctypes mirror."""
+    import subprocess
+    from sdirt_amd import _lib
+    src = tmp_path / "abi.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "sdirt_dp.h"\n'
+                   'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %d\\n",'
+                   'sizeof(sdirt_surface_desc), offsetof(sdirt_surface_desc, r),'
+                   'offsetof(sdirt_surface_desc, ai), offsetof(sdirt_surface_desc, n1),'
+                   'sizeof(sdirt_rays), offsetof(sdirt_rays, obliq), sizeof(sdirt_dp_params),'
+                   'SDIRT_MAX_SURFACES);return 0;}\n')
+    exe = tmp_path / "abi"
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror",
+                           "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    S = _lib.SurfaceDesc
+    assert got == [ctypes.sizeof(S), S.r.offset, S.ai.offset, S.n1.offset, ctypes.sizeof(_lib.Rays),
+                   _lib.Rays.obliq.offset, ctypes.sizeof(_lib.DpParams), _lib.MAX_SURFACES]
+
+
+def test_no_product_import_of_the_oracle():
+    """The product must never route through oracle/ (or any CPU path)."""
+    for root, _, files in os.walk(os.path.join(ROOT, "sdirt_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                src = open(os.path.join(root, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src, f
+                assert "sdirt_oracle" not in src, f
+
+
+def test_argument_validation_without_a_device():
+    from sdirt_amd import _lib
+    h = _lib.lib()
+    assert h.sdirt_lens_create(None, 3, None) == -1
+    assert b"null" in h.sdirt_last_error()
+    arr = (_lib.SurfaceDesc * 1)()
+    arr[0].kind = 7
+    out = ctypes.c_void_p()
+    assert h.sdirt_lens_create(arr, 1, ctypes.byref(out)) == -1 and b"kind" in h.sdirt_last_error()
+    arr[0].kind, arr[0].c = 1, 0.0                                # sphere with c == 0
+    arr[0].n1 = arr[0].n2 = 1.0
+    assert h.sdirt_lens_create(arr, 1, ctypes.byref(out)) == -1
+    assert h.sdirt_lens_create(arr, 0, ctypes.byref(out)) == -1
+    assert h.sdirt_psf_normalize(None, 1, 5, None) == -1
+    with pytest.raises(_lib.SdirtError):
+        _lib.check(h.sdirt_points_to_object(None, 1, 0.1, 1.0, 36.0, 24.0, None, None))
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_tracing_without_gpu_fails_loudly():
+    from sdirt_amd import Lensgroup, SdirtError
+    from sdirt_amd import monte_carlo, render_psf
+    lens = Lensgroup(os.path.join(DATA, "rf50mm.json"), sensor_res=(512, 768),
+                     post_computation=False, device="cpu")
+    lens.set_state(hfov=0.39, pupil=(22.5, 6.0))
+    with pytest.raises(SdirtError):
+        lens.psf(torch.tensor([[0.0, 0.0, -1000.0]]), ks=5, spp=8)
+    with pytest.raises(SdirtError):
+        lens.post_computation()                                   # geometric optics trace too
+    with pytest.raises(SdirtError):
+        monte_carlo.assign_points_to_pixels_small_r(torch.zeros(4, 2), 5, [-1, 1], [-1, 1],
+                                                    torch.ones(4), x_tan=torch.zeros(4))
+    with pytest.raises(SdirtError):
+        render_psf.local_psf_render_fast(torch.zeros(1, 3, 4, 4), torch.zeros(1, 4, 4, 2, 3, 3), 3)

@@ -1,0 +1,146 @@
+"""The CPU oracle (oracle/sdirt_oracle.c) pinned against the reference's own
+outputs (tests/golden/*.npz, written by oracle/gen_golden.py from the real
+reference running on CPU).  No GPU needed.
+
+What is EQUAL: Newton trip counts (the batch-global loop rule), every validity
+flag after every surface, object-space points, normalised directions given the
+same pupil points.  What is CLOSE, and why it cannot be equal: torch's CPU
+sqrt / sin / cos / acos are MKL VML kernels (<1 ulp but not correctly rounded:
+0.4 % of sqrt and 5 % of cos results are 1 ulp off IEEE), r2**4..6 goes through
+a <=1-ulp vector pow, and torch.sum's reduction order over the spp axis depends
+on the CPU's vector width.  The oracle is the IEEE evaluation of the same
+operation sequence.
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden, load_state, ulp_diff
+
+DP = [0.78, 1.44, 0.3, 0.5]
+CASES = [("rf50mm", "f1_rf50_c1"), ("rf50mm", "f2_rf50_pts4"), ("rf35mm", "f3_rf35_pts4")]
+
+
+@pytest.mark.parametrize("lens_name,fx", CASES)
+def test_points_and_sampling(oracle, lens_name, fx):
+    st, g = load_state(lens_name), load_golden(fx)
+    po = oracle.points_to_object(g["points"], st)
+    assert np.array_equal(po, g["ray_o0"][0])
+    # reference pupil points -> bit-equal normalised directions (FMA-chain norm)
+    o, d, ra, ob = oracle.sample_rays(po, g["pupil_x2"], g["pupil_y2"], st["pupil_z"])
+    assert np.array_equal(o, g["ray_o0"]) and np.array_equal(d, g["ray_d0"])
+    # own disc mapping: within 1 ulp of MKL's sin/cos/sqrt on every sample
+    x2, y2 = oracle.pupil_samples(g["u_theta"], g["u_r2"], st["pupil_r"])
+    assert ulp_diff(x2, g["pupil_x2"]).max() <= 2 and ulp_diff(y2, g["pupil_y2"]).max() <= 2
+    assert np.mean(x2 == g["pupil_x2"]) > 0.9
+
+
+@pytest.mark.parametrize("lens_name,fx", CASES)
+def test_trace_every_surface(oracle, lens_name, fx):
+    st, g = load_state(lens_name), load_golden(fx)
+    surf = oracle.surfaces_from_state(st, 0.589)
+    S, N = g["ray_d0"].shape[:2]
+    out = oracle.trace(surf, g["ray_o0"], g["ray_d0"], np.ones((S, N), np.float32), record=True)
+    assert np.array_equal(out["trips"], g["trips"])           # reference's global loop rule
+    for k in range(len(surf)):
+        assert np.array_equal(out["rec_ra"][k], g["surf_ra"][k]), f"validity, surface {k}"
+        assert np.abs(out["rec_o"][k] - g["surf_o"][k]).max() < 2e-5, f"position, surface {k}"
+        assert np.abs(out["rec_d"][k] - g["surf_d"][k]).max() < 2e-6, f"direction, surface {k}"
+        assert np.mean(out["rec_o"][k] == g["surf_o"][k]) > 0.95
+    # first surface: no MKL-sqrt-dependent quantity has entered o yet -> bit exact
+    assert np.array_equal(out["rec_o"][0], g["surf_o"][0])
+    # forcing the table gives the same rays as discovering it
+    out2 = oracle.trace(surf, g["ray_o0"], g["ray_d0"], np.ones((S, N), np.float32), trips=g["trips"])
+    assert np.array_equal(out2["o"], out["o"]) and np.array_equal(out2["d"], out["d"])
+
+
+@pytest.mark.parametrize("lens_name,fx", CASES)
+def test_chief_ray_centre(oracle, lens_name, fx):
+    st, g = load_state(lens_name), load_golden(fx)
+    surf = oracle.surfaces_from_state(st, 0.589)
+    ones = np.ones(g["cen_d0"].shape[:2], np.float32)
+    out = oracle.trace(surf, g["cen_o0"], g["cen_d0"], ones)
+    assert np.array_equal(out["trips"], g["trips_center"])
+    assert np.array_equal(out["ra"], g["cen_ra_last"])
+    assert np.abs(out["o"] - g["cen_o_last"]).max() < 1e-5
+    osen = oracle.propagate_to(st["d_sensor"], out["o"], out["d"])
+    cen, ok = oracle.center_from_rays(osen, out["ra"])
+    assert ok and np.abs(cen - g["center"]).max() < 4e-6
+    # summation alone (reference's own sensor rays): <= 2 ulp of the larger coordinate
+    oref = oracle.propagate_to(st["d_sensor"], g["cen_o_last"], g["cen_d_last"])
+    cen2, _ = oracle.center_from_rays(oref, g["cen_ra_last"])
+    assert np.abs(cen2 - g["center"]).max() <= 2 * np.spacing(np.abs(g["center"]).max())
+
+
+@pytest.mark.parametrize("lens_name,fx", CASES)
+def test_splat_and_normalise_from_reference_rays(oracle, lens_name, fx):
+    st, g = load_state(lens_name), load_golden(fx)
+    ks = int(g["ks"])
+    osen = oracle.propagate_to(st["d_sensor"], g["surf_o"][-1], g["surf_d"][-1])
+    lg, rg = oracle.forward_integral(osen, g["surf_d"][-1], g["surf_ra"][-1], st["pixel_size"], ks,
+                                     g["center"], None)
+    assert np.abs(lg - g["grid_l"]).max() <= 2e-7 * g["grid_l"].max() + 1e-7
+    assert not rg.any() and not g["grid_r"].any()           # param_list=None: R stays zero
+    assert np.abs(oracle.psf_normalize(lg) - g["psf"]).max() < 1e-6
+
+
+@pytest.mark.parametrize("tag,dp", [("dp_l", DP), ("dp_r", DP), ("bigr", [0.78, 1.44, 0.3, 0.6])])
+def test_dual_pixel_parameter_list(oracle, tag, dp):
+    st, g0, g = load_state("rf50mm"), load_golden("f2_rf50_pts4"), load_golden("f2_rf50_pts4_" + tag)
+    osen = oracle.propagate_to(st["d_sensor"], g0["surf_o"][-1], g0["surf_d"][-1])
+    lg, rg = oracle.forward_integral(osen, g0["surf_d"][-1], g0["surf_ra"][-1], st["pixel_size"], 33,
+                                     g["center"], dp)
+    first, second = (rg, lg) if tag == "dp_r" else (lg, rg)    # direct != 'l' swaps the pair
+    assert np.abs(first - g["grid_l"]).max() <= 3e-7 * g["grid_l"].max()
+    assert np.abs(second - g["grid_r"]).max() <= 3e-7 * g["grid_r"].max()
+    assert np.abs(oracle.psf_normalize(first) - g["psf"]).max() < 1e-6
+
+
+def test_splat_synthetic_and_window_edges(oracle):
+    g = load_golden("f5_splat")
+    ks, ps = int(g["ks"]), float(g["ps"])
+    rng = [(-ks / 2 + 0.5) * ps, (ks / 2 - 0.5) * ps]
+    for tag in ("small", "small_r04", "big", "default"):
+        dp = None if tag == "default" else g[f"{tag}_param"]
+        lg, rg = oracle.assign_points_to_pixels(g["points"], g["ra"], g["x_tan"], ks, rng, dp)
+        assert np.abs(lg - g[f"{tag}_l"]).max() <= 3e-7 * g[f"{tag}_l"].max()
+        assert np.abs(rg - g[f"{tag}_r"]).max() <= 3e-7 * max(g[f"{tag}_r"].max(), 1e-30)
+    e = load_golden("f6_window_edges")
+    lg, rg = oracle.forward_integral(e["o"], e["d"], e["ra"], float(e["ps"]), int(e["ks"]),
+                                     e["center"], DP)
+    assert np.abs(lg - e["grid_l"]).max() <= 3e-7 and np.abs(rg - e["grid_r"]).max() <= 3e-7
+    assert np.abs(lg - e["psf_l"]).max() <= 3e-7             # forward_integral returns RAW L
+    # energy: s_l + s_r <= 1 per ray -> the two grids together stay below the ray count
+    assert lg.sum() + rg.sum() <= e["ra"].sum()
+    # probe rays: exactly on the window limit -> dropped, one ulp inside -> kept
+    lim = np.float32((int(e["ks"]) / 2 - 0.5 - 0.01) * float(e["ps"]))
+    o = np.zeros((2, 1, 3), np.float32); o[0, 0, 0] = lim; o[1, 0, 0] = np.nextafter(lim, np.float32(0))
+    d = np.zeros((2, 1, 3), np.float32); d[..., 2] = 1
+    one = np.ones((2, 1), np.float32); zc = np.zeros((1, 2), np.float32)
+    l0, _ = oracle.forward_integral(o[:1], d[:1], one[:1], float(e["ps"]), int(e["ks"]), zc, DP)
+    l1, _ = oracle.forward_integral(o[1:], d[1:], one[1:], float(e["ps"]), int(e["ks"]), zc, DP)
+    assert l0.sum() == 0 and l1.sum() > 0
+
+
+def test_end_to_end_mini_config2(oracle):
+    """Oracle psf() with the reference's pupil points vs the reference's PSFs
+    (3x3x3 volume, 4096 spp, ks 65): documents the attainable agreement."""
+    st, g, gr = load_state("rf50mm"), load_golden("f8_rf50_mini_c2"), load_golden("f8_rf50_mini_c2_r")
+    lo, ro, co, ok = oracle.psf(st, g["points"], g["pupil_x2"], g["pupil_y2"], g["pupil_xc"],
+                                g["pupil_yc"], 65, dp=DP)
+    assert ok
+    assert np.abs(co - g["center"]).max() < 4e-6
+    dl, dr = np.abs(lo - g["psf"]), np.abs(ro - gr["psf"])
+    assert dl.max() <= 6e-5 and dr.max() <= 6e-5
+    assert np.median(dl[g["psf"] > 1e-3]) <= 3e-6
+
+
+def test_rgb_wavelength_tables(oracle):
+    """psf_rgb (optics.py:999-1015): three fresh psf_diff calls, each centred on the
+    GREEN chief ray (optics.py:900)."""
+    st, g = load_state("rf50mm"), load_golden("f4_rf50_rgb")
+    for i, w in enumerate(g["wvlns"]):
+        lo, _, co, ok = oracle.psf(st, g["points"], g["pupil_x"][i], g["pupil_y"][i],
+                                   g["pupil_xc"][i], g["pupil_yc"][i], 17, wvln=float(w), dp=None)
+        assert ok and np.abs(co - g["centers"][i]).max() < 4e-6
+        assert np.abs(lo - g["psf"][:, i]).max() <= 3e-4       # 64 rays: single-ray sensitivity
+    assert np.array_equal(g["trips"].shape, (6, 12))
