@@ -110,7 +110,7 @@ def cpu_baseline(lens, points, budget_s=15.0):
         return len(sel), time.perf_counter() - t0
     n0, t0 = run(64)                                    # calibration (also warms the threads)
     n = int(min(len(pts), max(64, n0 * budget_s / max(t0, 1e-3))))
-    n = min(n, 4096)                                    # bound memory: [S, n, 3] fp32 x 2
+    n = min(n, 16384)                                   # bound memory: [S, n, 3] fp32 x 2 = 2.1 GB
     n1, t1 = run(n)
     return {"value": n1 * SPP / t1, "unit": "rays/s", "cores": cores, "kind": "port",
             "psfs_per_s": n1 / t1,

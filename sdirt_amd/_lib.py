@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libsdirt_dp.so")
+# SDIRT_AMD_LIB overrides the path (kernel-variant A/B runs in tools/kbench.py only)
+LIB_PATH = os.environ.get("SDIRT_AMD_LIB") or os.path.join(HERE, "libsdirt_dp.so")
 
 MAX_SURFACES = 64
 MAX_AI = 8

@@ -50,10 +50,28 @@ struct DevDpParams {
     float tr, tl;        // big-r only: asin(0.5/r), pi - tr  monte_carlo.py:275-276
     int32_t big;         // r > 0.5                           monte_carlo.py:59
     int32_t have_r;      // param_list is not None -> R grid is filled (:231)
+    int32_t r_pow2;      // r is a power of two: x / r == x * inv_r exactly
+    float inv_r;
 };
 
 struct Ray {
     float ox, oy, oz, dx, dy, dz, ra, ob;
+};
+
+// Math policies.  Ieee: correctly rounded / and sqrt (hipcc's default expansion),
+// the parity mode -- bit-identical to an IEEE CPU evaluation.  Fast: one-ulp
+// hardware reciprocal / square root (v_rcp_f32, v_sqrt_f32); results move by a
+// few ulp per operation, i.e. by what torch's own MKL kernels differ from IEEE.
+struct Ieee {
+    static __device__ __forceinline__ float div(float a, float b) { return a / b; }
+    static __device__ __forceinline__ float sqrt(float x) { return __builtin_sqrtf(x); }
+};
+struct Fast {
+    static __device__ __forceinline__ float div(float a, float b)
+    {
+        return a * __builtin_amdgcn_rcpf(b);
+    }
+    static __device__ __forceinline__ float sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 };
 
 __device__ __forceinline__ float clampf(float v, float lo, float hi)
@@ -68,16 +86,17 @@ __device__ __forceinline__ float clampf(float v, float lo, float hi)
 // torch.nn.functional.normalize over a last dim of 3 (basics.py:245,
 // surfaces.py:628): v / max(||v||, 1e-12); torch's CPU kernel accumulates the
 // squares with fused multiply-adds (x*x, then fma y, then fma z).
+template <class M>
 __device__ __forceinline__ void normalize3(float& x, float& y, float& z)
 {
     float acc = x * x;
     acc = __builtin_fmaf(y, y, acc);
     acc = __builtin_fmaf(z, z, acc);
-    float nrm = __builtin_sqrtf(acc);
+    float nrm = M::sqrt(acc);
     nrm = nrm < 1e-12f ? 1e-12f : nrm;
-    x = x / nrm;
-    y = y / nrm;
-    z = z / nrm;
+    x = M::div(x, nrm);
+    y = M::div(y, nrm);
+    z = M::div(z, nrm);
 }
 
 // r2 ** n as torch evaluates it on CPU: n==2 -> x*x, n==3 -> (x*x)*x, n>=4 a
@@ -94,13 +113,14 @@ __device__ __forceinline__ float powi(float x, int n)
 }
 
 // surfaces.py:787-808 and 811-830 evaluated together (they share sqrt(1-a)).
+template <class M>
 __device__ __forceinline__ void sag_g_dgd(const DevSurface& s, float r2, float& g, float& dgd)
 {
     const float a = (s.onepk * r2) * s.c2;
-    const float sf = __builtin_sqrtf(1.0f - a);
+    const float sf = M::sqrt(1.0f - a);
     const float onesf = 1.0f + sf;
-    g = (r2 * s.c) / onesf;
-    dgd = ((onesf + (a / 2.0f) / sf) * s.c) / (onesf * onesf);
+    g = M::div(r2 * s.c, onesf);
+    dgd = M::div((onesf + M::div(a / 2.0f, sf)) * s.c, onesf * onesf);
     if (s.ai_degree > 0) {
         dgd = dgd + s.ai[0];
         g = g + s.ai[0] * r2;
@@ -113,10 +133,11 @@ __device__ __forceinline__ void sag_g_dgd(const DevSurface& s, float r2, float& 
     }
 }
 
+template <class M>
 __device__ __forceinline__ float sag_dgd_only(const DevSurface& s, float r2)
 {
     float g, dgd;
-    sag_g_dgd(s, r2, g, dgd);
+    sag_g_dgd<M>(s, r2, g, dgd);
     return dgd;
 }
 
@@ -125,11 +146,12 @@ __device__ __forceinline__ float sag_dgd_only(const DevSurface& s, float r2)
 // mask_out (wave-uniform, lives in SGPRs) gets bit j set when ANY active lane of
 // the wave had |f(t)| > 50e-6 in trip j -- the per-wave share of the reference's
 // batch-wide `.any()` loop condition (surfaces.py:547).
+template <class M>
 __device__ __forceinline__ bool newton(const DevSurface& s, const Ray& r, int trips, float& t_out,
                                        uint32_t& mask_out)
 {
     const float tol_loose = (float)50e-6, tol_tight = (float)10e-6, eps = (float)1e-9;
-    const float t0 = (s.d - r.oz) / r.dz;
+    const float t0 = M::div(s.d - r.oz, r.dz);
     const float dd = r.dx * r.dx + r.dy * r.dy;
     const float dox = r.dx * r.ox + r.dy * r.oy;
     const bool alive = r.ra > 0.0f;
@@ -143,12 +165,12 @@ __device__ __forceinline__ bool newton(const DevSurface& s, const Ray& r, int tr
         const float x = nx * vf, y = ny * vf;
         const float r2 = x * x + y * y;
         float g, dgd;
-        sag_g_dgd(s, r2, g, dgd);
+        sag_g_dgd<M>(s, r2, g, dgd);
         const float ft = (g + s.d) - nz;
         const float dr2dt = 2.0f * (dd * t + dox);
         const float dfdt = dgd * dr2dt - r.dz;
         mask |= (__ballot(__builtin_fabsf(ft) > tol_loose) != 0ull) ? (1u << it) : 0u;
-        t = t - clampf(ft / (dfdt + eps), -kNewtonStepBound, kNewtonStepBound);
+        t = t - clampf(M::div(ft, dfdt + eps), -kNewtonStepBound, kNewtonStepBound);
     }
     mask_out = mask;
     const float t1 = t - t0;   // :563
@@ -161,11 +183,11 @@ __device__ __forceinline__ bool newton(const DevSurface& s, const Ray& r, int tr
     const float x = nx * vf, y = ny * vf;
     const float r2 = x * x + y * y;
     float g, dgd;
-    sag_g_dgd(s, r2, g, dgd);
+    sag_g_dgd<M>(s, r2, g, dgd);
     const float ft = (g + s.d) - nz;
     const float dr2dt = 2.0f * (dd * t + dox);
     const float dfdt = dgd * dr2dt - r.dz;
-    t = t - clampf(ft / (dfdt + eps), -kNewtonStepBound, kNewtonStepBound);
+    t = t - clampf(M::div(ft, dfdt + eps), -kNewtonStepBound, kNewtonStepBound);
     nx = r.ox + r.dx * t;
     ny = r.oy + r.dy * t;
     rr = nx * nx + ny * ny;
@@ -177,7 +199,7 @@ __device__ __forceinline__ bool newton(const DevSurface& s, const Ray& r, int tr
 
 // surfaces.py:633-679 with _normal (:589-630).  FWD: rays travel +z (n negated,
 // eta = n1/n2); !FWD: backward tracing.
-template <bool FWD>
+template <bool FWD, class M>
 __device__ __forceinline__ void refract(const DevSurface& s, Ray& r)
 {
     float nx, ny, nz;
@@ -192,10 +214,10 @@ __device__ __forceinline__ void refract(const DevSurface& s, Ray& r)
     } else {
         const float vf = r.ra > 0.0f ? 1.0f : 0.0f;
         const float xv = r.ox * vf, yv = r.oy * vf;
-        const float ds = sag_dgd_only(s, xv * xv + yv * yv);
+        const float ds = sag_dgd_only<M>(s, xv * xv + yv * yv);
         nx = (ds * 2.0f) * xv; ny = (ds * 2.0f) * yv; nz = -1.0f;
     }
-    normalize3(nx, ny, nz);
+    normalize3<M>(nx, ny, nz);
     if (FWD) { nx = -nx; ny = -ny; nz = -nz; }
     const float eta = FWD ? s.eta_f : s.eta_b;
     const float eta2 = FWD ? s.eta2_f : s.eta2_b;
@@ -204,7 +226,7 @@ __device__ __forceinline__ void refract(const DevSurface& s, Ray& r)
     const float omc = 1.0f - c2i;
     const bool v = (c2i > 0.1f) && (eta2 * omc < 1.0f) && (r.ra > 0.0f);
     const float vf = v ? 1.0f : 0.0f;
-    const float sr = __builtin_sqrtf(1.0f - (eta2 * omc) * vf);
+    const float sr = M::sqrt(1.0f - (eta2 * omc) * vf);
     float ndx = sr * nx + eta * (r.dx - cosi * nx);
     float ndy = sr * ny + eta * (r.dy - cosi * ny);
     float ndz = sr * nz + eta * (r.dz - cosi * nz);
@@ -216,35 +238,36 @@ __device__ __forceinline__ void refract(const DevSurface& s, Ray& r)
 
 // Aspheric.ray_reaction, surfaces.py:391-520.  Returns the Newton convergence
 // mask of this ray on this surface (0 for planes).
-template <bool FWD>
+template <bool FWD, class M>
 __device__ __forceinline__ uint32_t surface_reaction(const DevSurface& s, Ray& r, int trips)
 {
     uint32_t mask = 0;
     if (s.kind == 0) {
-        const float t = (s.d - r.oz) / r.dz;
+        const float t = M::div(s.d - r.oz, r.dz);
         const float nx = r.ox + t * r.dx, ny = r.oy + t * r.dy, nz = r.oz + t * r.dz;
-        const bool v = (__builtin_sqrtf(nx * nx + ny * ny) <= s.r_lim) && (r.ra > 0.0f);
+        const bool v = (M::sqrt(nx * nx + ny * ny) <= s.r_lim) && (r.ra > 0.0f);
         if (v) { r.ox = nx; r.oy = ny; r.oz = nz; }
         r.ra = r.ra * (v ? 1.0f : 0.0f);
-        if (s.do_refract) refract<FWD>(s, r);
+        if (s.do_refract) refract<FWD, M>(s, r);
         return 0;
     }
     float t;
-    const bool vn = newton(s, r, trips, t, mask);
+    const bool vn = newton<M>(s, r, trips, t, mask);
     const float nx = r.ox + t * r.dx, ny = r.oy + t * r.dy, nz = r.oz + t * r.dz;
     bool v;
     if (s.kind == 1) v = (nx * nx + ny * ny <= s.r2_lim) && (t >= 0.0f) && (r.ra > 0.0f);  // :464
     else v = vn;                                                                           // :495
     if (v) { r.ox = nx; r.oy = ny; r.oz = nz; }
     r.ra = r.ra * (v ? 1.0f : 0.0f);
-    refract<FWD>(s, r);
+    refract<FWD, M>(s, r);
     return mask;
 }
 
 // Ray.propagate_to, basics.py:256-264
+template <class M>
 __device__ __forceinline__ void propagate_to(Ray& r, float z)
 {
-    const float t = (z - r.oz) / r.dz;
+    const float t = M::div(z - r.oz, r.dz);
     r.ox = r.ox + r.dx * t;
     r.oy = r.oy + r.dy * t;
     r.oz = r.oz + r.dz * t;
@@ -254,6 +277,23 @@ __device__ __forceinline__ void propagate_to(Ray& r, float z)
 __device__ __forceinline__ float seg(float u)   // u - 1/2*sin(2u), monte_carlo.py:182
 {
     return u - 0.5f * __ocml_sin_f32(2.0f * u);
+}
+
+// seg(acos(z)) = acos(z) - z*sqrt(1-z^2), the area function of monte_carlo.py:179-183
+// with sin(2 acos z) = 2 z sqrt(1-z^2) applied.  (1-z)(1+z) instead of 1-z*z keeps the
+// root accurate next to the clamped ends z = +-1 (where it is exactly 0).  The result
+// differs from "sin(2*acos)" evaluated in fp32 by a few 1e-8 absolute -- less than the
+// reference's own MKL sin/acos differ from libm -- and it only scales splat WEIGHTS.
+__device__ __forceinline__ float seg_acos(float z)
+{
+    const float root = __builtin_amdgcn_sqrtf((1.0f - z) * (1.0f + z));
+    return __ocml_acos_f32(z) - z * root;
+}
+
+// x / r for the microlens radius: exact multiply when r is a power of two (default 0.5)
+__device__ __forceinline__ float over_r(const DevDpParams& p, float x)
+{
+    return p.r_pow2 ? x * p.inv_r : x / p.r;
 }
 
 // monte_carlo.py:169-206 (r <= 0.5)
@@ -266,18 +306,16 @@ __device__ __forceinline__ void dp_weights_small(const DevDpParams& p, float x_t
     float xm = ((-fx) * p.h) / fmh;
     float xl = (-p.w) - ((fx + p.w) * p.h) / fmh;
     xr = clampf(xr, -r, r); xm = clampf(xm, -r, r); xl = clampf(xl, -r, r);
-    float ur = __ocml_acos_f32(xr / r), um = __ocml_acos_f32(xm / r), ul = __ocml_acos_f32(xl / r);
-    float sm = seg(um);
-    const float sr_ml = rr * (sm - seg(ur));
-    const float sl_ml = rr * (seg(ul) - sm);
+    float sm = seg_acos(over_r(p, xm));
+    const float sr_ml = rr * (sm - seg_acos(over_r(p, xr)));
+    const float sl_ml = rr * (seg_acos(over_r(p, xl)) - sm);
     const float hx = p.h * x_tan;
     xr = p.w - hx; xm = 0.0f - hx; xl = (-p.w) - hx;
     xr = clampf(xr, -0.5f, 0.5f); xm = clampf(xm, -0.5f, 0.5f); xl = clampf(xl, -0.5f, 0.5f);
     const float xri = clampf(xr, -r, r), xmi = clampf(xm, -r, r), xli = clampf(xl, -r, r);
-    ur = __ocml_acos_f32(xri / r); um = __ocml_acos_f32(xmi / r); ul = __ocml_acos_f32(xli / r);
-    sm = seg(um);
-    const float sr_in = rr * (sm - seg(ur));
-    const float sl_in = rr * (seg(ul) - sm);
+    sm = seg_acos(over_r(p, xmi));
+    const float sr_in = rr * (sm - seg_acos(over_r(p, xri)));
+    const float sl_in = rr * (seg_acos(over_r(p, xli)) - sm);
     const float sr_mg = (xr - xm) * 1.0f - sr_in;
     const float sl_mg = (xm - xl) * 1.0f - sl_in;
     sr = sr_ml + sr_mg;

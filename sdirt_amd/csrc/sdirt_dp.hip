@@ -96,6 +96,9 @@ static DevDpParams make_dp(const sdirt_dp_params* dp)
     p.rr = p.r * p.r;
     p.big = r > 0.5;
     p.have_r = dp != nullptr;
+    int ex = 0;
+    p.r_pow2 = std::frexp(p.r, &ex) == 0.5f;
+    p.inv_r = 1.0f / p.r;
     p.tr = std::asin((1.0f / p.r) * 0.5f);
     p.tl = (float)3.141592653589793 - p.tr;
     return p;
@@ -136,6 +139,17 @@ static int make_trips(const sdirt_lens* lens, const int32_t* trips, TripTable& t
 // device helpers shared by the kernels
 // ---------------------------------------------------------------------------
 constexpr int kBlock = 256;
+// Workgroup size of the two fused kernels.  512 threads = 8 waves share one pair of
+// L/R tiles (33.8 KB at ks 65): 4 workgroups = 32 waves per CU = 8 per SIMD; both
+// kernels need <= 43 VGPRs.  Measured on config 2 (tools/kbench.py): k_psf_lr 12.69 ms
+// at 256 threads (LDS-limited to 4 waves/SIMD), 11.76 ms at 512, 15.7 ms at 1024.
+#ifndef SDIRT_FUSED_BLOCK
+#define SDIRT_FUSED_BLOCK 512
+#endif
+#ifndef SDIRT_PSF_WAVES
+#define SDIRT_PSF_WAVES 1
+#endif
+constexpr int kFused = SDIRT_FUSED_BLOCK;
 
 __device__ __forceinline__ Ray load_ray(const sdirt_rays& R, int64_t i)
 {
@@ -157,14 +171,20 @@ __device__ __forceinline__ void store_ray(const sdirt_rays& R, int64_t i, const 
 
 // Trace one ray through surfaces [first,last) in the travel direction.  The
 // per-wave convergence masks are OR-ed into lds_mask[k] by lane 0.
-template <bool FWD>
+#ifdef SDIRT_FAST_MATH_EXPERIMENT
+using HotMath = Fast;
+#else
+using HotMath = Ieee;
+#endif
+
+template <bool FWD, class M = Ieee>
 __device__ __forceinline__ void trace_ray(const DevSurface* __restrict__ lens, int first, int last,
                                           const TripTable& trips, Ray& r, uint32_t* lds_mask)
 {
     const int n = last - first;
     for (int step = 0; step < n; ++step) {
         const int k = FWD ? first + step : last - 1 - step;
-        const uint32_t m = surface_reaction<FWD>(lens[k], r, trips.t[k]);
+        const uint32_t m = surface_reaction<FWD, M>(lens[k], r, trips.t[k]);
         if (lds_mask && m != 0u && ((int)__lane_id() == __builtin_ctzll(__ballot(1))))
             atomicOr(&lds_mask[k], m);
     }
@@ -201,12 +221,13 @@ __global__ void k_pupil_samples(const float* __restrict__ ut, const float* __res
     y2[s] = r * (float)__ocml_sin_f64((double)theta);
 }
 
+template <class M = Ieee>
 __device__ __forceinline__ Ray make_ray(float px, float py, float pz, float x2, float y2, float z2)
 {
     Ray r;
     r.ox = px; r.oy = py; r.oz = pz;
     r.dx = x2 - px; r.dy = y2 - py; r.dz = z2 - pz;   // optics.py:490
-    normalize3(r.dx, r.dy, r.dz);                       // basics.py:245
+    normalize3<M>(r.dx, r.dy, r.dz);                    // basics.py:245
     r.ra = 1.0f; r.ob = 1.0f;
     return r;
 }
@@ -231,7 +252,7 @@ __global__ void k_rays_from_aos(const float* __restrict__ o, const float* __rest
         Ray r;
         r.ox = o[3 * i]; r.oy = o[3 * i + 1]; r.oz = o[3 * i + 2];
         r.dx = d[3 * i]; r.dy = d[3 * i + 1]; r.dz = d[3 * i + 2];
-        if (normalize) normalize3(r.dx, r.dy, r.dz);
+        if (normalize) normalize3<Ieee>(r.dx, r.dy, r.dz);
         r.ra = ra ? ra[i] : 1.0f;
         r.ob = 1.0f;
         store_ray(R, i, r);
@@ -367,7 +388,7 @@ __global__ void __launch_bounds__(kBlock) k_psf_normalize(float* __restrict__ ps
 
 // psf_center: one workgroup per point, Sc rays, fp64 partial sums reduced in a
 // fixed order (deterministic).
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kFused)
 k_chief_center(const DevSurface* __restrict__ lens, int K, TripTable trips,
                const float* __restrict__ po, const float* __restrict__ xc,
                const float* __restrict__ yc, int Sc, float pz, float zs,
@@ -375,7 +396,7 @@ k_chief_center(const DevSurface* __restrict__ lens, int K, TripTable trips,
                uint32_t* __restrict__ conv_mask)
 {
     __shared__ uint32_t lds_mask[SDIRT_MAX_SURFACES];
-    __shared__ double red[3][kBlock];
+    __shared__ double red[3][kFused];
     __shared__ int red_any;
     const int n = blockIdx.x;
     if (threadIdx.x < SDIRT_MAX_SURFACES) lds_mask[threadIdx.x] = 0;
@@ -385,9 +406,9 @@ k_chief_center(const DevSurface* __restrict__ lens, int K, TripTable trips,
     double sx = 0.0, sy = 0.0, sr = 0.0;
     int any = 0;
     for (int s = threadIdx.x; s < Sc; s += blockDim.x) {
-        Ray r = make_ray(px, py, pzo, xc[s], yc[s], pz);
-        trace_ray<true>(lens, 0, K, trips, r, conv_mask ? lds_mask : nullptr);
-        propagate_to(r, zs);
+        Ray r = make_ray<HotMath>(px, py, pzo, xc[s], yc[s], pz);
+        trace_ray<true, HotMath>(lens, 0, K, trips, r, conv_mask ? lds_mask : nullptr);
+        propagate_to<HotMath>(r, zs);
         sx += (double)(r.ox * r.ra);
         sy += (double)(r.oy * r.ra);
         sr += (double)r.ra;
@@ -396,7 +417,7 @@ k_chief_center(const DevSurface* __restrict__ lens, int K, TripTable trips,
     red[0][threadIdx.x] = sx; red[1][threadIdx.x] = sy; red[2][threadIdx.x] = sr;
     if (any) red_any = 1;
     __syncthreads();
-    for (int off = kBlock / 2; off > 0; off >>= 1) {
+    for (int off = kFused / 2; off > 0; off >>= 1) {
         if ((int)threadIdx.x < off) {
             red[0][threadIdx.x] += red[0][threadIdx.x + off];
             red[1][threadIdx.x] += red[1][threadIdx.x + off];
@@ -420,8 +441,8 @@ k_chief_center(const DevSurface* __restrict__ lens, int K, TripTable trips,
 //   nsplit == 1 : the tile is complete in LDS -> normalise (flag) and store.
 //   nsplit  > 1 : tiles are added to the pre-zeroed output with global float
 //                 atomics; the caller normalises afterwards.
-template <bool HAVE_R>
-__global__ void __launch_bounds__(kBlock)
+template <bool HAVE_R, bool BIG>
+__global__ void __launch_bounds__(kFused, SDIRT_PSF_WAVES)
 k_psf_lr(const DevSurface* __restrict__ lens, int K, TripTable trips,
          const float* __restrict__ po, const float* __restrict__ x2, const float* __restrict__ y2,
          int S, int nsplit, int chunk, float pz, float zs, SplatGeom gm, DevDpParams dp,
@@ -430,7 +451,7 @@ k_psf_lr(const DevSurface* __restrict__ lens, int K, TripTable trips,
 {
     extern __shared__ __attribute__((aligned(16))) float tiles[];   // [L | R] ks*ks each
     __shared__ uint32_t lds_mask[SDIRT_MAX_SURFACES];
-    __shared__ float red[kBlock / 64];
+    __shared__ float red[kFused / 64];
     const int tile = gm.ks * gm.ks;
     float* tl = tiles;
     float* trr = tiles + tile;
@@ -445,15 +466,15 @@ k_psf_lr(const DevSurface* __restrict__ lens, int K, TripTable trips,
     const float cx = center[2 * n], cy = center[2 * n + 1];
     const int s_end = min(S, (j + 1) * chunk);
     for (int s = j * chunk + threadIdx.x; s < s_end; s += blockDim.x) {
-        Ray r = make_ray(px, py, pzo, x2[s], y2[s], pz);
-        trace_ray<true>(lens, 0, K, trips, r, conv_mask ? lds_mask : nullptr);
-        propagate_to(r, zs);
+        Ray r = make_ray<HotMath>(px, py, pzo, x2[s], y2[s], pz);
+        trace_ray<true, HotMath>(lens, 0, K, trips, r, conv_mask ? lds_mask : nullptr);
+        propagate_to<HotMath>(r, zs);
         SplatTaps tp;
         if (!splat_taps(gm, r.ox, r.oy, cx, cy, r.ra, tp)) continue;
         const float x_tan = (-r.dx) / r.dz;
         float sl, sr;
-        if (dp.big) dp_weights_big(dp, x_tan, sl, sr);
-        else dp_weights_small(dp, x_tan, sl, sr);
+        if (BIG) dp_weights_big(dp, x_tan, sl, sr);      // separate instantiation: the rarely
+        else dp_weights_small(dp, x_tan, sl, sr);        // used r > 0.5 branch costs registers
         atomicAdd(&tl[tp.i_tl], tp.w_tl * sl);
         atomicAdd(&tl[tp.i_tr], tp.w_tr * sl);
         atomicAdd(&tl[tp.i_bl], tp.w_bl * sl);
@@ -785,7 +806,7 @@ int sdirt_chief_center(const sdirt_lens* lens, const float* point_obj, int64_t N
     TripTable tt;
     if (int rc = make_trips(lens, trips, tt)) return rc;
     if (N == 0) return SDIRT_OK;
-    k_chief_center<<<(int)N, kBlock, 0, as_stream(stream)>>>(
+    k_chief_center<<<(int)N, kFused, 0, as_stream(stream)>>>(
         lens->dev, lens->n_surfaces, tt, point_obj, xc, yc, (int)Sc, (float)pupil_z,
         (float)d_sensor, center, any_valid, conv_mask);
     LAUNCH_CHECK();
@@ -813,14 +834,14 @@ int sdirt_psf_lr(const sdirt_lens* lens, const float* point_obj, int64_t N, cons
     // number of points alone cannot (e.g. PSFNet training: N=64, S=20000).
     int nsplit = 1;
     const int64_t want_blocks = 256 * 4;
-    if (N < want_blocks && S > 2 * kBlock) {
+    if (N < want_blocks && S > 2 * kFused) {
         nsplit = (int)((want_blocks + N - 1) / N);
-        const int max_split = (int)((S + 2 * kBlock - 1) / (2 * kBlock));
+        const int max_split = (int)((S + 2 * kFused - 1) / (2 * kFused));
         if (nsplit > max_split) nsplit = max_split;
         if (nsplit < 1) nsplit = 1;
     }
     int chunk = (int)((S + nsplit - 1) / nsplit);
-    chunk = ((chunk + kBlock - 1) / kBlock) * kBlock;
+    chunk = ((chunk + kFused - 1) / kFused) * kFused;
     nsplit = (int)((S + chunk - 1) / (chunk > 0 ? chunk : 1));
     if (nsplit < 1) nsplit = 1;
 
@@ -832,18 +853,20 @@ int sdirt_psf_lr(const sdirt_lens* lens, const float* point_obj, int64_t N, cons
     const SplatGeom gm = make_geom(ps, ks);
     const DevDpParams dpp = make_dp(dp);
     const int grid = (int)(N * nsplit);
-    if (have_r && dpp.have_r)
-        k_psf_lr<true><<<grid, kBlock, lds, st>>>(lens->dev, lens->n_surfaces, tt, point_obj, x2, y2,
-                                                   (int)S, nsplit, chunk, (float)pupil_z,
-                                                   (float)d_sensor, gm, dpp, center, flags, l_psf,
-                                                   r_psf, conv_mask);
-    else {
-        k_psf_lr<false><<<grid, kBlock, sizeof(float) * tile, st>>>(
-            lens->dev, lens->n_surfaces, tt, point_obj, x2, y2, (int)S, nsplit, chunk,
-            (float)pupil_z, (float)d_sensor, gm, dpp, center, flags, l_psf, nullptr, conv_mask);
+    const bool both = have_r && dpp.have_r;
+    const size_t lds_bytes = both ? lds : sizeof(float) * tile;
+#define SDIRT_LAUNCH_PSF(HR, BG)                                                                  \
+    k_psf_lr<HR, BG><<<grid, kFused, lds_bytes, st>>>(                                            \
+        lens->dev, lens->n_surfaces, tt, point_obj, x2, y2, (int)S, nsplit, chunk, (float)pupil_z, \
+        (float)d_sensor, gm, dpp, center, flags, l_psf, both ? r_psf : nullptr, conv_mask)
+    if (both) {
+        if (dpp.big) SDIRT_LAUNCH_PSF(true, true); else SDIRT_LAUNCH_PSF(true, false);
+    } else {
+        if (dpp.big) SDIRT_LAUNCH_PSF(false, true); else SDIRT_LAUNCH_PSF(false, false);
         // param_list=None leaves the R grid all-zero (monte_carlo.py:230-235)
         if (have_r) HIP_TRY(hipMemsetAsync(r_psf, 0, sizeof(float) * (size_t)N * tile, st));
     }
+#undef SDIRT_LAUNCH_PSF
     LAUNCH_CHECK();
     if (nsplit > 1 && (flags & SDIRT_PSF_NORMALIZE)) {
         k_psf_normalize<<<(int)N, kBlock, 0, st>>>(l_psf, tile);
