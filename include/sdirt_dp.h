@@ -37,7 +37,7 @@ extern "C" {
 #define SDIRT_MAX_SURFACES 64
 #define SDIRT_MAX_AI 8
 #define SDIRT_NEWTON_MAXITER 10 /* deeplens/surfaces.py:26 */
-#define SDIRT_MAX_KS 143        /* two ks*ks fp32 tiles must fit in 160 KiB of LDS */
+#define SDIRT_MAX_KS 141        /* two ks*ks fp32 tiles + 1 KiB of bookkeeping fit in 160 KiB of LDS */
 
 typedef enum sdirt_status {
     SDIRT_OK = 0,

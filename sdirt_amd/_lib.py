@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("SDIRT_AMD_LIB") or os.path.join(HERE, "libsdirt_dp.so
 MAX_SURFACES = 64
 MAX_AI = 8
 NEWTON_MAXITER = 10
-MAX_KS = 143
+MAX_KS = 141
 PSF_NORMALIZE = 1
 
 KIND_PLANE, KIND_SPHERE, KIND_ASPHERE = 0, 1, 2

@@ -855,6 +855,19 @@ int sdirt_psf_lr(const sdirt_lens* lens, const float* point_obj, int64_t N, cons
     const int grid = (int)(N * nsplit);
     const bool both = have_r && dpp.have_r;
     const size_t lds_bytes = both ? lds : sizeof(float) * tile;
+    if (lds_bytes > 48 * 1024) {
+        // large tiles: opt in to the full 160 KiB of LDS (once per instantiation is enough,
+        // the call is cheap and idempotent)
+        const int want = 160 * 1024 - 1024;
+        HIP_TRY(hipFuncSetAttribute((const void*)k_psf_lr<true, false>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, want));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_psf_lr<true, true>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, want));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_psf_lr<false, false>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, want));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_psf_lr<false, true>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, want));
+    }
 #define SDIRT_LAUNCH_PSF(HR, BG)                                                                  \
     k_psf_lr<HR, BG><<<grid, kFused, lds_bytes, st>>>(                                            \
         lens->dev, lens->n_surfaces, tt, point_obj, x2, y2, (int)S, nsplit, chunk, (float)pupil_z, \

@@ -1,0 +1,115 @@
+"""GPU tests of the rows either side of the hot path: the
+image-space per-pixel PSF convolution (f1), the PSFNet data generators (f2) and
+this package's own geometric optics (f3)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import DATA, load_golden, load_state, make_lens
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def t(a):
+    return torch.tensor(np.ascontiguousarray(a), device=DEV)
+
+
+def test_local_psf_render_against_reference():
+    """render_psf.py:76-188 on the f7 fixture (B=2, C=3, 8x12 image, ks 5)."""
+    from sdirt_amd import local_dp_psf_render, local_psf_render, local_psf_render_fast
+    g = load_golden("f7_render")
+    img, psf, ks = t(g["img"]), t(g["psf"]), int(g["ks"])
+    out = local_dp_psf_render(img, psf, kernel_size=ks)                 # fp32 path
+    assert out.shape == g["dp_fp32"].shape
+    assert np.abs(out.cpu().numpy() - g["dp_fp32"]).max() < 2e-6
+    for fn, key in ((local_psf_render_fast, "fast"), (local_psf_render, "half")):
+        rl, rr = fn(img, psf, kernel_size=ks)                           # fp16 arithmetic
+        assert rl.dtype == torch.float32 and rl.shape == g[key + "_l"].shape
+        # one fp16 ulp at values < 1 is 4.9e-4; the reference itself differs from the
+        # fp32 result by 3e-4
+        assert np.abs(rl.cpu().numpy() - g[key + "_l"]).max() <= 5e-4
+        assert np.abs(rr.cpu().numpy() - g[key + "_r"]).max() <= 5e-4
+        assert np.mean(rl.cpu().numpy() == g[key + "_l"]) > 0.9         # mostly bit-equal fp16 values
+    # replicate padding + flipped kernel: a delta kernel at tap (0,0) shifts the image by (+pad,+pad)
+    d = torch.zeros(1, 8, 12, 2, ks, ks, device=DEV)
+    d[..., 0, 0] = 1.0
+    rl, _ = local_psf_render_fast(img[:1], d, kernel_size=ks)
+    pad = (ks - 1) // 2
+    exp = torch.nn.functional.pad(img[:1], (pad, pad, pad, pad), mode="replicate")[..., 2 * pad:, 2 * pad:]
+    assert torch.allclose(rl, exp.half().float(), atol=0)
+
+
+def test_render_production_size_runs_and_conserves_energy():
+    """512x768, ks 21 (config 5 of BASELINE.json): normalised kernels keep a flat image flat."""
+    from sdirt_amd import local_psf_render_fast
+    H, W, ks = 512, 768, 21
+    g = torch.Generator(device=DEV).manual_seed(0)
+    psf = torch.rand(1, H, W, 2, ks, ks, device=DEV, generator=g)
+    psf = psf / psf.sum((-1, -2), keepdim=True)
+    img = torch.full((1, 3, H, W), 0.5, device=DEV)
+    rl, rr = local_psf_render_fast(img, psf, kernel_size=ks)
+    assert rl.shape == (1, 3, H, W)
+    assert (rl - 0.5).abs().max() < 2e-3 and (rr - 0.5).abs().max() < 2e-3
+
+
+@pytest.mark.parametrize("name", ["rf50mm", "rf35mm"])
+def test_own_geometric_optics_against_reference_state(name):
+    """calc_fov / paraxial pupils / refocus computed here (device traces + float64
+    closed-form line intersections) vs the values the reference computed
+    (tests/golden/lens_state_*.json).  The reference's pupil is itself only
+    reproducible to ~1.3e-5 relative (fp32 lstsq), its refocus depends on the
+    2048 random rays drawn."""
+    from sdirt_amd.psfnet import PSFNet
+    st = load_state(name)
+    torch.manual_seed(0)
+    lens = PSFNet(os.path.join(DATA, f"{name}.json"), sensor_res=(512, 768), kernel_size=21,
+                  device=DEV)
+    assert lens.aper_idx == st["aper_idx"]
+    ez, er = lens.entrance_pupil()
+    xz, xr = lens.exit_pupil()
+    print(name, "entrance pupil", (ez, er), "ref", (st["pupil_z"], st["pupil_r"]),
+          "exit", (xz, xr), "ref", (st["exit_pupil_z"], st["exit_pupil_r"]))
+    # reference estimator (fp32 lstsq on the host): the reference's own spread between two
+    # identical calls is 1.3e-5 (entrance) / 2e-4 (exit) relative
+    assert abs(ez - st["pupil_z"]) < 2e-3 and abs(er / st["pupil_r"] - 1) < 1e-4
+    assert abs(xz - st["exit_pupil_z"]) < 5e-3 and abs(xr / st["exit_pupil_r"] - 1) < 1e-3
+    # exact estimator: deterministic, agrees with the reference's to its fp32 bias (~1e-3)
+    lens.pupil_method = "exact"
+    lens._pupil_cache.clear()
+    ez2, er2 = lens.entrance_pupil()
+    assert abs(er2 / st["pupil_r"] - 1) < 3e-3 and abs(ez2 - st["pupil_z"]) < 5e-3
+    lens.pupil_method = "reference"
+    lens._pupil_cache.clear()
+    lens.refocus(-1000 + lens.d_sensor)                       # 1_fit_psfnet.py:23-25
+    assert abs(lens.d_sensor - st["d_sensor"]) < 0.05
+    assert abs(lens.hfov / st["hfov"] - 1) < 2e-3
+    assert abs(lens.foclen / st["foclen"] - 1) < 2e-3
+    assert abs(lens.fnum / st["fnum"] - 1) < 2e-3
+    # with the sensor pinned to the reference's value hfov agrees tightly (same 100 rays)
+    lens.d_sensor = st["d_sensor"]
+    lens.post_computation()
+    assert abs(lens.hfov / st["hfov"] - 1) < 2e-5
+
+
+def test_psfnet_data_generators():
+    from sdirt_amd.psfnet import PSFNet
+    st = load_state("rf50mm")
+    lens = PSFNet(os.path.join(DATA, "rf50mm.json"), sensor_res=(512, 768), kernel_size=21,
+                  device=DEV)
+    lens.set_state(d_sensor=st["d_sensor"], hfov=st["hfov"], pupil=(st["pupil_z"], st["pupil_r"]))
+    torch.manual_seed(0); np.random.seed(0)
+    inp, psf = lens.get_training_data(bs=64, spp=2048)       # training shape (1_fit_psfnet.py:36)
+    assert inp.shape == (64, 3) and psf.shape == (64, 21, 21) and psf.is_cuda
+    assert float(psf.amax((1, 2)).min()) > 0.999 and float(psf.min()) >= 0
+    assert (inp[:, :2].abs() <= 1).all() and (inp[:, 2] >= 0).all() and (inp[:, 2] <= 1).all()
+    # RNG order of the reference: choice, rand, rand, randn, then the PSF call's draws
+    torch.manual_seed(0); np.random.seed(0)
+    np.random.choice(lens.foc_z_arr)
+    x = (torch.rand(64) - 0.5) * 2
+    assert torch.equal(inp[:, 0], x)
+    inp2, psf2 = lens.get_test_data(bs=1024, spp=256)
+    assert inp2.shape == (1024, 3) and psf2.shape == (1024, 21, 21)
+    assert float(lens.z2depth(torch.tensor(0.0))) == -200 and float(lens.z2depth(torch.tensor(1.0))) == -20000

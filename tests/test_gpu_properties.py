@@ -1,0 +1,173 @@
+"""Size-independent properties of the HIP path at BASELINE.json's full sizes and on
+edge-case inputs (no oracle needed: these hold for any correct implementation)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, load_state, make_lens
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+DP = (0.78, 1.44, 0.3, 0.5)
+
+
+@pytest.fixture(scope="module")
+def lens():
+    return make_lens("rf50mm", DEV)
+
+
+def full_volume():
+    import bench
+    return bench.volume_points(1)
+
+
+def test_full_config2_volume(lens):
+    """16384 points x 4096 spp x 65x65 L+R: finite, normalised, mirror-symmetric."""
+    pts = full_volume()
+    torch.manual_seed(1)
+    L, R = lens.psf_lr(pts, ks=65, spp=4096, dp=DP)
+    assert L.shape == (16384, 65, 65) and R.shape == L.shape
+    assert torch.isfinite(L).all() and torch.isfinite(R).all()
+    assert float(L.min()) >= 0 and float(R.min()) >= 0
+    mx = L.amax((1, 2))
+    assert float(mx.max()) <= 1.0 and float(mx.min()) > 0.99       # psf/(max+1e-6), every point lit
+    # the reference derives R from L by mirroring x (psfnet.py:327-330): with the pupil sample
+    # set mirrored as well the ray bundle is the exact mirror image, so
+    # R(x,y,z) == fliplr(L(-x,y,z)) up to rounding (dual-pixel split is along x only)
+    st = load_state("rf50mm")
+    g = torch.Generator().manual_seed(2)
+    u = torch.rand(4, 4096, generator=g)
+    th, r = u[0] * 2 * np.pi, torch.sqrt(u[1] * st["pupil_r"] ** 2)
+    x2, y2 = r * torch.cos(th), r * torch.sin(th)
+    thc, rc = u[2, :2048] * 2 * np.pi, torch.sqrt(u[3, :2048] * (st["pupil_r"] * 0.25) ** 2)
+    xc, yc = rc * torch.cos(thc), rc * torch.sin(thc)
+    p = pts[torch.arange(0, 16384, 257)].clone()
+    _, R1 = lens.psf_lr(p, ks=65, dp=DP, pupil_xy=(x2, y2), center_pupil_xy=(xc, yc))
+    p[:, 0] = -p[:, 0]
+    L2, _ = lens.psf_lr(p, ks=65, dp=DP, pupil_xy=(-x2, y2), center_pupil_xy=(-xc, yc))
+    diff = (R1 - torch.flip(L2, [-1])).abs()
+    # Not exact, and not a bug: the reference takes the top-right tap's column as
+    # floor(col + 1) in fp32 (monte_carlo.py:220), which is floor(col) + 2 when col sits one
+    # ulp below an integer -- a ray landing 1e-7 mm left of a pixel centre splats differently
+    # from its mirror image 1e-7 mm right of it.  One such ray exists in these 64 x 4096.
+    assert float((diff > 2e-5).float().mean()) < 1e-5 and float(diff.max()) < 0.03
+    assert torch.allclose(R1.sum((1, 2)), L2.sum((1, 2)), rtol=2e-5)
+
+
+def test_single_point_and_default_param_list(lens):
+    p = torch.tensor([0.3, -0.2, -1500.0])
+    torch.manual_seed(5)
+    a = lens.psf(p, ks=21, spp=512)                      # [3] -> [ks,ks]  (optics.py:949-953,993)
+    torch.manual_seed(5)
+    b = lens.psf(p.unsqueeze(0), ks=21, spp=512)
+    # bit-equal in the reference; here equal up to the order of the LDS float atomics
+    assert a.shape == (21, 21) and torch.allclose(a, b[0], atol=2e-6)
+    torch.manual_seed(5)
+    c = lens.psf_diff(p, ks=21, spp=512, param_list=[0.78, 1.44, 0.3, 0.5, "l"])
+    assert torch.allclose(a, c, atol=2e-6)               # defaults == explicit list (monte_carlo.py:157)
+    torch.manual_seed(5)
+    d = lens.psf_diff(p, ks=21, spp=512, param_list=[0.78, 1.44, 0.3, 0.5, "r"])
+    assert d.shape == (21, 21) and not torch.allclose(a, d, atol=1e-3)
+
+
+def test_spp_split_path_equals_single_workgroup_path(lens):
+    """Few points + many samples take the nsplit>1 route (global float atomics +
+    separate normalise); it must agree with the one-workgroup-per-point route."""
+    st = load_state("rf50mm")
+    pts = torch.tensor([[0.0, 0.0, -800.0], [0.6, -0.5, -3000.0], [-0.9, 0.9, -250.0]])
+    g = torch.Generator().manual_seed(11)
+    S = 20000                                            # PSFNet training spp (1_fit_psfnet.py:36)
+    u = torch.rand(2, S, generator=g)
+    th, r = u[0] * 2 * np.pi, torch.sqrt(u[1] * st["pupil_r"] ** 2)
+    xy = (r * torch.cos(th), r * torch.sin(th))
+    uc = torch.rand(2, 2048, generator=g)
+    thc, rc = uc[0] * 2 * np.pi, torch.sqrt(uc[1] * (st["pupil_r"] * 0.25) ** 2)
+    xyc = (rc * torch.cos(thc), rc * torch.sin(thc))
+    L3, R3 = lens.psf_lr(pts, ks=21, dp=DP, pupil_xy=xy, center_pupil_xy=xyc)   # N=3 -> split
+    big = pts.repeat(400, 1)                                                   # N=1200 -> no split
+    Lb, Rb = lens.psf_lr(big, ks=21, dp=DP, pupil_xy=xy, center_pupil_xy=xyc)
+    assert torch.allclose(L3, Lb[:3], atol=3e-6) and torch.allclose(R3, Rb[:3], atol=3e-6)
+    # identical points in different workgroups: LDS float atomics -> equal up to summation order
+    assert torch.allclose(Lb[:3], Lb[3:6], atol=2e-6)
+
+def test_trip_policy_max_is_close_to_reference_policy(lens):
+    pts = torch.tensor([[0.2, 0.1, -1000.0], [-0.8, 0.7, -10000.0]])
+    torch.manual_seed(3)
+    a, _ = lens.psf_lr(pts, ks=33, spp=4096, dp=DP)
+    lens.trip_policy = "max"
+    try:
+        torch.manual_seed(3)
+        b, _ = lens.psf_lr(pts, ks=33, spp=4096, dp=DP)
+    finally:
+        lens.trip_policy = "reference"
+    # extra Newton trips after convergence move t by rounding noise only (SURVEY.md §7 hard part 2)
+    assert float((a - b).abs().max()) < 1e-4
+
+
+def test_edge_cases(lens):
+    # empty batch
+    L, R = lens.psf_lr(torch.zeros(0, 3), ks=9, spp=64, dp=DP)
+    assert L.shape == (0, 9, 9)
+    # extreme field point outside the image circle: everything vignetted or outside the window
+    far = torch.tensor([[5.0, 5.0, -1000.0]])
+    lens.trip_policy = "max"                             # no 'No sampled rays is valid.' assertion
+    try:
+        L, R = lens.psf_lr(far, ks=9, spp=256, dp=DP)
+    finally:
+        lens.trip_policy = "reference"
+    assert torch.isfinite(L).all() and float(L.max()) <= 1.0
+    with pytest.raises(AssertionError, match="No sampled rays is valid"):
+        lens.psf(far, ks=9, spp=64)                      # optics.py:902
+    # smallest / largest supported kernel sizes, even ks
+    for ks in (2, 8, 141):
+        L, _ = lens.psf_lr(torch.tensor([[0.0, 0.0, -1000.0]]), ks=ks, spp=128, dp=DP)
+        assert L.shape == (1, ks, ks) and torch.isfinite(L).all()
+    from sdirt_amd import SdirtError
+    with pytest.raises(SdirtError):
+        lens.psf(torch.tensor([[0.0, 0.0, -1000.0]]), ks=142, spp=64)
+    # center=False uses the pinhole centre (optics.py:971-976)
+    L = lens.psf(torch.tensor([[0.0, 0.0, -1000.0]]), ks=21, spp=256, center=False)
+    assert L.shape == (1, 21, 21) and float(L.max()) > 0.99
+
+
+def test_rgb_and_map_shapes(lens):
+    pts = torch.tensor([[0.0, 0.0, -1000.0], [0.5, 0.5, -2000.0]])
+    rgb = lens.psf_rgb(pts, ks=11, spp=128)
+    assert rgb.shape == (2, 3, 11, 11)
+    assert lens.psf_rgb(pts[0], ks=11, spp=128).shape == (3, 11, 11)
+    m = lens.psf_map(depth=-1000.0, grid=3, ks=11, spp=128)
+    assert m.shape == (3, 33, 33) and torch.isfinite(m).all()
+
+
+def test_staged_pipeline_equals_fused(lens):
+    """sample_from_points -> trace2sensor -> forward_integral (the reference's own
+    decomposition, rays in HBM as SoA) against the fused kernel on the same samples."""
+    from sdirt_amd import forward_integral_lr
+    st = load_state("rf50mm")
+    pts = torch.tensor([[0.1, 0.3, -700.0], [-0.6, -0.4, -4000.0]])
+    po = lens._points_to_object(pts)
+    torch.manual_seed(21)
+    ray = lens.sample_from_points(po, spp=2048)
+    assert ray.o.shape == (2048, 2, 3) and ray.ra.shape == (2048, 2)
+    ray = lens.trace2sensor(ray)
+    cen = torch.tensor([[0.01, -0.02], [0.0, 0.0]], device=DEV)
+    lg, rg = forward_integral_lr(ray, lens.pixel_size, 33, cen, list(DP) + ["l"])
+    torch.manual_seed(21)
+    u = (torch.rand(2048), torch.rand(2048))
+    # fused kernel with explicit centre: reproduce through the C ABI
+    import ctypes as C
+    from sdirt_amd import _lib
+    from sdirt_amd.basics import dptr, stream_ptr
+    xy = torch.empty((2, 2048), device=DEV)
+    ud = torch.stack(u).to(DEV)
+    sp = stream_ptr(torch.device(DEV))
+    _lib.check(_lib.lib().sdirt_pupil_samples(dptr(ud[0]), dptr(ud[1]), 2048, st["pupil_r"],
+                                              dptr(xy[0]), dptr(xy[1]), sp))
+    K = len(lens.surfaces)
+    trips = (C.c_int32 * K)(*[int(v) for v in lens.trips.cache[("trace", 0.589, 0, K, True)]])
+    L = torch.empty((2, 33, 33), device=DEV); R = torch.empty_like(L)
+    dp = _lib.DpParams(*DP)
+    _lib.check(_lib.lib().sdirt_psf_lr(lens.dev_lens(0.589), dptr(po), 2, dptr(xy[0]), dptr(xy[1]),
+                                       2048, st["pupil_z"], st["d_sensor"], st["pixel_size"], 33,
+                                       dptr(cen), C.byref(dp), trips, 0, dptr(L), dptr(R), None, sp))
+    assert torch.allclose(L, lg, atol=3e-6 * float(lg.max())) and torch.allclose(R, rg, atol=3e-6 * float(rg.max()))
