@@ -54,24 +54,93 @@ struct DevDpParams {
     float inv_r;
 };
 
-struct Ray {
-    float ox, oy, oz, dx, dy, dz, ra, ob;
+// ---------------------------------------------------------------------------
+// Lane types.  The trace core is written once, generic in the per-lane value type:
+//   float : one ray per lane -- what every kernel instantiates;
+//   f2    : two rays per lane.  Kept as a tested experiment: on gfx950 the compiler
+//           turns the adds/multiplies into v_pk_mul_f32 / v_pk_add_f32, results are
+//           bit-identical, but a packed fp32 op occupies the SIMD-32 for twice the
+//           passes of a scalar one (the 157 TFLOP/s vector-fp32 peak is already the
+//           un-packed FMA rate), so it buys nothing: measured 5.35 / 12.09 ms
+//           (f2) against 5.08 / 11.76 ms (float) for k_chief_center / k_psf_lr.
+// ---------------------------------------------------------------------------
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef int i2 __attribute__((ext_vector_type(2)));
+
+template <class T> struct Lane;
+
+template <> struct Lane<float> {
+    using Mask = bool;
+    static constexpr int width = 1;
+    static __device__ __forceinline__ float splat(float v) { return v; }
+    static __device__ __forceinline__ Mask lt(float a, float b) { return a < b; }
+    static __device__ __forceinline__ Mask le(float a, float b) { return a <= b; }
+    static __device__ __forceinline__ Mask gt(float a, float b) { return a > b; }
+    static __device__ __forceinline__ Mask ge(float a, float b) { return a >= b; }
+    static __device__ __forceinline__ Mask isnan(float a) { return a != a; }
+    static __device__ __forceinline__ Mask mand(Mask a, Mask b) { return a && b; }
+    static __device__ __forceinline__ Mask mnot(Mask a) { return !a; }
+    static __device__ __forceinline__ Mask all(bool u) { return u; }
+    static __device__ __forceinline__ bool any(Mask m) { return m; }
+    static __device__ __forceinline__ float sel(Mask m, float a, float b) { return m ? a : b; }
+    static __device__ __forceinline__ float to01(Mask m) { return m ? 1.0f : 0.0f; }
+    static __device__ __forceinline__ float fabs(float a) { return __builtin_fabsf(a); }
+    static __device__ __forceinline__ float fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+    static __device__ __forceinline__ float sqrt_ieee(float a) { return __builtin_sqrtf(a); }
+    static __device__ __forceinline__ float sqrt_fast(float a) { return __builtin_amdgcn_sqrtf(a); }
+    static __device__ __forceinline__ float rcp_fast(float a) { return __builtin_amdgcn_rcpf(a); }
+    template <class F> static __device__ __forceinline__ float map(float a, F f) { return f(a); }
 };
+
+template <> struct Lane<f2> {
+    using Mask = i2;
+    static constexpr int width = 2;
+    static __device__ __forceinline__ f2 splat(float v) { return f2{v, v}; }
+    static __device__ __forceinline__ Mask lt(f2 a, f2 b) { return a < b; }
+    static __device__ __forceinline__ Mask le(f2 a, f2 b) { return a <= b; }
+    static __device__ __forceinline__ Mask gt(f2 a, f2 b) { return a > b; }
+    static __device__ __forceinline__ Mask ge(f2 a, f2 b) { return a >= b; }
+    static __device__ __forceinline__ Mask isnan(f2 a) { return a != a; }
+    static __device__ __forceinline__ Mask mand(Mask a, Mask b) { return a & b; }
+    static __device__ __forceinline__ Mask mnot(Mask a) { return ~a; }
+    static __device__ __forceinline__ Mask all(bool u) { return u ? i2{-1, -1} : i2{0, 0}; }
+    static __device__ __forceinline__ bool any(Mask m) { return (m.x | m.y) != 0; }
+    static __device__ __forceinline__ f2 sel(Mask m, f2 a, f2 b)
+    {
+        return f2{m.x ? a.x : b.x, m.y ? a.y : b.y};
+    }
+    static __device__ __forceinline__ f2 to01(Mask m) { return f2{m.x ? 1.0f : 0.0f, m.y ? 1.0f : 0.0f}; }
+    static __device__ __forceinline__ f2 fabs(f2 a) { return f2{__builtin_fabsf(a.x), __builtin_fabsf(a.y)}; }
+    static __device__ __forceinline__ f2 fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+    static __device__ __forceinline__ f2 sqrt_ieee(f2 a) { return f2{__builtin_sqrtf(a.x), __builtin_sqrtf(a.y)}; }
+    static __device__ __forceinline__ f2 sqrt_fast(f2 a)
+    {
+        return f2{__builtin_amdgcn_sqrtf(a.x), __builtin_amdgcn_sqrtf(a.y)};
+    }
+    static __device__ __forceinline__ f2 rcp_fast(f2 a)
+    {
+        return f2{__builtin_amdgcn_rcpf(a.x), __builtin_amdgcn_rcpf(a.y)};
+    }
+    template <class F> static __device__ __forceinline__ f2 map(f2 a, F f) { return f2{f(a.x), f(a.y)}; }
+};
+
+template <class T>
+struct RayT {
+    T ox, oy, oz, dx, dy, dz, ra, ob;
+};
+using Ray = RayT<float>;
 
 // Math policies.  Ieee: correctly rounded / and sqrt (hipcc's default expansion),
 // the parity mode -- bit-identical to an IEEE CPU evaluation.  Fast: one-ulp
 // hardware reciprocal / square root (v_rcp_f32, v_sqrt_f32); results move by a
 // few ulp per operation, i.e. by what torch's own MKL kernels differ from IEEE.
 struct Ieee {
-    static __device__ __forceinline__ float div(float a, float b) { return a / b; }
-    static __device__ __forceinline__ float sqrt(float x) { return __builtin_sqrtf(x); }
+    template <class T> static __device__ __forceinline__ T div(T a, T b) { return a / b; }
+    template <class T> static __device__ __forceinline__ T sqrt(T x) { return Lane<T>::sqrt_ieee(x); }
 };
 struct Fast {
-    static __device__ __forceinline__ float div(float a, float b)
-    {
-        return a * __builtin_amdgcn_rcpf(b);
-    }
-    static __device__ __forceinline__ float sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+    template <class T> static __device__ __forceinline__ T div(T a, T b) { return a * Lane<T>::rcp_fast(b); }
+    template <class T> static __device__ __forceinline__ T sqrt(T x) { return Lane<T>::sqrt_fast(x); }
 };
 
 __device__ __forceinline__ float clampf(float v, float lo, float hi)
@@ -83,17 +152,27 @@ __device__ __forceinline__ float clampf(float v, float lo, float hi)
     return v;
 }
 
+template <class T>
+__device__ __forceinline__ T clampv(T v, float lo, float hi)
+{
+    using L = Lane<T>;
+    T w = L::sel(L::lt(v, L::splat(lo)), L::splat(lo), v);
+    w = L::sel(L::gt(w, L::splat(hi)), L::splat(hi), w);
+    return L::sel(L::isnan(v), v, w);
+}
+
 // torch.nn.functional.normalize over a last dim of 3 (basics.py:245,
 // surfaces.py:628): v / max(||v||, 1e-12); torch's CPU kernel accumulates the
 // squares with fused multiply-adds (x*x, then fma y, then fma z).
-template <class M>
-__device__ __forceinline__ void normalize3(float& x, float& y, float& z)
+template <class M, class T>
+__device__ __forceinline__ void normalize3(T& x, T& y, T& z)
 {
-    float acc = x * x;
-    acc = __builtin_fmaf(y, y, acc);
-    acc = __builtin_fmaf(z, z, acc);
-    float nrm = M::sqrt(acc);
-    nrm = nrm < 1e-12f ? 1e-12f : nrm;
+    using L = Lane<T>;
+    T acc = x * x;
+    acc = L::fma(y, y, acc);
+    acc = L::fma(z, z, acc);
+    T nrm = M::sqrt(acc);
+    nrm = L::sel(L::lt(nrm, L::splat(1e-12f)), L::splat(1e-12f), nrm);
     x = M::div(x, nrm);
     y = M::div(y, nrm);
     z = M::div(z, nrm);
@@ -113,30 +192,32 @@ __device__ __forceinline__ float powi(float x, int n)
 }
 
 // surfaces.py:787-808 and 811-830 evaluated together (they share sqrt(1-a)).
-template <class M>
-__device__ __forceinline__ void sag_g_dgd(const DevSurface& s, float r2, float& g, float& dgd)
+template <class M, class T>
+__device__ __forceinline__ void sag_g_dgd(const DevSurface& s, T r2, T& g, T& dgd)
 {
-    const float a = (s.onepk * r2) * s.c2;
-    const float sf = M::sqrt(1.0f - a);
-    const float onesf = 1.0f + sf;
+    using L = Lane<T>;
+    const T a = (s.onepk * r2) * s.c2;
+    const T sf = M::sqrt(1.0f - a);
+    const T onesf = 1.0f + sf;
     g = M::div(r2 * s.c, onesf);
-    dgd = M::div((onesf + M::div(a / 2.0f, sf)) * s.c, onesf * onesf);
+    dgd = M::div((onesf + M::div(a * 0.5f, sf)) * s.c, onesf * onesf);   // a/2 == a*0.5 exactly
     if (s.ai_degree > 0) {
         dgd = dgd + s.ai[0];
         g = g + s.ai[0] * r2;
-        float pw = r2;   // r2 ** i
+        T pw = r2;   // r2 ** i
         for (int i = 1; i < s.ai_degree; ++i) {
             dgd = dgd + s.kai[i] * pw;
-            pw = powi(r2, i + 1);
+            const int n = i + 1;
+            pw = L::map(r2, [n](float v) { return powi(v, n); });
             g = g + s.ai[i] * pw;
         }
     }
 }
 
-template <class M>
-__device__ __forceinline__ float sag_dgd_only(const DevSurface& s, float r2)
+template <class M, class T>
+__device__ __forceinline__ T sag_dgd_only(const DevSurface& s, T r2)
 {
-    float g, dgd;
+    T g, dgd;
     sag_g_dgd<M>(s, r2, g, dgd);
     return dgd;
 }
@@ -146,65 +227,75 @@ __device__ __forceinline__ float sag_dgd_only(const DevSurface& s, float r2)
 // mask_out (wave-uniform, lives in SGPRs) gets bit j set when ANY active lane of
 // the wave had |f(t)| > 50e-6 in trip j -- the per-wave share of the reference's
 // batch-wide `.any()` loop condition (surfaces.py:547).
-template <class M>
-__device__ __forceinline__ bool newton(const DevSurface& s, const Ray& r, int trips, float& t_out,
-                                       uint32_t& mask_out)
+template <class M, class T>
+__device__ __forceinline__ typename Lane<T>::Mask newton(const DevSurface& s, const RayT<T>& r,
+                                                         int trips, T& t_out, uint32_t& mask_out)
 {
+    using L = Lane<T>;
+    using Mk = typename L::Mask;
     const float tol_loose = (float)50e-6, tol_tight = (float)10e-6, eps = (float)1e-9;
-    const float t0 = M::div(s.d - r.oz, r.dz);
-    const float dd = r.dx * r.dx + r.dy * r.dy;
-    const float dox = r.dx * r.ox + r.dy * r.oy;
-    const bool alive = r.ra > 0.0f;
-    float t = t0;
+    const T t0 = M::div(s.d - r.oz, r.dz);
+    const T dd = r.dx * r.dx + r.dy * r.dy;
+    const T dox = r.dx * r.ox + r.dy * r.oy;
+    const Mk alive = L::gt(r.ra, L::splat(0.0f));
+    const Mk kgt = L::all(s.k_gt_m1 != 0);
+    T t = t0;
     uint32_t mask = 0;
     for (int it = 1; it <= trips; ++it) {
-        const float nx = r.ox + r.dx * t, ny = r.oy + r.dy * t, nz = r.oz + r.dz * t;
-        const float rr = nx * nx + ny * ny;
-        const bool v = (s.k_gt_m1 ? (rr < s.lim_loose) : (rr > 0.0f)) && alive;
-        const float vf = v ? 1.0f : 0.0f;
-        const float x = nx * vf, y = ny * vf;
-        const float r2 = x * x + y * y;
-        float g, dgd;
+        const T nx = r.ox + r.dx * t, ny = r.oy + r.dy * t, nz = r.oz + r.dz * t;
+        const T rr = nx * nx + ny * ny;
+        const Mk inside = s.k_gt_m1 ? L::lt(rr, L::splat(s.lim_loose)) : L::gt(rr, L::splat(0.0f));
+        const T vf = L::to01(L::mand(inside, alive));
+        const T x = nx * vf, y = ny * vf;
+        const T r2 = x * x + y * y;
+        T g, dgd;
         sag_g_dgd<M>(s, r2, g, dgd);
-        const float ft = (g + s.d) - nz;
-        const float dr2dt = 2.0f * (dd * t + dox);
-        const float dfdt = dgd * dr2dt - r.dz;
-        mask |= (__ballot(__builtin_fabsf(ft) > tol_loose) != 0ull) ? (1u << it) : 0u;
-        t = t - clampf(M::div(ft, dfdt + eps), -kNewtonStepBound, kNewtonStepBound);
+        const T ft = (g + s.d) - nz;
+        const T dr2dt = 2.0f * (dd * t + dox);
+        const T dfdt = dgd * dr2dt - r.dz;
+        const bool open = L::any(L::gt(L::fabs(ft), L::splat(tol_loose)));
+        mask |= (__ballot(open) != 0ull) ? (1u << it) : 0u;
+        t = t - clampv(M::div(ft, dfdt + eps), -kNewtonStepBound, kNewtonStepBound);
     }
+    (void)kgt;
     mask_out = mask;
-    const float t1 = t - t0;   // :563
-    t = t0 + t1;               // :567
-    float nx = r.ox + r.dx * t, ny = r.oy + r.dy * t;
-    const float nz = r.oz + r.dz * t;
-    float rr = nx * nx + ny * ny;
-    bool v = (rr < s.r2_lim) && (!s.k_gt_m1 || rr < s.lim_loose) && alive;
-    const float vf = v ? 1.0f : 0.0f;
-    const float x = nx * vf, y = ny * vf;
-    const float r2 = x * x + y * y;
-    float g, dgd;
+    const T t1 = t - t0;   // :563
+    t = t0 + t1;           // :567
+    T nx = r.ox + r.dx * t, ny = r.oy + r.dy * t;
+    const T nz = r.oz + r.dz * t;
+    T rr = nx * nx + ny * ny;
+    Mk v = L::mand(L::lt(rr, L::splat(s.r2_lim)), alive);
+    if (s.k_gt_m1) v = L::mand(v, L::lt(rr, L::splat(s.lim_loose)));
+    const T vf = L::to01(v);
+    const T x = nx * vf, y = ny * vf;
+    const T r2 = x * x + y * y;
+    T g, dgd;
     sag_g_dgd<M>(s, r2, g, dgd);
-    const float ft = (g + s.d) - nz;
-    const float dr2dt = 2.0f * (dd * t + dox);
-    const float dfdt = dgd * dr2dt - r.dz;
-    t = t - clampf(M::div(ft, dfdt + eps), -kNewtonStepBound, kNewtonStepBound);
+    const T ft = (g + s.d) - nz;
+    const T dr2dt = 2.0f * (dd * t + dox);
+    const T dfdt = dgd * dr2dt - r.dz;
+    t = t - clampv(M::div(ft, dfdt + eps), -kNewtonStepBound, kNewtonStepBound);
     nx = r.ox + r.dx * t;
     ny = r.oy + r.dy * t;
     rr = nx * nx + ny * ny;
-    v = (rr < s.r2_lim) && (!s.k_gt_m1 || rr < s.lim_loose) && (__builtin_fabsf(ft) < tol_tight) &&
-        alive && (t > 0.0f);
+    v = L::mand(L::lt(rr, L::splat(s.r2_lim)), alive);
+    if (s.k_gt_m1) v = L::mand(v, L::lt(rr, L::splat(s.lim_loose)));
+    v = L::mand(v, L::lt(L::fabs(ft), L::splat(tol_tight)));
+    v = L::mand(v, L::gt(t, L::splat(0.0f)));
     t_out = t;
     return v;
 }
 
 // surfaces.py:633-679 with _normal (:589-630).  FWD: rays travel +z (n negated,
 // eta = n1/n2); !FWD: backward tracing.
-template <bool FWD, class M>
-__device__ __forceinline__ void refract(const DevSurface& s, Ray& r)
+template <bool FWD, class M, class T>
+__device__ __forceinline__ void refract(const DevSurface& s, RayT<T>& r)
 {
-    float nx, ny, nz;
+    using L = Lane<T>;
+    using Mk = typename L::Mask;
+    T nx, ny, nz;
     if (s.kind == 0) {
-        nx = 0.0f; ny = 0.0f; nz = -1.0f;
+        nx = L::splat(0.0f); ny = L::splat(0.0f); nz = L::splat(-1.0f);
     } else if (s.kind == 1) {
         if (s.c > 0.0f) {
             nx = 2.0f * r.ox; ny = 2.0f * r.oy; nz = 2.0f * r.oz - 2.0f * s.d_plus_R;
@@ -212,25 +303,26 @@ __device__ __forceinline__ void refract(const DevSurface& s, Ray& r)
             nx = -2.0f * r.ox; ny = -2.0f * r.oy; nz = -2.0f * r.oz + 2.0f * s.d_plus_R;
         }
     } else {
-        const float vf = r.ra > 0.0f ? 1.0f : 0.0f;
-        const float xv = r.ox * vf, yv = r.oy * vf;
-        const float ds = sag_dgd_only<M>(s, xv * xv + yv * yv);
-        nx = (ds * 2.0f) * xv; ny = (ds * 2.0f) * yv; nz = -1.0f;
+        const T vf = L::to01(L::gt(r.ra, L::splat(0.0f)));
+        const T xv = r.ox * vf, yv = r.oy * vf;
+        const T ds = sag_dgd_only<M>(s, xv * xv + yv * yv);
+        nx = (ds * 2.0f) * xv; ny = (ds * 2.0f) * yv; nz = L::splat(-1.0f);
     }
     normalize3<M>(nx, ny, nz);
     if (FWD) { nx = -nx; ny = -ny; nz = -nz; }
     const float eta = FWD ? s.eta_f : s.eta_b;
     const float eta2 = FWD ? s.eta2_f : s.eta2_b;
-    const float cosi = (r.dx * nx + r.dy * ny) + r.dz * nz;
-    const float c2i = cosi * cosi;
-    const float omc = 1.0f - c2i;
-    const bool v = (c2i > 0.1f) && (eta2 * omc < 1.0f) && (r.ra > 0.0f);
-    const float vf = v ? 1.0f : 0.0f;
-    const float sr = M::sqrt(1.0f - (eta2 * omc) * vf);
-    float ndx = sr * nx + eta * (r.dx - cosi * nx);
-    float ndy = sr * ny + eta * (r.dy - cosi * ny);
-    float ndz = sr * nz + eta * (r.dz - cosi * nz);
-    if (!v) { ndx = r.dx; ndy = r.dy; ndz = r.dz; }
+    const T cosi = (r.dx * nx + r.dy * ny) + r.dz * nz;
+    const T c2i = cosi * cosi;
+    const T omc = 1.0f - c2i;
+    Mk v = L::mand(L::gt(c2i, L::splat(0.1f)), L::lt(eta2 * omc, L::splat(1.0f)));
+    v = L::mand(v, L::gt(r.ra, L::splat(0.0f)));
+    const T vf = L::to01(v);
+    const T sr = M::sqrt(1.0f - (eta2 * omc) * vf);
+    T ndx = sr * nx + eta * (r.dx - cosi * nx);
+    T ndy = sr * ny + eta * (r.dy - cosi * ny);
+    T ndz = sr * nz + eta * (r.dz - cosi * nz);
+    ndx = L::sel(v, ndx, r.dx); ndy = L::sel(v, ndy, r.dy); ndz = L::sel(v, ndz, r.dz);
     r.ob = r.ob * ((ndx * r.dx + ndy * r.dy) + ndz * r.dz);
     r.dx = ndx; r.dy = ndy; r.dz = ndz;
     r.ra = r.ra * vf;
@@ -238,36 +330,43 @@ __device__ __forceinline__ void refract(const DevSurface& s, Ray& r)
 
 // Aspheric.ray_reaction, surfaces.py:391-520.  Returns the Newton convergence
 // mask of this ray on this surface (0 for planes).
-template <bool FWD, class M>
-__device__ __forceinline__ uint32_t surface_reaction(const DevSurface& s, Ray& r, int trips)
+template <bool FWD, class M, class T>
+__device__ __forceinline__ uint32_t surface_reaction(const DevSurface& s, RayT<T>& r, int trips)
 {
+    using L = Lane<T>;
+    using Mk = typename L::Mask;
     uint32_t mask = 0;
     if (s.kind == 0) {
-        const float t = M::div(s.d - r.oz, r.dz);
-        const float nx = r.ox + t * r.dx, ny = r.oy + t * r.dy, nz = r.oz + t * r.dz;
-        const bool v = (M::sqrt(nx * nx + ny * ny) <= s.r_lim) && (r.ra > 0.0f);
-        if (v) { r.ox = nx; r.oy = ny; r.oz = nz; }
-        r.ra = r.ra * (v ? 1.0f : 0.0f);
+        const T t = M::div(s.d - r.oz, r.dz);
+        const T nx = r.ox + t * r.dx, ny = r.oy + t * r.dy, nz = r.oz + t * r.dz;
+        const Mk v = L::mand(L::le(M::sqrt(nx * nx + ny * ny), L::splat(s.r_lim)),
+                             L::gt(r.ra, L::splat(0.0f)));
+        r.ox = L::sel(v, nx, r.ox); r.oy = L::sel(v, ny, r.oy); r.oz = L::sel(v, nz, r.oz);
+        r.ra = r.ra * L::to01(v);
         if (s.do_refract) refract<FWD, M>(s, r);
         return 0;
     }
-    float t;
-    const bool vn = newton<M>(s, r, trips, t, mask);
-    const float nx = r.ox + t * r.dx, ny = r.oy + t * r.dy, nz = r.oz + t * r.dz;
-    bool v;
-    if (s.kind == 1) v = (nx * nx + ny * ny <= s.r2_lim) && (t >= 0.0f) && (r.ra > 0.0f);  // :464
-    else v = vn;                                                                           // :495
-    if (v) { r.ox = nx; r.oy = ny; r.oz = nz; }
-    r.ra = r.ra * (v ? 1.0f : 0.0f);
+    T t;
+    const Mk vn = newton<M>(s, r, trips, t, mask);
+    const T nx = r.ox + t * r.dx, ny = r.oy + t * r.dy, nz = r.oz + t * r.dz;
+    Mk v;
+    if (s.kind == 1) {                                                                    // :464
+        v = L::mand(L::le(nx * nx + ny * ny, L::splat(s.r2_lim)), L::ge(t, L::splat(0.0f)));
+        v = L::mand(v, L::gt(r.ra, L::splat(0.0f)));
+    } else {
+        v = vn;                                                                           // :495
+    }
+    r.ox = L::sel(v, nx, r.ox); r.oy = L::sel(v, ny, r.oy); r.oz = L::sel(v, nz, r.oz);
+    r.ra = r.ra * L::to01(v);
     refract<FWD, M>(s, r);
     return mask;
 }
 
 // Ray.propagate_to, basics.py:256-264
-template <class M>
-__device__ __forceinline__ void propagate_to(Ray& r, float z)
+template <class M, class T>
+__device__ __forceinline__ void propagate_to(RayT<T>& r, float z)
 {
-    const float t = M::div(z - r.oz, r.dz);
+    const T t = M::div(z - r.oz, r.dz);
     r.ox = r.ox + r.dx * t;
     r.oy = r.oy + r.dy * t;
     r.oz = r.oz + r.dz * t;

@@ -177,9 +177,9 @@ using HotMath = Fast;
 using HotMath = Ieee;
 #endif
 
-template <bool FWD, class M = Ieee>
+template <bool FWD, class M = Ieee, class T = float>
 __device__ __forceinline__ void trace_ray(const DevSurface* __restrict__ lens, int first, int last,
-                                          const TripTable& trips, Ray& r, uint32_t* lds_mask)
+                                          const TripTable& trips, RayT<T>& r, uint32_t* lds_mask)
 {
     const int n = last - first;
     for (int step = 0; step < n; ++step) {
@@ -221,14 +221,15 @@ __global__ void k_pupil_samples(const float* __restrict__ ut, const float* __res
     y2[s] = r * (float)__ocml_sin_f64((double)theta);
 }
 
-template <class M = Ieee>
-__device__ __forceinline__ Ray make_ray(float px, float py, float pz, float x2, float y2, float z2)
+template <class M = Ieee, class T = float>
+__device__ __forceinline__ RayT<T> make_ray(float px, float py, float pz, T x2, T y2, float z2)
 {
-    Ray r;
-    r.ox = px; r.oy = py; r.oz = pz;
-    r.dx = x2 - px; r.dy = y2 - py; r.dz = z2 - pz;   // optics.py:490
-    normalize3<M>(r.dx, r.dy, r.dz);                    // basics.py:245
-    r.ra = 1.0f; r.ob = 1.0f;
+    using L = Lane<T>;
+    RayT<T> r;
+    r.ox = L::splat(px); r.oy = L::splat(py); r.oz = L::splat(pz);
+    r.dx = x2 - px; r.dy = y2 - py; r.dz = L::splat(z2 - pz);   // optics.py:490
+    normalize3<M>(r.dx, r.dy, r.dz);                              // basics.py:245
+    r.ra = L::splat(1.0f); r.ob = L::splat(1.0f);
     return r;
 }
 
@@ -465,13 +466,10 @@ k_psf_lr(const DevSurface* __restrict__ lens, int K, TripTable trips,
     const float px = po[3 * n], py = po[3 * n + 1], pzo = po[3 * n + 2];
     const float cx = center[2 * n], cy = center[2 * n + 1];
     const int s_end = min(S, (j + 1) * chunk);
-    for (int s = j * chunk + threadIdx.x; s < s_end; s += blockDim.x) {
-        Ray r = make_ray<HotMath>(px, py, pzo, x2[s], y2[s], pz);
-        trace_ray<true, HotMath>(lens, 0, K, trips, r, conv_mask ? lds_mask : nullptr);
-        propagate_to<HotMath>(r, zs);
+    auto splat = [&](float sx, float sy, float dx, float dz, float ra) {
         SplatTaps tp;
-        if (!splat_taps(gm, r.ox, r.oy, cx, cy, r.ra, tp)) continue;
-        const float x_tan = (-r.dx) / r.dz;
+        if (!splat_taps(gm, sx, sy, cx, cy, ra, tp)) return;
+        const float x_tan = (-dx) / dz;
         float sl, sr;
         if (BIG) dp_weights_big(dp, x_tan, sl, sr);      // separate instantiation: the rarely
         else dp_weights_small(dp, x_tan, sl, sr);        // used r > 0.5 branch costs registers
@@ -485,6 +483,12 @@ k_psf_lr(const DevSurface* __restrict__ lens, int K, TripTable trips,
             atomicAdd(&trr[tp.i_bl], tp.w_bl * sr);
             atomicAdd(&trr[tp.i_br], tp.w_br * sr);
         }
+    };
+    for (int s = j * chunk + threadIdx.x; s < s_end; s += blockDim.x) {
+        Ray r = make_ray<HotMath>(px, py, pzo, x2[s], y2[s], pz);
+        trace_ray<true, HotMath>(lens, 0, K, trips, r, conv_mask ? lds_mask : nullptr);
+        propagate_to<HotMath>(r, zs);
+        splat(r.ox, r.oy, r.dx, r.dz, r.ra);
     }
     __syncthreads();
 
