@@ -185,12 +185,21 @@ int sdirt_psf_normalize(float* psf /*dev [N,ks,ks]*/, int64_t n_points, int32_t 
 int sdirt_chief_center(const sdirt_lens* lens, const float* point_obj /*dev [N,3]*/,
                        int64_t n_points, const float* xc /*dev [Sc]*/, const float* yc /*dev [Sc]*/,
                        int64_t spp_center, double pupil_z, double d_sensor,
-                       const int32_t* trips /*host [K]*/, float* center /*dev [N,2]*/,
-                       int32_t* any_valid /*dev or NULL*/, uint32_t* conv_mask /*dev [K] or NULL*/,
-                       void* stream);
+                       const int32_t* trips /*host [K]*/, uint32_t flags /*SDIRT_PSF_STRICT_IEEE or 0*/,
+                       float* center /*dev [N,2]*/, int32_t* any_valid /*dev or NULL*/,
+                       uint32_t* conv_mask /*dev [K] or NULL*/, void* stream);
 
 #define SDIRT_PSF_NORMALIZE 1u /* apply optics.py:983-987 to each written grid */
 #define SDIRT_PSF_ACCUMULATE 2u /* internal: grids pre-zeroed, blocks add partial tiles */
+/* By default the fused kernels divide and take square roots with "lean" sequences (rcp /
+ * sqrt seed + fma corrections, 6 and 10 instructions) that are PROVEN bit-identical to
+ * correctly rounded IEEE results for normal-range operands: all 2^46 mantissa pairs for the
+ * division, every fp32 >= 2^-100 for the square root (sdirt_selftest_math, tools/
+ * selftest_math.py, profiles/r01/selftest_math.txt).  They skip the range scaling and
+ * special-value fix-up of the compiler's 12/17-instruction sequences: x/0 yields NaN
+ * instead of inf, denormal operands are not handled.  No valid ray produces such operands.
+ * This flag selects the compiler's full-range IEEE sequences instead (~1.26x slower). */
+#define SDIRT_PSF_STRICT_IEEE 4u
 
 /* Lensgroup.psf_diff, deeplens/optics.py:934-996, fused from sampling to the
  * normalised left/right PSFs: one workgroup per (point, spp-slice), rays
@@ -205,6 +214,16 @@ int sdirt_psf_lr(const sdirt_lens* lens, const float* point_obj /*dev [N,3]*/, i
                  const int32_t* trips /*host [K]*/, uint32_t flags, float* l_psf /*dev [N,ks,ks]*/,
                  float* r_psf /*dev or NULL*/, uint32_t* conv_mask /*dev [K] or NULL*/,
                  void* stream);
+
+/* ---- diagnostics ----------------------------------------------------------- */
+
+/* Counts how often the lean arithmetic (the default, see SDIRT_PSF_STRICT_IEEE) differs from correctly rounded IEEE:
+ * mode 0 = sqrt on every fp32 bit pattern in [first, first+count) (exhaustive for 0, 2^32);
+ * mode 1 = division on `count` pseudo-random operand pairs (all mantissas, exponents within
+ * +-exp_span of 0); mode 2 = division on mantissa pairs [first, first+count) of all 2^46.
+ * out (dev, 9 x uint64): out[0] = mismatches, out[1..8] = examples. */
+int sdirt_selftest_math(int32_t mode, uint64_t first, uint64_t count, int32_t exp_span,
+                        uint64_t* out /*dev [9]*/, void* stream);
 
 /* ---- image-space consumer of the PSFs ------------------------------------ */
 

@@ -16,6 +16,7 @@ MAX_AI = 8
 NEWTON_MAXITER = 10
 MAX_KS = 141
 PSF_NORMALIZE = 1
+PSF_STRICT_IEEE = 4
 
 KIND_PLANE, KIND_SPHERE, KIND_ASPHERE = 0, 1, 2
 
@@ -62,10 +63,11 @@ SIGNATURES = {
     "sdirt_forward_integral": (C.c_int, [Rays, _I64, _I64, _D, _I32, _P, C.POINTER(DpParams),
                                          _P, _P, _P]),
     "sdirt_psf_normalize": (C.c_int, [_P, _I64, _I32, _P]),
-    "sdirt_chief_center": (C.c_int, [_P, _P, _I64, _P, _P, _I64, _D, _D, C.POINTER(_I32), _P, _P,
-                                     _P, _P]),
+    "sdirt_chief_center": (C.c_int, [_P, _P, _I64, _P, _P, _I64, _D, _D, C.POINTER(_I32), _U32,
+                                     _P, _P, _P, _P]),
     "sdirt_psf_lr": (C.c_int, [_P, _P, _I64, _P, _P, _I64, _D, _D, _D, _I32, _P,
                                C.POINTER(DpParams), C.POINTER(_I32), _U32, _P, _P, _P, _P]),
+    "sdirt_selftest_math": (C.c_int, [_I32, C.c_uint64, C.c_uint64, _I32, _P, _P]),
     "sdirt_local_psf_render": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P, _P]),
 }
 

@@ -89,6 +89,13 @@ template <> struct Lane<float> {
     static __device__ __forceinline__ float sqrt_ieee(float a) { return __builtin_sqrtf(a); }
     static __device__ __forceinline__ float sqrt_fast(float a) { return __builtin_amdgcn_sqrtf(a); }
     static __device__ __forceinline__ float rcp_fast(float a) { return __builtin_amdgcn_rcpf(a); }
+    static __device__ __forceinline__ float rsq_fast(float a) { return __builtin_amdgcn_rsqf(a); }
+    static __device__ __forceinline__ float next_up(float a) { return __uint_as_float(__float_as_uint(a) + 1u); }
+    static __device__ __forceinline__ float next_down(float a) { return __uint_as_float(__float_as_uint(a) - 1u); }
+    static __device__ __forceinline__ Mask is_zero_or_pinf(float a)
+    {
+        return __builtin_amdgcn_class(a, 0x260);   // -0 | +0 | +inf
+    }
     template <class F> static __device__ __forceinline__ float map(float a, F f) { return f(a); }
 };
 
@@ -121,6 +128,22 @@ template <> struct Lane<f2> {
     {
         return f2{__builtin_amdgcn_rcpf(a.x), __builtin_amdgcn_rcpf(a.y)};
     }
+    static __device__ __forceinline__ Mask is_zero_or_pinf(f2 a)
+    {
+        return i2{__builtin_amdgcn_class(a.x, 0x260) ? -1 : 0, __builtin_amdgcn_class(a.y, 0x260) ? -1 : 0};
+    }
+    static __device__ __forceinline__ f2 next_up(f2 a)
+    {
+        return f2{__uint_as_float(__float_as_uint(a.x) + 1u), __uint_as_float(__float_as_uint(a.y) + 1u)};
+    }
+    static __device__ __forceinline__ f2 next_down(f2 a)
+    {
+        return f2{__uint_as_float(__float_as_uint(a.x) - 1u), __uint_as_float(__float_as_uint(a.y) - 1u)};
+    }
+    static __device__ __forceinline__ f2 rsq_fast(f2 a)
+    {
+        return f2{__builtin_amdgcn_rsqf(a.x), __builtin_amdgcn_rsqf(a.y)};
+    }
     template <class F> static __device__ __forceinline__ f2 map(f2 a, F f) { return f2{f(a.x), f(a.y)}; }
 };
 
@@ -130,19 +153,52 @@ struct RayT {
 };
 using Ray = RayT<float>;
 
-// Math policies.  Ieee: correctly rounded / and sqrt (hipcc's default expansion),
-// the parity mode -- bit-identical to an IEEE CPU evaluation.  Fast: one-ulp
-// hardware reciprocal / square root (v_rcp_f32, v_sqrt_f32); results move by a
-// few ulp per operation, i.e. by what torch's own MKL kernels differ from IEEE.
+// Math policies.
+//  Ieee: correctly rounded / and sqrt (hipcc's default expansion: 12- and 17-instruction
+//        sequences with range scaling and special-case fix-up): bit-identical to an IEEE CPU
+//        evaluation of the reference's operation sequence for ALL operands.
+//  Lean: the same correctly rounded results for every NORMAL-RANGE operand, without the
+//        range scaling (v_div_scale / 2^32 pre-scaling) and special-value fix-up
+//        (v_div_fixup, class tests) that the compiler's sequences carry for denormal, huge
+//        and zero/inf operands -- 6 and 10 instructions instead of 12 and 17:
+//          div : y0 = rcp(b); y = y0 + y0*(1 - b*y0); q0 = a*y; q = q0 + y*(a - b*q0)
+//                (all via fma).  Verified bit-identical to IEEE on ALL 2^46 mantissa pairs
+//                (sdirt_selftest_math mode 1; the recurrence is exact-scaling in the exponent,
+//                so this covers every operand pair whose exponents stay within +-60).
+//                a == 0 gives the correctly signed zero; b == 0 gives NaN instead of inf.
+//          sqrt: s = v_sqrt_f32(x) (<= 1 ulp), then pick among {s-ulp, s, s+ulp} by the sign
+//                of the exact residuals x - s'*s (fma) -- the compiler's own correction
+//                step.  Verified on EVERY positive normal fp32 (mode 0, exhaustive); +-0,
+//                +inf, negative and NaN inputs behave as IEEE; denormal inputs do not.
+//        No operand on a valid ray is denormal or zero-denominator (eps = 1e-9 guards, unit
+//        direction vectors, |positions| in [1e-6, 2e4] mm), so valid rays are bit-identical
+//        to the Ieee instantiation; tests/test_gpu_parity.py runs both against the oracle.
 struct Ieee {
     template <class T> static __device__ __forceinline__ T div(T a, T b) { return a / b; }
     template <class T> static __device__ __forceinline__ T sqrt(T x) { return Lane<T>::sqrt_ieee(x); }
 };
-struct Fast {
-    template <class T> static __device__ __forceinline__ T div(T a, T b) { return a * Lane<T>::rcp_fast(b); }
-    template <class T> static __device__ __forceinline__ T sqrt(T x) { return Lane<T>::sqrt_fast(x); }
+struct Lean {
+    template <class T> static __device__ __forceinline__ T div(T a, T b)
+    {
+        using L = Lane<T>;
+        const T y0 = L::rcp_fast(b);
+        const T y = L::fma(L::fma(-b, y0, L::splat(1.0f)), y0, y0);
+        const T q0 = a * y;
+        return L::fma(L::fma(-b, q0, a), y, q0);
+    }
+    template <class T> static __device__ __forceinline__ T sqrt(T x)
+    {
+        using L = Lane<T>;
+        T s = L::sqrt_fast(x);
+        const T sm = L::next_down(s), sp = L::next_up(s);
+        const T rm = L::fma(-sm, s, x);          // x - (s - ulp) * s
+        const T rp = L::fma(-sp, s, x);          // x - (s + ulp) * s
+        s = L::sel(L::le(rm, L::splat(0.0f)), sm, s);
+        s = L::sel(L::gt(rp, L::splat(0.0f)), sp, s);
+        // +-0 and +inf map to themselves; negative / NaN inputs give NaN through v_sqrt_f32
+        return L::sel(L::is_zero_or_pinf(x), x, s);
+    }
 };
-
 __device__ __forceinline__ float clampf(float v, float lo, float hi)
 {
     // torch.clamp semantics: NaN propagates

@@ -171,12 +171,6 @@ __device__ __forceinline__ void store_ray(const sdirt_rays& R, int64_t i, const 
 
 // Trace one ray through surfaces [first,last) in the travel direction.  The
 // per-wave convergence masks are OR-ed into lds_mask[k] by lane 0.
-#ifdef SDIRT_FAST_MATH_EXPERIMENT
-using HotMath = Fast;
-#else
-using HotMath = Ieee;
-#endif
-
 template <bool FWD, class M = Ieee, class T = float>
 __device__ __forceinline__ void trace_ray(const DevSurface* __restrict__ lens, int first, int last,
                                           const TripTable& trips, RayT<T>& r, uint32_t* lds_mask)
@@ -389,6 +383,7 @@ __global__ void __launch_bounds__(kBlock) k_psf_normalize(float* __restrict__ ps
 
 // psf_center: one workgroup per point, Sc rays, fp64 partial sums reduced in a
 // fixed order (deterministic).
+template <class HotMath>
 __global__ void __launch_bounds__(kFused)
 k_chief_center(const DevSurface* __restrict__ lens, int K, TripTable trips,
                const float* __restrict__ po, const float* __restrict__ xc,
@@ -442,7 +437,7 @@ k_chief_center(const DevSurface* __restrict__ lens, int K, TripTable trips,
 //   nsplit == 1 : the tile is complete in LDS -> normalise (flag) and store.
 //   nsplit  > 1 : tiles are added to the pre-zeroed output with global float
 //                 atomics; the caller normalises afterwards.
-template <bool HAVE_R, bool BIG>
+template <bool HAVE_R, bool BIG, class HotMath>
 __global__ void __launch_bounds__(kFused, SDIRT_PSF_WAVES)
 k_psf_lr(const DevSurface* __restrict__ lens, int K, TripTable trips,
          const float* __restrict__ po, const float* __restrict__ x2, const float* __restrict__ y2,
@@ -469,7 +464,7 @@ k_psf_lr(const DevSurface* __restrict__ lens, int K, TripTable trips,
     auto splat = [&](float sx, float sy, float dx, float dz, float ra) {
         SplatTaps tp;
         if (!splat_taps(gm, sx, sy, cx, cy, ra, tp)) return;
-        const float x_tan = (-dx) / dz;
+        const float x_tan = HotMath::div(-dx, dz);
         float sl, sr;
         if (BIG) dp_weights_big(dp, x_tan, sl, sr);      // separate instantiation: the rarely
         else dp_weights_small(dp, x_tan, sl, sr);        // used r > 0.5 branch costs registers
@@ -582,6 +577,62 @@ k_local_psf_render(const float* __restrict__ img, const float* __restrict__ psf,
         outl[o] = HALF ? round_half(accl[c]) : accl[c];
         outr[o] = HALF ? round_half(accr[c]) : accr[c];
     }
+}
+
+// ---------------------------------------------------------------------------
+// diagnostics: does the Lean math policy ever differ from IEEE?
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t mix32(uint64_t x)
+{
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
+    return (uint32_t)x;
+}
+
+// mode 0: sqrt over EVERY fp32 bit pattern i in [first, first+count)  (exhaustive when
+//         first = 0, count = 2^32);
+// mode 1: division over pseudo-random operand pairs: mantissas uniform over all 2^23 values,
+//         exponents uniform in [-exp_span, exp_span], random signs;
+// mode 2: division over mantissa pairs i in [first, first+count) of the 2^46 pairs
+//         (a = 1.m_a, b = 1.m_b; exhaustive when first = 0, count = 2^46).
+// out[0] = number of results whose bits differ from the IEEE result, out[1..] = up to 8
+// offending operand bit patterns.
+__global__ void k_selftest_math(int mode, uint64_t first, uint64_t count, int exp_span,
+                                unsigned long long* __restrict__ out)
+{
+    unsigned long long bad = 0;
+    for (uint64_t i = first + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < first + count;
+         i += (uint64_t)gridDim.x * blockDim.x) {
+        if (mode == 0) {
+            const float x = __uint_as_float((uint32_t)i);
+            const float a = Lean::sqrt(x), b = __builtin_sqrtf(x);
+            const bool same = (__float_as_uint(a) == __float_as_uint(b)) || (a != a && b != b);
+            if (!same) {
+                const unsigned long long k = atomicAdd(&out[0], 1ull);
+                if (k < 8) out[1 + k] = i;
+            }
+        } else if (mode == 2) {
+            // exhaustive division: i enumerates ALL mantissa pairs, operands in [1, 2)
+            const float a = __uint_as_float(0x3f800000u | (uint32_t)(i & 0x7fffffu));
+            const float b = __uint_as_float(0x3f800000u | (uint32_t)((i >> 23) & 0x7fffffu));
+            if (__float_as_uint(Lean::div(a, b)) != __float_as_uint(a / b)) {
+                const unsigned long long k = atomicAdd(&out[0], 1ull);
+                if (k < 8) out[1 + k] = ((unsigned long long)__float_as_uint(a) << 32) | __float_as_uint(b);
+            }
+        } else {
+            const uint32_t h0 = mix32(2 * i + 1), h1 = mix32(2 * i + 2), h2 = mix32(~i);
+            const int ea = 127 + (int)(h2 % (2 * exp_span + 1)) - exp_span;
+            const int eb = 127 + (int)((h2 >> 8) % (2 * exp_span + 1)) - exp_span;
+            const float a = __uint_as_float((h0 & 0x807fffffu) | ((uint32_t)ea << 23));
+            const float b = __uint_as_float((h1 & 0x807fffffu) | ((uint32_t)eb << 23));
+            const float q = Lean::div(a, b);
+            if (__float_as_uint(q) != __float_as_uint(a / b)) {
+                ++bad;
+                const unsigned long long k = atomicAdd(&out[0], 1ull);
+                if (k < 8) out[1 + k] = ((unsigned long long)__float_as_uint(a) << 32) | __float_as_uint(b);
+            }
+        }
+    }
+    (void)bad;
 }
 
 // ---------------------------------------------------------------------------
@@ -802,7 +853,7 @@ int sdirt_psf_normalize(float* psf, int64_t N, int32_t ks, void* stream)
 
 int sdirt_chief_center(const sdirt_lens* lens, const float* point_obj, int64_t N, const float* xc,
                        const float* yc, int64_t Sc, double pupil_z, double d_sensor,
-                       const int32_t* trips, float* center, int32_t* any_valid,
+                       const int32_t* trips, uint32_t flags, float* center, int32_t* any_valid,
                        uint32_t* conv_mask, void* stream)
 {
     if (!lens || !point_obj || !xc || !yc || !center || N < 0 || Sc < 0 || Sc > (1ll << 30))
@@ -810,9 +861,14 @@ int sdirt_chief_center(const sdirt_lens* lens, const float* point_obj, int64_t N
     TripTable tt;
     if (int rc = make_trips(lens, trips, tt)) return rc;
     if (N == 0) return SDIRT_OK;
-    k_chief_center<<<(int)N, kFused, 0, as_stream(stream)>>>(
-        lens->dev, lens->n_surfaces, tt, point_obj, xc, yc, (int)Sc, (float)pupil_z,
-        (float)d_sensor, center, any_valid, conv_mask);
+    if (!(flags & SDIRT_PSF_STRICT_IEEE))
+        k_chief_center<Lean><<<(int)N, kFused, 0, as_stream(stream)>>>(
+            lens->dev, lens->n_surfaces, tt, point_obj, xc, yc, (int)Sc, (float)pupil_z,
+            (float)d_sensor, center, any_valid, conv_mask);
+    else
+        k_chief_center<Ieee><<<(int)N, kFused, 0, as_stream(stream)>>>(
+            lens->dev, lens->n_surfaces, tt, point_obj, xc, yc, (int)Sc, (float)pupil_z,
+            (float)d_sensor, center, any_valid, conv_mask);
     LAUNCH_CHECK();
     return SDIRT_OK;
 }
@@ -859,30 +915,30 @@ int sdirt_psf_lr(const sdirt_lens* lens, const float* point_obj, int64_t N, cons
     const int grid = (int)(N * nsplit);
     const bool both = have_r && dpp.have_r;
     const size_t lds_bytes = both ? lds : sizeof(float) * tile;
-    if (lds_bytes > 48 * 1024) {
-        // large tiles: opt in to the full 160 KiB of LDS (once per instantiation is enough,
-        // the call is cheap and idempotent)
-        const int want = 160 * 1024 - 1024;
-        HIP_TRY(hipFuncSetAttribute((const void*)k_psf_lr<true, false>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, want));
-        HIP_TRY(hipFuncSetAttribute((const void*)k_psf_lr<true, true>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, want));
-        HIP_TRY(hipFuncSetAttribute((const void*)k_psf_lr<false, false>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, want));
-        HIP_TRY(hipFuncSetAttribute((const void*)k_psf_lr<false, true>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, want));
-    }
-#define SDIRT_LAUNCH_PSF(HR, BG)                                                                  \
-    k_psf_lr<HR, BG><<<grid, kFused, lds_bytes, st>>>(                                            \
-        lens->dev, lens->n_surfaces, tt, point_obj, x2, y2, (int)S, nsplit, chunk, (float)pupil_z, \
-        (float)d_sensor, gm, dpp, center, flags, l_psf, both ? r_psf : nullptr, conv_mask)
+    const bool lean = (flags & SDIRT_PSF_STRICT_IEEE) == 0;
+#define SDIRT_LAUNCH_PSF(HR, BG, MM)                                                              \
+    do {                                                                                          \
+        if (lds_bytes > 48 * 1024) /* large tiles: opt in to the full 160 KiB of LDS */           \
+            HIP_TRY(hipFuncSetAttribute((const void*)k_psf_lr<HR, BG, MM>,                        \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize,               \
+                                        160 * 1024 - 1024));                                      \
+        k_psf_lr<HR, BG, MM><<<grid, kFused, lds_bytes, st>>>(                                    \
+            lens->dev, lens->n_surfaces, tt, point_obj, x2, y2, (int)S, nsplit, chunk,            \
+            (float)pupil_z, (float)d_sensor, gm, dpp, center, flags, l_psf,                       \
+            both ? r_psf : nullptr, conv_mask);                                                   \
+    } while (0)
+#define SDIRT_LAUNCH_PSF_M(HR, BG)                                                                \
+    do {                                                                                          \
+        if (lean) SDIRT_LAUNCH_PSF(HR, BG, Lean); else SDIRT_LAUNCH_PSF(HR, BG, Ieee);            \
+    } while (0)
     if (both) {
-        if (dpp.big) SDIRT_LAUNCH_PSF(true, true); else SDIRT_LAUNCH_PSF(true, false);
+        if (dpp.big) SDIRT_LAUNCH_PSF_M(true, true); else SDIRT_LAUNCH_PSF_M(true, false);
     } else {
-        if (dpp.big) SDIRT_LAUNCH_PSF(false, true); else SDIRT_LAUNCH_PSF(false, false);
+        if (dpp.big) SDIRT_LAUNCH_PSF_M(false, true); else SDIRT_LAUNCH_PSF_M(false, false);
         // param_list=None leaves the R grid all-zero (monte_carlo.py:230-235)
         if (have_r) HIP_TRY(hipMemsetAsync(r_psf, 0, sizeof(float) * (size_t)N * tile, st));
     }
+#undef SDIRT_LAUNCH_PSF_M
 #undef SDIRT_LAUNCH_PSF
     LAUNCH_CHECK();
     if (nsplit > 1 && (flags & SDIRT_PSF_NORMALIZE)) {
@@ -890,6 +946,19 @@ int sdirt_psf_lr(const sdirt_lens* lens, const float* point_obj, int64_t N, cons
         if (have_r && dpp.have_r) k_psf_normalize<<<(int)N, kBlock, 0, st>>>(r_psf, tile);
         LAUNCH_CHECK();
     }
+    return SDIRT_OK;
+}
+
+int sdirt_selftest_math(int32_t mode, uint64_t first, uint64_t count, int32_t exp_span,
+                        uint64_t* out, void* stream)
+{
+    if (!out || mode < 0 || mode > 2 || exp_span < 0 || exp_span > 60)
+        return fail(SDIRT_ERR_INVALID_ARGUMENT, "bad argument");
+    HIP_TRY(hipMemsetAsync(out, 0, sizeof(uint64_t) * 9, as_stream(stream)));
+    if (count == 0) return SDIRT_OK;
+    k_selftest_math<<<256 * 32, 256, 0, as_stream(stream)>>>(mode, first, count, exp_span,
+                                                            (unsigned long long*)out);
+    LAUNCH_CHECK();
     return SDIRT_OK;
 }
 

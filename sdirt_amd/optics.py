@@ -92,6 +92,11 @@ class Lensgroup:
         self.trip_policy = "reference"
         #: optional hook reducing convergence masks over ranks (set by sdirt_amd.dist)
         self.mask_reduce = None
+        #: 'lean' (default): division / sqrt by rcp/sqrt seed + fma corrections, proven
+        #: bit-identical to IEEE for normal-range operands (all 2^46 mantissa pairs / every
+        #: fp32 >= 2^-100; tools/selftest_math.py).  'ieee': the compiler's full-range
+        #: sequences (also handles denormal / zero-denominator operands), ~1.26x slower.
+        self.precision = "lean"
         #: how the paraxial pupil is estimated from the 16 traced rays (optics.py:1470-1515):
         #: 'reference' = the reference's estimator: pairwise 2x2 systems solved in fp32 by
         #: torch.linalg.lstsq on the host (the same LAPACK call the reference's CPU path
@@ -231,6 +236,11 @@ class Lensgroup:
                 dl = _DevLens(self.surfaces, key)
             self._dev[key] = dl
         return dl.handle
+
+    def _math_flags(self):
+        if self.precision not in ("ieee", "lean"):
+            raise ValueError("precision must be 'lean' or 'ieee'")
+        return _lib.PSF_STRICT_IEEE if self.precision == "ieee" else 0
 
     def _timed(self, name):
         return _EventBracket(self.kernel_events, name, self.device)
@@ -395,9 +405,9 @@ class Lensgroup:
             with self._timed("chief_center"):
                 _lib.check(_lib.lib().sdirt_chief_center(
                     handle, dptr(po), po.shape[0], dptr(xc), dptr(yc), xc.shape[0], float(pupilz),
-                    float(self.d_sensor), trips, dptr(center), dptr(anyv), mask_ptr,
-                    stream_ptr(self.device)))
-        self._run_with_trips(("center",), range(len(self.surfaces)), enqueue)
+                    float(self.d_sensor), trips, self._math_flags(), dptr(center), dptr(anyv),
+                    mask_ptr, stream_ptr(self.device)))
+        self._run_with_trips(("center", self.precision), range(len(self.surfaces)), enqueue)
         if self.trip_policy == "reference":
             assert int(anyv.item()) == 1, "No sampled rays is valid."   # optics.py:902
         return center
@@ -470,7 +480,7 @@ class Lensgroup:
         R = torch.empty_like(L) if need_r else None
         dpp = None if (dp is None or _default_r_zero) else _lib.DpParams(*[float(v) for v in dp])
         handle = self.dev_lens(wvln)
-        flags = _lib.PSF_NORMALIZE if normalize else 0
+        flags = (_lib.PSF_NORMALIZE if normalize else 0) | self._math_flags()
 
         def enqueue(trips, mask_ptr):
             with self._timed("psf_lr"):
@@ -480,7 +490,7 @@ class Lensgroup:
                     C.byref(dpp) if dpp is not None else None, trips, flags, dptr(L), dptr(R),
                     mask_ptr, stream_ptr(self.device)))
         wkey = round(float(wvln if wvln < 10 else wvln * 1e-3), 6)
-        self._run_with_trips(("psf", wkey), range(len(self.surfaces)), enqueue)
+        self._run_with_trips(("psf", wkey, self.precision), range(len(self.surfaces)), enqueue)
         if R is None and want_r:
             R = torch.zeros_like(L)
         if single_point:

@@ -97,7 +97,7 @@ def test_chief_center(oracle, lens_name, fx):
     cen = torch.empty((po.shape[0], 2), device=DEV)
     x2d, y2d = t(x2), t(y2)
     lens._chief_center(po, x2d, y2d, st["pupil_z"], cen)
-    assert np.array_equal(lens.trips.cache[("center",)], g["trips_center"])
+    assert np.array_equal(lens.trips.cache[("center", "lean")], g["trips_center"])
     assert np.abs(cen.cpu().numpy() - g["center"]).max() < 4e-6       # mm; pixel is 46.9e-3 mm
     # oracle with the same pupil points and trips
     surf = oracle.surfaces_from_state(st, 0.589)
@@ -168,7 +168,7 @@ def test_psf_end_to_end_same_seed(oracle, lens_name, fx, seed):
     torch.manual_seed(seed)
     psf = lens.psf(torch.tensor(g["points"]), ks=int(g["ks"]), spp=int(g["spp"]))
     assert psf.shape == g["psf"].shape
-    assert np.array_equal(lens.trips.cache[("psf", 0.589)], g["trips"])
+    assert np.array_equal(lens.trips.cache[("psf", 0.589, "lean")], g["trips"])
     assert np.abs(psf.cpu().numpy() - g["psf"]).max() <= 3e-4
     # the fused kernel against the oracle on identical pupil points: tight
     x2, y2 = oracle.pupil_samples(g["u_theta"], g["u_r2"], st["pupil_r"])
@@ -209,8 +209,8 @@ def test_mini_config2_4096spp(oracle):
     L, R = lens.psf_lr(torch.tensor(g["points"]), ks=65, dp=DP,
                        pupil_xy=(g["pupil_x2"], g["pupil_y2"]),
                        center_pupil_xy=(g["pupil_xc"], g["pupil_yc"]))
-    assert np.array_equal(lens.trips.cache[("psf", 0.589)], g["trips"])
-    assert np.array_equal(lens.trips.cache[("center",)], g["trips_center"])
+    assert np.array_equal(lens.trips.cache[("psf", 0.589, "lean")], g["trips"])
+    assert np.array_equal(lens.trips.cache[("center", "lean")], g["trips_center"])
     L, R = L.cpu().numpy(), R.cpu().numpy()
     dl, dr = np.abs(L - g["psf"]), np.abs(R - gr["psf"])
     print("mini-C2 hand-off  max |dPSF|/peak: L", dl.max(), "R", dr.max(),

@@ -171,3 +171,54 @@ def test_staged_pipeline_equals_fused(lens):
                                        2048, st["pupil_z"], st["d_sensor"], st["pixel_size"], 33,
                                        dptr(cen), C.byref(dp), trips, 0, dptr(L), dptr(R), None, sp))
     assert torch.allclose(L, lg, atol=3e-6 * float(lg.max())) and torch.allclose(R, rg, atol=3e-6 * float(rg.max()))
+
+
+def test_lean_and_strict_ieee_modes_agree():
+    """The default lean division / sqrt are proven equal to IEEE on normal-range operands
+    (test_lean_math_is_exact below); on real rays the two kernel instantiations must give the
+    same centres bit for bit and the same PSFs up to LDS-atomic summation order."""
+    st, g = load_state("rf50mm"), load_golden("f8_rf50_mini_c2")
+    lens = make_lens("rf50mm", DEV, st)
+    kw = dict(ks=65, dp=DP, pupil_xy=(g["pupil_x2"], g["pupil_y2"]),
+              center_pupil_xy=(g["pupil_xc"], g["pupil_yc"]))
+    pts = torch.tensor(g["points"])
+    assert lens.precision == "lean"
+    Ll, Rl = lens.psf_lr(pts, **kw)
+    cl = lens.psf_center(lens._points_to_object(pts))      # draws fresh samples; compare below
+    lens.precision = "ieee"
+    Li, Ri = lens.psf_lr(pts, **kw)
+    assert np.array_equal(lens.trips.cache[("psf", 0.589, "ieee")], g["trips"])
+    assert np.array_equal(lens.trips.cache[("psf", 0.589, "lean")], g["trips"])
+    assert float((Ll - Li).abs().max()) < 1e-6 and float((Rl - Ri).abs().max()) < 1e-6
+    # centres: deterministic fp64 reduction -> bit-equal between the two instantiations
+    po = lens._points_to_object(pts)
+    xc, yc = torch.tensor(g["pupil_xc"], device=DEV), torch.tensor(g["pupil_yc"], device=DEV)
+    ci = torch.empty((len(pts), 2), device=DEV)
+    lens._chief_center(po, xc, yc, st["pupil_z"], ci)
+    lens.precision = "lean"
+    cl = torch.empty_like(ci)
+    lens._chief_center(po, xc, yc, st["pupil_z"], cl)
+    assert torch.equal(ci, cl)
+    with pytest.raises(ValueError):
+        lens.precision = "sloppy"
+        lens.psf_lr(pts[:1], ks=9, spp=64)
+
+
+def test_lean_math_is_exact():
+    """sdirt_selftest_math: the lean sqrt on EVERY fp32 >= 2^-100 and the lean division on
+    2^36 random operand pairs plus a 2^36 slice of the exhaustive mantissa-pair enumeration
+    (the full 2^46 run takes 46 s: tools/selftest_math.py, profiles/r01/selftest_math.txt)."""
+    from sdirt_amd import _lib
+    from sdirt_amd.basics import dptr, stream_ptr
+    out = torch.zeros(9, dtype=torch.int64, device=DEV)
+
+    def run(mode, first, count, span=0):
+        _lib.check(_lib.lib().sdirt_selftest_math(mode, first, count, span, dptr(out),
+                                                  stream_ptr(torch.device(DEV))))
+        return int(out.cpu()[0])
+    lo = (127 - 100) << 23
+    assert run(0, lo, 0x7F800000 - lo) == 0                     # all normals >= 2^-100
+    assert run(0, 0, 1) == 0 and run(0, 0x7F800000, 1) == 0     # +0, +inf
+    assert run(0, 0x80000000, 1) == 0 and run(0, 0xBF800000, 1) == 0   # -0, -1 -> NaN
+    assert run(1, 0, 1 << 36, 40) == 0
+    assert run(2, 0x123456789AB, 1 << 36) == 0

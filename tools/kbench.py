@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--spp", type=int, default=4096)
     ap.add_argument("--ks", type=int, default=65)
     ap.add_argument("--lens", default="rf50mm")
+    ap.add_argument("--flags", type=int, default=0, help="4 = SDIRT_PSF_STRICT_IEEE")
     args = ap.parse_args()
     from conftest import load_state, make_lens
     from sdirt_amd import _lib
@@ -58,11 +59,11 @@ def main():
 
     def center():
         _lib.check(h.sdirt_chief_center(hl, dptr(po), N, dptr(xyc[0]), dptr(xyc[1]), 2048, st["pupil_z"],
-                                        st["d_sensor"], tripc, dptr(cen), None, dptr(mask), sp))
+                                        st["d_sensor"], tripc, args.flags & 4, dptr(cen), None, dptr(mask), sp))
 
     def psf():
         _lib.check(h.sdirt_psf_lr(hl, dptr(po), N, dptr(xy[0]), dptr(xy[1]), args.spp, st["pupil_z"],
-                                  st["d_sensor"], st["pixel_size"], ks, dptr(cen), C.byref(dp), trips, 1,
+                                  st["d_sensor"], st["pixel_size"], ks, dptr(cen), C.byref(dp), trips, 1 | args.flags,
                                   dptr(L), dptr(R), dptr(mask), sp))
 
     def timeit(fn):
