@@ -529,32 +529,37 @@ k_psf_lr(const DevSurface* __restrict__ lens, int K, TripTable trips,
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ float round_half(float v) { return (float)(_Float16)v; }
 
-// One thread per output pixel (b, y, x); loops over the ks*ks taps once and
-// accumulates all channels of L and R.  The per-pixel kernels are read with the
-// flipped index (render_psf.py:138) so that consecutive lanes (consecutive x)
-// read consecutive ks*ks*2 blocks.
+// One WAVE per output pixel: the 64 lanes stride over the 2*ks*ks kernel taps of that
+// pixel, so the per-pixel PSFs -- the only large operand, 2*ks*ks*4 B per pixel, read exactly
+// once -- stream in as fully coalesced 256-B segments.  The image (a few MB) is gathered
+// through L1/L2 with replicate padding (clamped coordinates) and the flipped-tap index of
+// render_psf.py:138.  Each lane keeps C partial sums for L and for R; a butterfly of wave
+// shuffles reduces them.  A workgroup of 4 waves walks 4 consecutive pixels at a time.
 template <int C, bool HALF>
 __global__ void __launch_bounds__(kBlock)
 k_local_psf_render(const float* __restrict__ img, const float* __restrict__ psf, int B, int H, int W,
                    int ks, float* __restrict__ outl, float* __restrict__ outr)
 {
     const int64_t HW = (int64_t)H * W;
-    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= (int64_t)B * HW) return;
-    const int b = (int)(p / HW);
-    const int64_t q = p - (int64_t)b * HW;
-    const int y = (int)(q / W), x = (int)(q - (int64_t)y * W);
+    const int64_t P = (int64_t)B * HW;
+    const int lane = threadIdx.x & 63;
     const int pad = (ks - 1) / 2, kk = ks * ks;
-    const float* kl = psf + p * 2 * kk;
-    const float* kr = kl + kk;
-    float accl[C], accr[C];
+    const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t p = wave0; p < P; p += nwaves) {
+        const int b = (int)(p / HW);
+        const int64_t q = p - (int64_t)b * HW;
+        const int y = (int)(q / W), x = (int)(q - (int64_t)y * W);
+        const float* kl = psf + p * 2 * kk;
+        const float* kr = kl + kk;
+        float accl[C], accr[C];
 #pragma unroll
-    for (int c = 0; c < C; ++c) { accl[c] = 0.0f; accr[c] = 0.0f; }
-    for (int i = 0; i < ks; ++i) {
-        const int yy = min(max(y + i - pad, 0), H - 1);          // replicate padding
-        for (int jx = 0; jx < ks; ++jx) {
-            const int xx = min(max(x + jx - pad, 0), W - 1);
-            const int f = (ks - 1 - i) * ks + (ks - 1 - jx);     // flipped kernel tap
+        for (int c = 0; c < C; ++c) { accl[c] = 0.0f; accr[c] = 0.0f; }
+        for (int f = lane; f < kk; f += 64) {
+            // stored tap f multiplies the neighbour at the FLIPPED offset (render_psf.py:138)
+            const int fi = f / ks, fj = f - fi * ks;
+            const int yy = min(max(y + (ks - 1 - fi) - pad, 0), H - 1);
+            const int xx = min(max(x + (ks - 1 - fj) - pad, 0), W - 1);
             float wl = kl[f], wr = kr[f];
             if (HALF) { wl = round_half(wl); wr = round_half(wr); }
 #pragma unroll
@@ -570,12 +575,19 @@ k_local_psf_render(const float* __restrict__ img, const float* __restrict__ psf,
                 }
             }
         }
-    }
 #pragma unroll
-    for (int c = 0; c < C; ++c) {
-        const int64_t o = ((int64_t)(b * C + c) * H + y) * W + x;
-        outl[o] = HALF ? round_half(accl[c]) : accl[c];
-        outr[o] = HALF ? round_half(accr[c]) : accr[c];
+        for (int c = 0; c < C; ++c) {
+            float a = accl[c], r = accr[c];
+            for (int off = 32; off > 0; off >>= 1) {
+                a += __shfl_xor(a, off);
+                r += __shfl_xor(r, off);
+            }
+            if (lane == 0) {
+                const int64_t o = ((int64_t)(b * C + c) * H + y) * W + x;
+                outl[o] = HALF ? round_half(a) : a;
+                outr[o] = HALF ? round_half(r) : r;
+            }
+        }
     }
 }
 
@@ -970,7 +982,9 @@ int sdirt_local_psf_render(const float* img, const float* psf, int32_t B, int32_
         return fail(SDIRT_ERR_INVALID_ARGUMENT, "bad argument (ks must be odd)");
     if (B == 0) return SDIRT_OK;
     const int64_t P = (int64_t)B * H * W;
-    const int grid = (int)((P + kBlock - 1) / kBlock);
+    const int waves_per_block = kBlock / 64;
+    const int grid = grid_for(P * 64, kBlock, 256 * 32);      // one wave per pixel, grid-stride
+    (void)waves_per_block;
     hipStream_t st = as_stream(stream);
 #define SDIRT_RENDER(CC)                                                                        \
     do {                                                                                        \
