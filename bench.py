@@ -135,11 +135,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback exists)"
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # SDIRT_BENCH_BACKEND=gloo is a DRY-RUN aid for boxes with fewer GPUs than ranks (all ranks
+    # share the visible devices round-robin, collectives go through gloo): it exercises the
+    # multi-rank control flow, its numbers mean nothing.  The driver's runs use nccl (= RCCL).
+    backend = os.environ.get("SDIRT_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank if backend == "nccl" else local_rank % max(ndev, 1)
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from sdirt_amd import dist as sd
     lens = build_lens(device)
@@ -151,7 +160,13 @@ def main():
 
     if world > 1:
         sharded = sd.ShardedPSF.from_lens(lens, KS, dp=DP)
-        gather_buf = torch.empty((n_total, 2, KS, KS), dtype=torch.float32, device=device)
+        # the all-gather of step i runs on its own stream underneath the kernels of step i+1
+        # (double-buffered: xGMI copy engines / RCCL channels vs. VALU-bound compute)
+        comm_stream = torch.cuda.Stream(device)
+        gather_buf = [torch.empty((n_total, 2, KS, KS), dtype=torch.float32, device=device)
+                      for _ in range(2)]
+        in_flight = []          # (event, tensors kept alive until their gather has finished)
+    step_no = [0]
 
     def step():
         if world == 1:
@@ -159,11 +174,22 @@ def main():
         u = sd.broadcast_uniforms(SPP, device)
         L, R = sharded.render(points_local, u)
         if not args.no_gather:
-            sd.all_gather_shards(torch.stack((L, R), dim=1), n_total, world, out=gather_buf)
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(device))
+            buf = gather_buf[step_no[0] % 2]
+            with torch.cuda.stream(comm_stream):
+                comm_stream.wait_event(ready)
+                sd.all_gather_shards(torch.stack((L, R), dim=1), n_total, world, out=buf)
+                done = torch.cuda.Event()
+                done.record(comm_stream)
+            in_flight.append((done, L, R))
+            while len(in_flight) > 2:            # buffer reuse: wait for the gather two steps back
+                in_flight.pop(0)[0].synchronize()
+        step_no[0] += 1
         return L, R
 
     def fence():
-        torch.cuda.synchronize(device)
+        torch.cuda.synchronize(device)          # all streams of the device, the gather one too
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize(device)
@@ -205,6 +231,7 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "psfs_per_sec": n_total * args.steps / dt,
+            "backend": backend,
             "config": {"workload": f"rf50mm 32x32x{GRID_Z * world} (x,y,z) PSF volume, "
                                    f"{n_local} points/GPU, 4096 spp (+2048 chief-ray rays/point), "
                                    "65x65 L+R PSFs, lambda 0.589um, focus 1 m F/4",

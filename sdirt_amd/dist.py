@@ -67,7 +67,13 @@ def all_gather_shards(local, n_total, world, group=None, out=None):
         local = pad
     if out is None or out.shape != (world * width,) + tail:
         out = torch.empty((world * width,) + tail, dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+    if local.is_cuda and dist.get_backend(group) == "gloo":
+        # gloo has no CUDA all-gather: stage through the host (dry runs only, see bench.py)
+        host = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(host, local.contiguous().cpu(), group=group)
+        out.copy_(host)
+    else:
+        dist.all_gather_into_tensor(out, local.contiguous(), group=group)
     if all(b - a == width for a, b in bounds):
         return out
     return torch.cat([out[r * width:r * width + (b - a)] for r, (a, b) in enumerate(bounds)])
