@@ -94,7 +94,7 @@ template <> struct Lane<float> {
     static __device__ __forceinline__ float next_down(float a) { return __uint_as_float(__float_as_uint(a) - 1u); }
     static __device__ __forceinline__ Mask is_zero_or_pinf(float a)
     {
-        return __builtin_amdgcn_class(a, 0x260);   // -0 | +0 | +inf
+        return __builtin_amdgcn_classf(a, 0x260);   // -0 | +0 | +inf
     }
     template <class F> static __device__ __forceinline__ float map(float a, F f) { return f(a); }
 };
@@ -130,7 +130,7 @@ template <> struct Lane<f2> {
     }
     static __device__ __forceinline__ Mask is_zero_or_pinf(f2 a)
     {
-        return i2{__builtin_amdgcn_class(a.x, 0x260) ? -1 : 0, __builtin_amdgcn_class(a.y, 0x260) ? -1 : 0};
+        return i2{__builtin_amdgcn_classf(a.x, 0x260) ? -1 : 0, __builtin_amdgcn_classf(a.y, 0x260) ? -1 : 0};
     }
     static __device__ __forceinline__ f2 next_up(f2 a)
     {
@@ -176,6 +176,10 @@ using Ray = RayT<float>;
 struct Ieee {
     template <class T> static __device__ __forceinline__ T div(T a, T b) { return a / b; }
     template <class T> static __device__ __forceinline__ T sqrt(T x) { return Lane<T>::sqrt_ieee(x); }
+    template <class T> static __device__ __forceinline__ void div3(T& a0, T& a1, T& a2, T b)
+    {
+        a0 = a0 / b; a1 = a1 / b; a2 = a2 / b;
+    }
 };
 struct Lean {
     template <class T> static __device__ __forceinline__ T div(T a, T b)
@@ -185,6 +189,17 @@ struct Lean {
         const T y = L::fma(L::fma(-b, y0, L::splat(1.0f)), y0, y0);
         const T q0 = a * y;
         return L::fma(L::fma(-b, q0, a), y, q0);
+    }
+    // three numerators over one denominator: the refined reciprocal is computed once; each
+    // quotient is the same arithmetic as div(), hence the same bits
+    template <class T> static __device__ __forceinline__ void div3(T& a0, T& a1, T& a2, T b)
+    {
+        using L = Lane<T>;
+        const T y0 = L::rcp_fast(b);
+        const T y = L::fma(L::fma(-b, y0, L::splat(1.0f)), y0, y0);
+        T q = a0 * y; a0 = L::fma(L::fma(-b, q, a0), y, q);
+        q = a1 * y;   a1 = L::fma(L::fma(-b, q, a1), y, q);
+        q = a2 * y;   a2 = L::fma(L::fma(-b, q, a2), y, q);
     }
     template <class T> static __device__ __forceinline__ T sqrt(T x)
     {
@@ -229,9 +244,7 @@ __device__ __forceinline__ void normalize3(T& x, T& y, T& z)
     acc = L::fma(z, z, acc);
     T nrm = M::sqrt(acc);
     nrm = L::sel(L::lt(nrm, L::splat(1e-12f)), L::splat(1e-12f), nrm);
-    x = M::div(x, nrm);
-    y = M::div(y, nrm);
-    z = M::div(z, nrm);
+    M::div3(x, y, z, nrm);
 }
 
 // r2 ** n as torch evaluates it on CPU: n==2 -> x*x, n==3 -> (x*x)*x, n>=4 a
@@ -283,9 +296,9 @@ __device__ __forceinline__ T sag_dgd_only(const DevSurface& s, T r2)
 // mask_out (wave-uniform, lives in SGPRs) gets bit j set when ANY active lane of
 // the wave had |f(t)| > 50e-6 in trip j -- the per-wave share of the reference's
 // batch-wide `.any()` loop condition (surfaces.py:547).
-template <class M, class T>
-__device__ __forceinline__ typename Lane<T>::Mask newton(const DevSurface& s, const RayT<T>& r,
-                                                         int trips, T& t_out, uint32_t& mask_out)
+template <class M, bool KGT, class T>
+__device__ __forceinline__ typename Lane<T>::Mask newton_k(const DevSurface& s, const RayT<T>& r,
+                                                           int trips, T& t_out, uint32_t& mask_out)
 {
     using L = Lane<T>;
     using Mk = typename L::Mask;
@@ -294,13 +307,12 @@ __device__ __forceinline__ typename Lane<T>::Mask newton(const DevSurface& s, co
     const T dd = r.dx * r.dx + r.dy * r.dy;
     const T dox = r.dx * r.ox + r.dy * r.oy;
     const Mk alive = L::gt(r.ra, L::splat(0.0f));
-    const Mk kgt = L::all(s.k_gt_m1 != 0);
     T t = t0;
     uint32_t mask = 0;
     for (int it = 1; it <= trips; ++it) {
         const T nx = r.ox + r.dx * t, ny = r.oy + r.dy * t, nz = r.oz + r.dz * t;
         const T rr = nx * nx + ny * ny;
-        const Mk inside = s.k_gt_m1 ? L::lt(rr, L::splat(s.lim_loose)) : L::gt(rr, L::splat(0.0f));
+        const Mk inside = KGT ? L::lt(rr, L::splat(s.lim_loose)) : L::gt(rr, L::splat(0.0f));
         const T vf = L::to01(L::mand(inside, alive));
         const T x = nx * vf, y = ny * vf;
         const T r2 = x * x + y * y;
@@ -313,7 +325,6 @@ __device__ __forceinline__ typename Lane<T>::Mask newton(const DevSurface& s, co
         mask |= (__ballot(open) != 0ull) ? (1u << it) : 0u;
         t = t - clampv(M::div(ft, dfdt + eps), -kNewtonStepBound, kNewtonStepBound);
     }
-    (void)kgt;
     mask_out = mask;
     const T t1 = t - t0;   // :563
     t = t0 + t1;           // :567
@@ -321,7 +332,7 @@ __device__ __forceinline__ typename Lane<T>::Mask newton(const DevSurface& s, co
     const T nz = r.oz + r.dz * t;
     T rr = nx * nx + ny * ny;
     Mk v = L::mand(L::lt(rr, L::splat(s.r2_lim)), alive);
-    if (s.k_gt_m1) v = L::mand(v, L::lt(rr, L::splat(s.lim_loose)));
+    if (KGT) v = L::mand(v, L::lt(rr, L::splat(s.lim_loose)));
     const T vf = L::to01(v);
     const T x = nx * vf, y = ny * vf;
     const T r2 = x * x + y * y;
@@ -335,11 +346,21 @@ __device__ __forceinline__ typename Lane<T>::Mask newton(const DevSurface& s, co
     ny = r.oy + r.dy * t;
     rr = nx * nx + ny * ny;
     v = L::mand(L::lt(rr, L::splat(s.r2_lim)), alive);
-    if (s.k_gt_m1) v = L::mand(v, L::lt(rr, L::splat(s.lim_loose)));
+    if (KGT) v = L::mand(v, L::lt(rr, L::splat(s.lim_loose)));
     v = L::mand(v, L::lt(L::fabs(ft), L::splat(tol_tight)));
     v = L::mand(v, L::gt(t, L::splat(0.0f)));
     t_out = t;
     return v;
+}
+
+// k > -1 (every sphere, ellipsoid, mild asphere) and k <= -1 differ only in the domain test
+// (surfaces.py:727-743); the branch is wave-uniform, so it is taken once, outside the loop.
+template <class M, class T>
+__device__ __forceinline__ typename Lane<T>::Mask newton(const DevSurface& s, const RayT<T>& r,
+                                                         int trips, T& t_out, uint32_t& mask_out)
+{
+    if (s.k_gt_m1) return newton_k<M, true>(s, r, trips, t_out, mask_out);
+    return newton_k<M, false>(s, r, trips, t_out, mask_out);
 }
 
 // surfaces.py:633-679 with _normal (:589-630).  FWD: rays travel +z (n negated,
