@@ -5,6 +5,7 @@
 // for the data layout and the roofline of each kernel.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -546,6 +547,9 @@ k_local_psf_render(const float* __restrict__ img, const float* __restrict__ psf,
     const int pad = (ks - 1) / 2, kk = ks * ks;
     const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int rows_per_iter = ks <= 64 ? 64 / ks : 1;
+    const int lane_row = ks <= 64 ? lane / ks : 0;
+    const int lane_col = ks <= 64 ? lane - lane_row * ks : lane;
     for (int64_t p = wave0; p < P; p += nwaves) {
         const int b = (int)(p / HW);
         const int64_t q = p - (int64_t)b * HW;
@@ -555,23 +559,31 @@ k_local_psf_render(const float* __restrict__ img, const float* __restrict__ psf,
         float accl[C], accr[C];
 #pragma unroll
         for (int c = 0; c < C; ++c) { accl[c] = 0.0f; accr[c] = 0.0f; }
-        for (int f = lane; f < kk; f += 64) {
-            // stored tap f multiplies the neighbour at the FLIPPED offset (render_psf.py:138)
-            const int fi = f / ks, fj = f - fi * ks;
-            const int yy = min(max(y + (ks - 1 - fi) - pad, 0), H - 1);
-            const int xx = min(max(x + (ks - 1 - fj) - pad, 0), W - 1);
-            float wl = kl[f], wr = kr[f];
-            if (HALF) { wl = round_half(wl); wr = round_half(wr); }
+        // lanes tile the kernel as (rows_per_iter x ks): no integer division inside the loop,
+        // consecutive lanes read consecutive taps (and consecutive image columns)
+        for (int i0 = 0; i0 < ks; i0 += rows_per_iter) {
+            for (int j0 = 0; j0 < ks; j0 += 64) {
+                const int fi = i0 + lane_row, fj = j0 + lane_col;
+                if (lane_row < rows_per_iter && fi < ks && fj < ks) {
+                    const int f = fi * ks + fj;
+                    // stored tap f multiplies the neighbour at the FLIPPED offset (render_psf.py:138)
+                    const int yy = min(max(y + (ks - 1 - fi) - pad, 0), H - 1);
+                    const int xx = min(max(x + (ks - 1 - fj) - pad, 0), W - 1);
+                    float wl = kl[f], wr = kr[f];
+                    if (HALF) { wl = round_half(wl); wr = round_half(wr); }
+                    const float* px = img + ((int64_t)b * C * H + yy) * W + xx;
 #pragma unroll
-            for (int c = 0; c < C; ++c) {
-                float v = img[((int64_t)(b * C + c) * H + yy) * W + xx];
-                if (HALF) {
-                    v = round_half(v);
-                    accl[c] += round_half(v * wl);
-                    accr[c] += round_half(v * wr);
-                } else {
-                    accl[c] += v * wl;
-                    accr[c] += v * wr;
+                    for (int c = 0; c < C; ++c) {
+                        float v = px[(int64_t)c * HW];
+                        if (HALF) {
+                            v = round_half(v);
+                            accl[c] += round_half(v * wl);
+                            accr[c] += round_half(v * wr);
+                        } else {
+                            accl[c] += v * wl;
+                            accr[c] += v * wr;
+                        }
+                    }
                 }
             }
         }
@@ -588,6 +600,89 @@ k_local_psf_render(const float* __restrict__ img, const float* __restrict__ psf,
                 outr[o] = HALF ? round_half(r) : r;
             }
         }
+    }
+}
+
+// LDS-tiled variant: a workgroup streams the [L | R] kernels of PIX consecutive pixels (one
+// contiguous, 16-byte aligned run of PIX*2*ks*ks floats) into LDS with 16-B-per-lane loads --
+// every PSF byte is read from HBM exactly once, at full coalescing width -- then each wave
+// convolves PIX/4 of those pixels reading its weights from LDS.  Several workgroups per CU
+// overlap one group's staging with another's arithmetic.
+template <int C, bool HALF, int PIX>
+__global__ void __launch_bounds__(kBlock)
+k_local_psf_render_tiled(const float* __restrict__ img, const float* __restrict__ psf, int B, int H,
+                         int W, int ks, float* __restrict__ outl, float* __restrict__ outr)
+{
+    extern __shared__ __attribute__((aligned(16))) float wts[];     // [PIX][2][ks*ks]
+    const int64_t HW = (int64_t)H * W;
+    const int64_t P = (int64_t)B * HW;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pad = (ks - 1) / 2, kk = ks * ks;
+    const int rows_per_iter = ks <= 64 ? 64 / ks : 1;
+    const int lane_row = ks <= 64 ? lane / ks : 0;
+    const int lane_col = ks <= 64 ? lane - lane_row * ks : lane;
+    const int64_t ngroups = (P + PIX - 1) / PIX;
+    for (int64_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
+        const int64_t p0 = g * PIX;
+        const int npix = (int)min((int64_t)PIX, P - p0);
+        const int nfl = npix * 2 * kk;                                // floats in this group
+        const float* src = psf + p0 * 2 * kk;                         // 16-B aligned (PIX even)
+        const int nf4 = nfl >> 2;
+        const float4* src4 = reinterpret_cast<const float4*>(src);
+        float4* dst4 = reinterpret_cast<float4*>(wts);
+        for (int i = threadIdx.x; i < nf4; i += blockDim.x) dst4[i] = src4[i];
+        for (int i = (nf4 << 2) + threadIdx.x; i < nfl; i += blockDim.x) wts[i] = src[i];
+        __syncthreads();
+        for (int q = wave; q < npix; q += kBlock / 64) {
+            const int64_t p = p0 + q;
+            const int b = (int)(p / HW);
+            const int64_t r = p - (int64_t)b * HW;
+            const int y = (int)(r / W), x = (int)(r - (int64_t)y * W);
+            const float* kl = wts + q * 2 * kk;
+            const float* kr = kl + kk;
+            float accl[C], accr[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) { accl[c] = 0.0f; accr[c] = 0.0f; }
+            for (int i0 = 0; i0 < ks; i0 += rows_per_iter) {
+                for (int j0 = 0; j0 < ks; j0 += 64) {
+                    const int fi = i0 + lane_row, fj = j0 + lane_col;
+                    if (lane_row < rows_per_iter && fi < ks && fj < ks) {
+                        const int f = fi * ks + fj;
+                        const int yy = min(max(y + (ks - 1 - fi) - pad, 0), H - 1);
+                        const int xx = min(max(x + (ks - 1 - fj) - pad, 0), W - 1);
+                        float wl = kl[f], wr = kr[f];
+                        if (HALF) { wl = round_half(wl); wr = round_half(wr); }
+                        const float* px = img + ((int64_t)b * C * H + yy) * W + xx;
+#pragma unroll
+                        for (int c = 0; c < C; ++c) {
+                            float v = px[(int64_t)c * HW];
+                            if (HALF) {
+                                v = round_half(v);
+                                accl[c] += round_half(v * wl);
+                                accr[c] += round_half(v * wr);
+                            } else {
+                                accl[c] += v * wl;
+                                accr[c] += v * wr;
+                            }
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                float a = accl[c], rr = accr[c];
+                for (int off = 32; off > 0; off >>= 1) {
+                    a += __shfl_xor(a, off);
+                    rr += __shfl_xor(rr, off);
+                }
+                if (lane == 0) {
+                    const int64_t o = ((int64_t)(b * C + c) * H + y) * W + x;
+                    outl[o] = HALF ? round_half(a) : a;
+                    outr[o] = HALF ? round_half(rr) : rr;
+                }
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -982,16 +1077,34 @@ int sdirt_local_psf_render(const float* img, const float* psf, int32_t B, int32_
         return fail(SDIRT_ERR_INVALID_ARGUMENT, "bad argument (ks must be odd)");
     if (B == 0) return SDIRT_OK;
     const int64_t P = (int64_t)B * H * W;
-    const int waves_per_block = kBlock / 64;
     const int grid = grid_for(P * 64, kBlock, 256 * 32);      // one wave per pixel, grid-stride
-    (void)waves_per_block;
     hipStream_t st = as_stream(stream);
-#define SDIRT_RENDER(CC)                                                                        \
-    do {                                                                                        \
-        if (half_precision)                                                                     \
-            k_local_psf_render<CC, true><<<grid, kBlock, 0, st>>>(img, psf, B, H, W, ks, out_l, out_r); \
-        else                                                                                    \
-            k_local_psf_render<CC, false><<<grid, kBlock, 0, st>>>(img, psf, B, H, W, ks, out_l, out_r); \
+    // LDS-tiled kernel whenever 8 (or 4, or 2) pixels' kernels fit in 64 KB of LDS, else the
+    // direct one-wave-per-pixel kernel
+    const size_t per_pixel = sizeof(float) * 2 * (size_t)ks * ks;
+    const int pix = per_pixel * 8 <= 64 * 1024 ? 8 : per_pixel * 4 <= 64 * 1024 ? 4
+                    : per_pixel * 2 <= 64 * 1024 ? 2 : 0;
+    const size_t lds_tile = per_pixel * pix;
+    const int grid_t = pix ? (int)std::min<int64_t>((P + pix - 1) / pix, 256 * 64) : 0;
+#define SDIRT_RENDER_T(CC, HF, PP)                                                               \
+    do {                                                                                         \
+        if (lds_tile > 48 * 1024)                                                                \
+            HIP_TRY(hipFuncSetAttribute((const void*)k_local_psf_render_tiled<CC, HF, PP>,       \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)); \
+        k_local_psf_render_tiled<CC, HF, PP><<<grid_t, kBlock, lds_tile, st>>>(img, psf, B, H, W, \
+                                                                              ks, out_l, out_r); \
+    } while (0)
+#define SDIRT_RENDER_H(CC, HF)                                                                   \
+    do {                                                                                         \
+        if (pix == 8) SDIRT_RENDER_T(CC, HF, 8);                                                 \
+        else if (pix == 4) SDIRT_RENDER_T(CC, HF, 4);                                            \
+        else if (pix == 2) SDIRT_RENDER_T(CC, HF, 2);                                            \
+        else k_local_psf_render<CC, HF><<<grid, kBlock, 0, st>>>(img, psf, B, H, W, ks, out_l,    \
+                                                                out_r);                          \
+    } while (0)
+#define SDIRT_RENDER(CC)                                                                         \
+    do {                                                                                         \
+        if (half_precision) SDIRT_RENDER_H(CC, true); else SDIRT_RENDER_H(CC, false);            \
     } while (0)
     switch (C) {
     case 1: SDIRT_RENDER(1); break;
@@ -1000,6 +1113,8 @@ int sdirt_local_psf_render(const float* img, const float* psf, int32_t B, int32_
     default: return fail(SDIRT_ERR_UNSUPPORTED, "channels=%d (supported: 1, 3, 4)", C);
     }
 #undef SDIRT_RENDER
+#undef SDIRT_RENDER_H
+#undef SDIRT_RENDER_T
     LAUNCH_CHECK();
     return SDIRT_OK;
 }
