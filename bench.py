@@ -38,6 +38,16 @@ sys.path.insert(0, ROOT)
 
 KS, SPP, GRID_XY, GRID_Z = 65, 4096, 32, 16
 DP = (0.78, 1.44, 0.3, 0.5)
+# BASELINE.json configs: c2 is the headline (and the default); c3 / c4 are the other GPU
+# configurations, runnable with --workload for completeness (they are parity-test cases).
+WORKLOADS = {
+    "c2": dict(lens="rf50mm", ks=65, spp=4096, grid_z=16, sensor_z=62.25,
+               desc="rf50mm 32x32x{gz} (x,y,z) PSF volume"),
+    "c3": dict(lens="rf50mm", ks=21, spp=8192, grid_z=64, sensor_z=62.25,
+               desc="rf50mm dense PSFNet grid 32x32x{gz} (8 shards of 8192 points on a node)"),
+    "c4": dict(lens="rf35mm", ks=65, spp=4096, grid_z=16, sensor_z=80.447,
+               desc="rf35mm (21 surfaces) 32x32x{gz} PSF volume"),
+}
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s HBM3E
 
 
@@ -55,14 +65,14 @@ def volume_points(world):
     return pts.reshape(-1, 3).contiguous()
 
 
-def build_lens(device):
-    """rf50mm as 1_fit_psfnet.py:21-25 sets it up: sensor at 62.25 mm
-    (psfnet.py:44-45), then refocus to 1 m -- all with this package's own
-    geometric optics running on the GPU."""
+def build_lens(device, name="rf50mm", sensor_z=62.25):
+    """The lens as 1_fit_psfnet.py:21-25 sets it up: sensor at 62.25 mm (rf50mm) /
+    80.447 mm (rf35mm) (psfnet.py:42-45), then refocus to 1 m -- all with this
+    package's own geometric optics running on the GPU."""
     from sdirt_amd import Lensgroup
-    lens = Lensgroup(os.path.join(ROOT, "sdirt_amd", "data", "rf50mm.json"),
+    lens = Lensgroup(os.path.join(ROOT, "sdirt_amd", "data", f"{name}.json"),
                      sensor_res=(512, 768), post_computation=False, device=device)
-    lens.d_sensor = 62.25
+    lens.d_sensor = sensor_z
     torch.manual_seed(0)
     lens.post_computation()
     lens.refocus(-1000 + lens.d_sensor)
@@ -127,7 +137,13 @@ def main():
     ap.add_argument("--no-gather", action="store_true",
                     help="skip the all-gather of the PSF shards (N > 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2")
     args = ap.parse_args()
+    global KS, SPP, GRID_Z
+    wl = WORKLOADS[args.workload]
+    KS, SPP = wl["ks"], wl["spp"]
+    # c3 is a 65536-point grid meant for 8 GPUs: per-GPU slab = 8 depth planes
+    GRID_Z = wl["grid_z"] if args.workload != "c3" else 8
 
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -151,7 +167,7 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     from sdirt_amd import dist as sd
-    lens = build_lens(device)
+    lens = build_lens(device, wl["lens"], wl["sensor_z"])
     points_all = volume_points(world)
     n_total = points_all.shape[0]
     a, b = sd.shard_bounds(n_total, world)[rank]
@@ -222,19 +238,20 @@ def main():
         ach = alg_bytes / (k_ms["psf_lr"] * 1e-3) / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(pmc):
+        if os.path.exists(pmc) and args.workload == "c2":
             with open(pmc) as f:
                 traffic = json.load(f).get("k_psf_lr_hbm_bytes_per_launch")
         res = {
-            "metric": "rays/sec rf50mm 65x65 DP-PSF @4096spp", "value": rays / dt,
+            "metric": f"rays/sec {wl['lens']} {KS}x{KS} DP-PSF @{SPP}spp", "value": rays / dt,
             "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "psfs_per_sec": n_total * args.steps / dt,
             "backend": backend,
-            "config": {"workload": f"rf50mm 32x32x{GRID_Z * world} (x,y,z) PSF volume, "
-                                   f"{n_local} points/GPU, 4096 spp (+2048 chief-ray rays/point), "
-                                   "65x65 L+R PSFs, lambda 0.589um, focus 1 m F/4",
+            "config": {"workload": wl["desc"].format(gz=GRID_Z * world)
+                                   + f", {n_local} points/GPU, {SPP} spp (+2048 chief-ray "
+                                   f"rays/point), {KS}x{KS} L+R PSFs, lambda 0.589um, focus 1 m F/4",
+                       "name": args.workload,
                        "points_per_gpu": n_local, "spp": SPP, "ks": KS,
                        "parallelism": f"points sharded over {world} GPU(s)"
                                       + ("" if world == 1 or args.no_gather
@@ -246,7 +263,7 @@ def main():
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "k_psf_lr", "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "scalar-per-ray fp32 math: the kernel is VALU-bound by "
-                                 "construction (~9 k VALU instr/ray), see DESIGN.md §3"},
+                                 "construction (~6.4 k VALU instr/ray vs 8.25 B/ray), DESIGN.md §3"},
         }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(lens, points_all)

@@ -20,7 +20,6 @@ namespace sdirt {
 
 constexpr int kMaxAi = 8;
 constexpr float kNewtonStepBound = 5.0f;   // deeplens/surfaces.py:29
-constexpr float kMaxT = 1e5f;              // deeplens/basics.py:33
 
 // Flat per-surface constant block.  Every field that the reference obtains by
 // rounding a Python/numpy float64 to fp32 at the point of use is rounded on the

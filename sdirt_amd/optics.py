@@ -14,14 +14,12 @@ libsdirt_dp.so is not built or no MI355X is visible.
 """
 import ctypes as C
 import json
-import os
 
 import numpy as np
 import torch
 
 from . import _lib
-from .basics import (DEFAULT_WAVE, DEPTH, EPSILON, GEO_SPP, WAVE_RGB, Material, Ray, dptr,
-                     stream_ptr)
+from .basics import DEFAULT_WAVE, DEPTH, GEO_SPP, WAVE_RGB, Ray, dptr, stream_ptr
 from .newton import NEWTON_MAXITER, TripPlanner
 from .surfaces import Aspheric
 

@@ -54,6 +54,30 @@ def test_full_config2_volume(lens):
     assert torch.allclose(R1.sum((1, 2)), L2.sum((1, 2)), rtol=2e-5)
 
 
+@pytest.mark.parametrize("name,ks,spp,n_z", [("rf35mm", 65, 4096, 16), ("rf50mm", 21, 8192, 8)])
+def test_other_baseline_configs_full_size(name, ks, spp, n_z):
+    """BASELINE config 4 (rf35mm, 21 surfaces, same volume) and one GPU's share of config 3
+    (dense grid, 8192 spp, ks 21) at full size: finite, non-negative, every PSF normalised,
+    L and R energies consistent with the closed-form sub-pixel areas (s_l + s_r <= 1)."""
+    import bench
+    ln = make_lens(name, DEV)
+    bench.GRID_Z = n_z
+    try:
+        pts = bench.volume_points(1)
+    finally:
+        bench.GRID_Z = 16
+    torch.manual_seed(4)
+    L, R = ln.psf_lr(pts, ks=ks, spp=spp, dp=DP, normalize=False)
+    assert L.shape == (1024 * n_z, ks, ks)
+    assert torch.isfinite(L).all() and torch.isfinite(R).all()
+    assert float(L.min()) >= 0 and float(R.min()) >= 0
+    e = L.sum((1, 2)) + R.sum((1, 2))
+    assert float(e.max()) <= spp * (1 + 1e-5)            # energy never exceeds the ray count
+    assert float((L.sum((1, 2)) > 0).float().mean()) == 1.0
+    Ln, Rn = ln.psf_lr(pts[::97], ks=ks, spp=spp, dp=DP)
+    assert float(Ln.amax((1, 2)).min()) > 0.99 and float(Rn.amax((1, 2)).max()) <= 1.0
+
+
 def test_single_point_and_default_param_list(lens):
     p = torch.tensor([0.3, -0.2, -1500.0])
     torch.manual_seed(5)
