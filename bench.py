@@ -183,12 +183,18 @@ def main():
                       for _ in range(2)]
         in_flight = []          # (event, tensors kept alive until their gather has finished)
     step_no = [0]
+    # output buffers are owned by the caller and re-used (two sets: the previous step's PSFs
+    # may still be feeding the all-gather / the consumer while the next step renders)
+    out_bufs = [tuple(torch.empty((n_local, KS, KS), dtype=torch.float32, device=device)
+                      for _ in range(2)) for _ in range(2)]
 
     def step():
+        out = out_bufs[step_no[0] % 2]
         if world == 1:
-            return lens.psf_lr(points_local, ks=KS, spp=SPP, dp=DP)
+            step_no[0] += 1
+            return lens.psf_lr(points_local, ks=KS, spp=SPP, dp=DP, out=out)
         u = sd.broadcast_uniforms(SPP, device)
-        L, R = sharded.render(points_local, u)
+        L, R = sharded.render(points_local, u, out)
         if not args.no_gather:
             ready = torch.cuda.Event()
             ready.record(torch.cuda.current_stream(device))

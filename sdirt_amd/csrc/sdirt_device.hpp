@@ -226,9 +226,9 @@ template <class T>
 __device__ __forceinline__ T clampv(T v, float lo, float hi)
 {
     using L = Lane<T>;
+    // a NaN fails both comparisons and passes through, as torch.clamp does
     T w = L::sel(L::lt(v, L::splat(lo)), L::splat(lo), v);
-    w = L::sel(L::gt(w, L::splat(hi)), L::splat(hi), w);
-    return L::sel(L::isnan(v), v, w);
+    return L::sel(L::gt(w, L::splat(hi)), L::splat(hi), w);
 }
 
 // torch.nn.functional.normalize over a last dim of 3 (basics.py:245,
@@ -312,9 +312,9 @@ __device__ __forceinline__ typename Lane<T>::Mask newton_k(const DevSurface& s, 
         const T nx = r.ox + r.dx * t, ny = r.oy + r.dy * t, nz = r.oz + r.dz * t;
         const T rr = nx * nx + ny * ny;
         const Mk inside = KGT ? L::lt(rr, L::splat(s.lim_loose)) : L::gt(rr, L::splat(0.0f));
-        const T vf = L::to01(L::mand(inside, alive));
-        const T x = nx * vf, y = ny * vf;
-        const T r2 = x * x + y * y;
+        // g(x*valid, y*valid) (surfaces.py:694-696): (x*1)^2 + (y*1)^2 is rr bit for bit, and
+        // (x*0)^2 + (y*0)^2 is 0 for every finite position
+        const T r2 = L::sel(L::mand(inside, alive), rr, L::splat(0.0f));
         T g, dgd;
         sag_g_dgd<M>(s, r2, g, dgd);
         const T ft = (g + s.d) - nz;
@@ -332,9 +332,7 @@ __device__ __forceinline__ typename Lane<T>::Mask newton_k(const DevSurface& s, 
     T rr = nx * nx + ny * ny;
     Mk v = L::mand(L::lt(rr, L::splat(s.r2_lim)), alive);
     if (KGT) v = L::mand(v, L::lt(rr, L::splat(s.lim_loose)));
-    const T vf = L::to01(v);
-    const T x = nx * vf, y = ny * vf;
-    const T r2 = x * x + y * y;
+    const T r2 = L::sel(v, rr, L::splat(0.0f));
     T g, dgd;
     sag_g_dgd<M>(s, r2, g, dgd);
     const T ft = (g + s.d) - nz;

@@ -105,11 +105,11 @@ class ShardedPSF:
                                                       stream_ptr(lens.device)))
             return xy[0], xy[1]
 
-        def render(points_local, u):
+        def render(points_local, u, out=None):
             _, pr = lens.entrance_pupil()
             return lens.psf_lr(points_local, ks=ks, wvln=wvln, dp=dp,
                                pupil_xy=disc(u[0], u[1], pr),
-                               center_pupil_xy=disc(u[2], u[3], pr * 0.25))
+                               center_pupil_xy=disc(u[2], u[3], pr * 0.25), out=out)
         return cls(render, lens.device, group)
 
     def local_slice(self, n_total):

@@ -430,7 +430,7 @@ class Lensgroup:
     @torch.no_grad()
     def psf_lr(self, points, ks=31, wvln=DEFAULT_WAVE, spp=GEO_SPP, center=True,
                dp=(0.78, 1.44, 0.3, 0.5), normalize=True, want_r=True, _default_r_zero=False,
-               pupil_xy=None, center_pupil_xy=None):
+               pupil_xy=None, center_pupil_xy=None, out=None):
         """Left AND right dual-pixel PSFs of one ray-traced batch: (L, R), each
         [N,ks,ks] (or [ks,ks] for a single point), max-normalised separately as
         optics.py:983-987 would normalise each of them.  dp = (h, f, w, r) of
@@ -439,7 +439,11 @@ class Lensgroup:
         pupil_xy / center_pupil_xy: optional explicit pupil sample points
         (x2[spp], y2[spp]) for the primary and the chief-ray pass; when given,
         no random numbers are drawn for that pass (used for ray-level parity
-        hand-off and for quasi-random sampling)."""
+        hand-off and for quasi-random sampling).
+
+        out: optional (L, R) float32 CUDA tensors [N,ks,ks] to write into -- a consumer
+        that renders batch after batch (PSFNet fitting) re-uses its buffers instead of
+        asking the caching allocator for two 277 MB blocks per call."""
         self._require_gpu()
         if not torch.is_tensor(points):
             points = torch.tensor(points)
@@ -473,9 +477,16 @@ class Lensgroup:
             pts = points.to(self.device, torch.float32)
             cen[:, 0] = pts[:, 0] * (self.sensor_size[1] / 2)      # optics.py:973-975
             cen[:, 1] = pts[:, 1] * (self.sensor_size[0] / 2)
-        L = torch.empty((N, ks, ks), dtype=torch.float32, device=self.device)
         need_r = want_r and not _default_r_zero
-        R = torch.empty_like(L) if need_r else None
+        if out is not None:
+            L, R = out[0], (out[1] if need_r else None)
+            for t_ in (L, R):
+                if t_ is not None and not (t_.is_cuda and t_.dtype == torch.float32 and t_.is_contiguous()
+                                           and tuple(t_.shape) == (N, ks, ks)):
+                    raise ValueError("out tensors must be contiguous float32 CUDA [N, ks, ks]")
+        else:
+            L = torch.empty((N, ks, ks), dtype=torch.float32, device=self.device)
+            R = torch.empty_like(L) if need_r else None
         dpp = None if (dp is None or _default_r_zero) else _lib.DpParams(*[float(v) for v in dp])
         handle = self.dev_lens(wvln)
         flags = (_lib.PSF_NORMALIZE if normalize else 0) | self._math_flags()

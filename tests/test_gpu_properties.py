@@ -154,6 +154,20 @@ def test_edge_cases(lens):
     assert L.shape == (1, 21, 21) and float(L.max()) > 0.99
 
 
+def test_caller_owned_output_buffers(lens):
+    pts = torch.tensor([[0.1, 0.2, -900.0], [-0.4, 0.3, -6000.0]])
+    L = torch.full((2, 17, 17), -1.0, device=DEV)
+    R = torch.full((2, 17, 17), -1.0, device=DEV)
+    torch.manual_seed(9)
+    L2, R2 = lens.psf_lr(pts, ks=17, spp=512, dp=DP, out=(L, R))
+    assert L2.data_ptr() == L.data_ptr() and R2.data_ptr() == R.data_ptr()
+    torch.manual_seed(9)
+    L3, R3 = lens.psf_lr(pts, ks=17, spp=512, dp=DP)
+    assert torch.allclose(L, L3, atol=2e-6) and torch.allclose(R, R3, atol=2e-6)
+    with pytest.raises(ValueError):
+        lens.psf_lr(pts, ks=17, spp=64, dp=DP, out=(L[:, :9], R))
+
+
 def test_rgb_and_map_shapes(lens):
     pts = torch.tensor([[0.0, 0.0, -1000.0], [0.5, 0.5, -2000.0]])
     rgb = lens.psf_rgb(pts, ks=11, spp=128)
