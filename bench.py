@@ -179,8 +179,8 @@ def main():
         # the all-gather of step i runs on its own stream underneath the kernels of step i+1
         # (double-buffered: xGMI copy engines / RCCL channels vs. VALU-bound compute)
         comm_stream = torch.cuda.Stream(device)
-        gather_buf = [torch.empty((n_total, 2, KS, KS), dtype=torch.float32, device=device)
-                      for _ in range(2)]
+        gather_buf = [tuple(torch.empty((n_total, KS, KS), dtype=torch.float32, device=device)
+                            for _ in range(2)) for _ in range(2)]          # (L_all, R_all) x 2
         in_flight = []          # (event, tensors kept alive until their gather has finished)
     step_no = [0]
     # output buffers are owned by the caller and re-used (two sets: the previous step's PSFs
@@ -201,7 +201,8 @@ def main():
             buf = gather_buf[step_no[0] % 2]
             with torch.cuda.stream(comm_stream):
                 comm_stream.wait_event(ready)
-                sd.all_gather_shards(torch.stack((L, R), dim=1), n_total, world, out=buf)
+                sd.all_gather_shards(L, n_total, world, out=buf[0])     # no staging copy:
+                sd.all_gather_shards(R, n_total, world, out=buf[1])     # shards go straight out
                 done = torch.cuda.Event()
                 done.record(comm_stream)
             in_flight.append((done, L, R))
