@@ -54,10 +54,18 @@ def broadcast_uniforms(spp, device, n_center=GEO_SPP, group=None, src=0):
     return u[:spp], u[spp:2 * spp], u[2 * spp:2 * spp + n_center], u[2 * spp + n_center:]
 
 
-def all_gather_shards(local, n_total, world, group=None, out=None):
+def all_gather_shards(local, n_total, world, group=None, out=None, algo=None):
     """local: [n_local, ...] shard of a contiguous partition (shard_bounds) ->
     [n_total, ...] on every rank.  Shards are padded to the largest one so a
-    single all_gather_into_tensor moves everything."""
+    single all_gather_into_tensor moves everything.
+
+    algo (or env SDIRT_GATHER_ALGO): 'allgather' (default) = one RCCL all-gather;
+    'direct' = every rank posts one send and one receive per peer in a single
+    batch_isend_irecv group -- xGMI is a full mesh of point-to-point links, so the
+    seven transfers of a GPU can use its seven links at once instead of being
+    paced by a ring.  Same result; to be compared on an 8-GPU node."""
+    import os
+    algo = algo or os.environ.get("SDIRT_GATHER_ALGO", "allgather")
     bounds = shard_bounds(n_total, world)
     width = max(b - a for a, b in bounds)
     tail = tuple(local.shape[1:])
@@ -67,7 +75,19 @@ def all_gather_shards(local, n_total, world, group=None, out=None):
         local = pad
     if out is None or out.shape != (world * width,) + tail:
         out = torch.empty((world * width,) + tail, dtype=local.dtype, device=local.device)
-    if local.is_cuda and dist.get_backend(group) == "gloo":
+    if algo == "direct" and world > 1:
+        rank = dist.get_rank(group)
+        local = local.contiguous()
+        out[rank * width:(rank + 1) * width].copy_(local)
+        ops = []
+        for peer in range(world):
+            if peer == rank:
+                continue
+            ops.append(dist.P2POp(dist.isend, local, peer, group))
+            ops.append(dist.P2POp(dist.irecv, out[peer * width:(peer + 1) * width], peer, group))
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    elif local.is_cuda and dist.get_backend(group) == "gloo":
         # gloo has no CUDA all-gather: stage through the host (dry runs only, see bench.py)
         host = torch.empty(out.shape, dtype=out.dtype)
         dist.all_gather_into_tensor(host, local.contiguous().cpu(), group=group)

@@ -45,6 +45,11 @@ def _worker(rank, world, port, n_total, ks, out_dir):
     a, b = sharded.local_slice(n_total)
     L, R = sharded.psf_volume(pts, spp=16, gather=True)
     Ll, Rl = sharded.psf_volume(pts, spp=16, gather=False)
+    # the point-to-point ("direct") gather must reassemble the same tensor as the collective
+    mine = torch.arange(b - a, dtype=torch.float32).reshape(-1, 1) + 100 * rank
+    g1 = sd.all_gather_shards(mine, n_total, world, algo="allgather")
+    g2 = sd.all_gather_shards(mine, n_total, world, algo="direct")
+    assert torch.equal(g1, g2) and g1.shape[0] == n_total
 
     # batch-global trip table: rank 1 holds the slow ray on surface 1
     need = [10, 3 + rank, 0, 2]
