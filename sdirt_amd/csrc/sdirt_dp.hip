@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <type_traits>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -603,16 +604,35 @@ k_local_psf_render(const float* __restrict__ img, const float* __restrict__ psf,
     }
 }
 
+// Sum over the 64 lanes of a wave with DPP row operations (VALU only: no LDS traffic, no
+// address registers); the total is returned in every lane.
+__device__ __forceinline__ float wave_sum(float v)
+{
+#define SDIRT_DPP_ADD(CTRL, ROWS)                                                               \
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROWS, 0xF, false))
+    SDIRT_DPP_ADD(0xB1, 0xF);     // quad_perm [1,0,3,2]
+    SDIRT_DPP_ADD(0x4E, 0xF);     // quad_perm [2,3,0,1]
+    SDIRT_DPP_ADD(0x141, 0xF);    // row_half_mirror
+    SDIRT_DPP_ADD(0x140, 0xF);    // row_mirror: every lane of a 16-lane row holds the row sum
+    SDIRT_DPP_ADD(0x142, 0xA);    // row_bcast:15 -> rows 1 and 3 add the previous row
+    SDIRT_DPP_ADD(0x143, 0xC);    // row_bcast:31 -> rows 2 and 3 add rows 0+1
+#undef SDIRT_DPP_ADD
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
 // LDS-tiled variant: a workgroup streams the [L | R] kernels of PIX consecutive pixels (one
 // contiguous, 16-byte aligned run of PIX*2*ks*ks floats) into LDS with 16-B-per-lane loads --
 // every PSF byte is read from HBM exactly once, at full coalescing width -- then each wave
 // convolves PIX/4 of those pixels reading its weights from LDS.  Several workgroups per CU
 // overlap one group's staging with another's arithmetic.
-template <int C, bool HALF, int PIX>
+template <int C, bool HALF, int PIX, int KS>
 __global__ void __launch_bounds__(kBlock)
 k_local_psf_render_tiled(const float* __restrict__ img, const float* __restrict__ psf, int B, int H,
-                         int W, int ks, float* __restrict__ outl, float* __restrict__ outr)
+                         int W, int ks_rt, float* __restrict__ outl, float* __restrict__ outr)
 {
+    // KS > 0: kernel size fixed at compile time -> the tap loop unrolls and all image gathers
+    // of a pixel are in flight together; KS == 0: run-time size
+    const int ks = KS > 0 ? KS : ks_rt;
     extern __shared__ __attribute__((aligned(16))) float wts[];     // [PIX][2][ks*ks]
     const int64_t HW = (int64_t)H * W;
     const int64_t P = (int64_t)B * HW;
@@ -628,9 +648,20 @@ k_local_psf_render_tiled(const float* __restrict__ img, const float* __restrict_
         const int nfl = npix * 2 * kk;                                // floats in this group
         const float* src = psf + p0 * 2 * kk;                         // 16-B aligned (PIX even)
         const int nf4 = nfl >> 2;
-        const float4* src4 = reinterpret_cast<const float4*>(src);
-        float4* dst4 = reinterpret_cast<float4*>(wts);
-        for (int i = threadIdx.x; i < nf4; i += blockDim.x) dst4[i] = src4[i];
+        typedef float fl4 __attribute__((ext_vector_type(4)));
+        const fl4* src4 = reinterpret_cast<const fl4*>(src);
+        fl4* dst4 = reinterpret_cast<fl4*>(wts);
+        // keep STAGE_U 16-byte loads per thread in flight before the first LDS write
+        constexpr int STAGE_U = 8;
+        for (int base = threadIdx.x; base < nf4; base += kBlock * STAGE_U) {
+            fl4 v[STAGE_U];
+#pragma unroll
+            for (int u = 0; u < STAGE_U; ++u)
+                if (base + u * kBlock < nf4) v[u] = __builtin_nontemporal_load(&src4[base + u * kBlock]);
+#pragma unroll
+            for (int u = 0; u < STAGE_U; ++u)
+                if (base + u * kBlock < nf4) dst4[base + u * kBlock] = v[u];
+        }
         for (int i = (nf4 << 2) + threadIdx.x; i < nfl; i += blockDim.x) wts[i] = src[i];
         __syncthreads();
         for (int q = wave; q < npix; q += kBlock / 64) {
@@ -643,6 +674,7 @@ k_local_psf_render_tiled(const float* __restrict__ img, const float* __restrict_
             float accl[C], accr[C];
 #pragma unroll
             for (int c = 0; c < C; ++c) { accl[c] = 0.0f; accr[c] = 0.0f; }
+#pragma unroll(KS > 0 ? 8 : 1)
             for (int i0 = 0; i0 < ks; i0 += rows_per_iter) {
                 for (int j0 = 0; j0 < ks; j0 += 64) {
                     const int fi = i0 + lane_row, fj = j0 + lane_col;
@@ -670,11 +702,7 @@ k_local_psf_render_tiled(const float* __restrict__ img, const float* __restrict_
             }
 #pragma unroll
             for (int c = 0; c < C; ++c) {
-                float a = accl[c], rr = accr[c];
-                for (int off = 32; off > 0; off >>= 1) {
-                    a += __shfl_xor(a, off);
-                    rr += __shfl_xor(rr, off);
-                }
+                const float a = wave_sum(accl[c]), rr = wave_sum(accr[c]);
                 if (lane == 0) {
                     const int64_t o = ((int64_t)(b * C + c) * H + y) * W + x;
                     outl[o] = HALF ? round_half(a) : a;
@@ -1089,14 +1117,18 @@ int sdirt_local_psf_render(const float* img, const float* psf, int32_t B, int32_
 #define SDIRT_RENDER_T(CC, HF, PP)                                                               \
     do {                                                                                         \
         if (lds_tile > 48 * 1024)                                                                \
-            HIP_TRY(hipFuncSetAttribute((const void*)k_local_psf_render_tiled<CC, HF, PP>,       \
+            HIP_TRY(hipFuncSetAttribute((const void*)k_local_psf_render_tiled<CC, HF, PP, 0>,    \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)); \
-        k_local_psf_render_tiled<CC, HF, PP><<<grid_t, kBlock, lds_tile, st>>>(img, psf, B, H, W, \
-                                                                              ks, out_l, out_r); \
+        k_local_psf_render_tiled<CC, HF, PP, 0><<<grid_t, kBlock, lds_tile, st>>>(               \
+            img, psf, B, H, W, ks, out_l, out_r);                                                \
     } while (0)
 #define SDIRT_RENDER_H(CC, HF)                                                                   \
     do {                                                                                         \
-        if (pix == 8) SDIRT_RENDER_T(CC, HF, 8);                                                 \
+        /* the reference's PSFNet kernel size (configs/dfdp_by_sdirt_rf50mm.yml: ks 21) on RGB */ \
+        if (pix == 8 && ks == 21 && CC == 3)                                                     \
+            k_local_psf_render_tiled<3, HF, 8, 21><<<grid_t, kBlock, lds_tile, st>>>(            \
+                img, psf, B, H, W, ks, out_l, out_r);                                            \
+        else if (pix == 8) SDIRT_RENDER_T(CC, HF, 8);                                            \
         else if (pix == 4) SDIRT_RENDER_T(CC, HF, 4);                                            \
         else if (pix == 2) SDIRT_RENDER_T(CC, HF, 2);                                            \
         else k_local_psf_render<CC, HF><<<grid, kBlock, 0, st>>>(img, psf, B, H, W, ks, out_l,    \
