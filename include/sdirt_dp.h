@@ -89,6 +89,19 @@ typedef struct sdirt_dp_params {
     double h, f, w, r;
 } sdirt_dp_params;
 
+/* ---- flags ---------------------------------------------------------------- */
+#define SDIRT_PSF_NORMALIZE 1u /* apply optics.py:983-987 to each written grid */
+#define SDIRT_PSF_ACCUMULATE 2u /* internal: grids pre-zeroed, blocks add partial tiles */
+/* By default the fused kernels divide and take square roots with "lean" sequences (rcp /
+ * sqrt seed + fma corrections, 6 and 10 instructions) that are PROVEN bit-identical to
+ * correctly rounded IEEE results for normal-range operands: all 2^46 mantissa pairs for the
+ * division, every fp32 >= 2^-100 for the square root (sdirt_selftest_math, tools/
+ * selftest_math.py, profiles/r01/selftest_math.txt).  They skip the range scaling and
+ * special-value fix-up of the compiler's 12/17-instruction sequences: x/0 yields NaN
+ * instead of inf, denormal operands are not handled.  No valid ray produces such operands.
+ * This flag selects the compiler's full-range IEEE sequences instead (~1.26x slower). */
+#define SDIRT_PSF_STRICT_IEEE 4u
+
 /* ---- library ------------------------------------------------------------ */
 int sdirt_abi_version(void);
 const char* sdirt_last_error(void);
@@ -153,8 +166,9 @@ int sdirt_rays_to_aos(sdirt_rays rays, int64_t n_rays, float* o /*dev [M,3] or N
  * 1..T-1 are set and bit T is clear (or T == 10); sdirt_amd/newton.py runs that
  * check and re-launches with the corrected table when speculation fails. */
 int sdirt_trace(const sdirt_lens* lens, int32_t first, int32_t last, int32_t backward,
-                const int32_t* trips /*host [K]*/, sdirt_rays rays, int64_t n_rays,
-                uint32_t* conv_mask /*dev [K] or NULL*/, void* stream);
+                const int32_t* trips /*host [K]*/, uint32_t flags /*SDIRT_PSF_STRICT_IEEE or 0*/,
+                sdirt_rays rays, int64_t n_rays, uint32_t* conv_mask /*dev [K] or NULL*/,
+                void* stream);
 
 /* Ray.propagate_to, deeplens/basics.py:256-264. */
 int sdirt_propagate_to(double z, sdirt_rays rays, int64_t n_rays, void* stream);
@@ -189,17 +203,7 @@ int sdirt_chief_center(const sdirt_lens* lens, const float* point_obj /*dev [N,3
                        float* center /*dev [N,2]*/, int32_t* any_valid /*dev or NULL*/,
                        uint32_t* conv_mask /*dev [K] or NULL*/, void* stream);
 
-#define SDIRT_PSF_NORMALIZE 1u /* apply optics.py:983-987 to each written grid */
-#define SDIRT_PSF_ACCUMULATE 2u /* internal: grids pre-zeroed, blocks add partial tiles */
-/* By default the fused kernels divide and take square roots with "lean" sequences (rcp /
- * sqrt seed + fma corrections, 6 and 10 instructions) that are PROVEN bit-identical to
- * correctly rounded IEEE results for normal-range operands: all 2^46 mantissa pairs for the
- * division, every fp32 >= 2^-100 for the square root (sdirt_selftest_math, tools/
- * selftest_math.py, profiles/r01/selftest_math.txt).  They skip the range scaling and
- * special-value fix-up of the compiler's 12/17-instruction sequences: x/0 yields NaN
- * instead of inf, denormal operands are not handled.  No valid ray produces such operands.
- * This flag selects the compiler's full-range IEEE sequences instead (~1.26x slower). */
-#define SDIRT_PSF_STRICT_IEEE 4u
+
 
 /* Lensgroup.psf_diff, deeplens/optics.py:934-996, fused from sampling to the
  * normalised left/right PSFs: one workgroup per (point, spp-slice), rays

@@ -265,7 +265,7 @@ __global__ void k_rays_to_aos(sdirt_rays R, int64_t M, float* __restrict__ o, fl
     }
 }
 
-template <bool FWD>
+template <bool FWD, class MP>
 __global__ void __launch_bounds__(kBlock)
 k_trace(const DevSurface* __restrict__ lens, int K, int first, int last, TripTable trips,
         sdirt_rays R, int64_t M, uint32_t* __restrict__ conv_mask)
@@ -276,7 +276,7 @@ k_trace(const DevSurface* __restrict__ lens, int K, int first, int last, TripTab
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M;
          i += (int64_t)gridDim.x * blockDim.x) {
         Ray r = load_ray(R, i);
-        trace_ray<FWD>(lens, first, last, trips, r, conv_mask ? lds_mask : nullptr);
+        trace_ray<FWD, MP>(lens, first, last, trips, r, conv_mask ? lds_mask : nullptr);
         store_ray(R, i, r);
     }
     __syncthreads();
@@ -674,7 +674,7 @@ k_local_psf_render_tiled(const float* __restrict__ img, const float* __restrict_
             float accl[C], accr[C];
 #pragma unroll
             for (int c = 0; c < C; ++c) { accl[c] = 0.0f; accr[c] = 0.0f; }
-#pragma unroll(KS > 0 ? 8 : 1)
+#pragma unroll KS > 0 ? 8 : 1
             for (int i0 = 0; i0 < ks; i0 += rows_per_iter) {
                 for (int j0 = 0; j0 < ks; j0 += 64) {
                     const int fi = i0 + lane_row, fj = j0 + lane_col;
@@ -908,7 +908,8 @@ int sdirt_rays_to_aos(sdirt_rays rays, int64_t M, float* o, float* d, void* stre
 }
 
 int sdirt_trace(const sdirt_lens* lens, int32_t first, int32_t last, int32_t backward,
-                const int32_t* trips, sdirt_rays rays, int64_t M, uint32_t* conv_mask, void* stream)
+                const int32_t* trips, uint32_t flags, sdirt_rays rays, int64_t M,
+                uint32_t* conv_mask, void* stream)
 {
     if (!lens) return fail(SDIRT_ERR_INVALID_ARGUMENT, "null lens");
     if (first < 0 || last > lens->n_surfaces || first > last)
@@ -919,12 +920,16 @@ int sdirt_trace(const sdirt_lens* lens, int32_t first, int32_t last, int32_t bac
     if (int rc = make_trips(lens, trips, tt)) return rc;
     if (M <= 0 || first == last) return M < 0 ? fail(SDIRT_ERR_INVALID_ARGUMENT, "n_rays < 0") : SDIRT_OK;
     const int grid = grid_for(M, kBlock);
-    if (backward)
-        k_trace<false><<<grid, kBlock, 0, as_stream(stream)>>>(lens->dev, lens->n_surfaces, first,
-                                                               last, tt, rays, M, conv_mask);
-    else
-        k_trace<true><<<grid, kBlock, 0, as_stream(stream)>>>(lens->dev, lens->n_surfaces, first,
-                                                              last, tt, rays, M, conv_mask);
+    const bool lean = (flags & SDIRT_PSF_STRICT_IEEE) == 0;
+#define SDIRT_LAUNCH_TRACE(FW, MM)                                                              \
+    k_trace<FW, MM><<<grid, kBlock, 0, as_stream(stream)>>>(lens->dev, lens->n_surfaces, first, \
+                                                            last, tt, rays, M, conv_mask)
+    if (backward) {
+        if (lean) SDIRT_LAUNCH_TRACE(false, Lean); else SDIRT_LAUNCH_TRACE(false, Ieee);
+    } else {
+        if (lean) SDIRT_LAUNCH_TRACE(true, Lean); else SDIRT_LAUNCH_TRACE(true, Ieee);
+    }
+#undef SDIRT_LAUNCH_TRACE
     LAUNCH_CHECK();
     return SDIRT_OK;
 }

@@ -321,8 +321,8 @@ class Lensgroup:
 
         def enqueue(trips, mask_ptr):
             _lib.check(_lib.lib().sdirt_trace(handle, first, last, 0 if forward else 1, trips,
-                                              ray.c_rays(), ray.numel, mask_ptr,
-                                              stream_ptr(self.device)))
+                                              self._math_flags(), ray.c_rays(), ray.numel,
+                                              mask_ptr, stream_ptr(self.device)))
 
         if self.trip_policy == "reference":
             # the trace is in place: keep the input to be able to re-launch
@@ -334,7 +334,7 @@ class Lensgroup:
                     ray.soa.copy_(saved)
                 calls[0] += 1
                 enqueue(trips, mask_ptr)
-            key = ("trace", round(float(ray.wvln), 6), first, last, forward)
+            key = ("trace", round(float(ray.wvln), 6), first, last, forward, self.precision)
             self._run_with_trips(key, order, enqueue_fresh)
         else:
             self._run_with_trips(None, order, enqueue)

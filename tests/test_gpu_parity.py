@@ -34,14 +34,18 @@ def rays_from_fixture(o, d, wvln=0.589):
     return r
 
 
+@pytest.mark.parametrize("precision", ["lean", "ieee"])
 @pytest.mark.parametrize("lens_name,fx", [("rf50mm", "f1_rf50_c1"), ("rf50mm", "f2_rf50_pts4"),
                                           ("rf35mm", "f3_rf35_pts4")])
-def test_staged_trace_bit_exact_vs_oracle_and_close_to_reference(oracle, lens_name, fx):
+def test_staged_trace_bit_exact_vs_oracle_and_close_to_reference(oracle, lens_name, fx, precision):
+    """Both math policies -- the default lean division/sqrt and the compiler's IEEE
+    sequences -- must reproduce the IEEE CPU oracle bit for bit."""
     st, g = load_state(lens_name), load_golden(fx)
     lens = make_lens(lens_name, DEV, st)
+    lens.precision = precision
     ray = rays_from_fixture(g["ray_o0"], g["ray_d0"])
     ray, valid, _ = lens.trace(ray)
-    used = lens.trips.cache[("trace", 0.589, 0, len(lens.surfaces), True)]
+    used = lens.trips.cache[("trace", 0.589, 0, len(lens.surfaces), True, precision)]
     # the speculate+verify loop must land on the reference's global trip counts
     assert np.array_equal(used, g["trips"])
     surf = oracle.surfaces_from_state(st, 0.589)

@@ -202,7 +202,7 @@ def test_staged_pipeline_equals_fused(lens):
     _lib.check(_lib.lib().sdirt_pupil_samples(dptr(ud[0]), dptr(ud[1]), 2048, st["pupil_r"],
                                               dptr(xy[0]), dptr(xy[1]), sp))
     K = len(lens.surfaces)
-    trips = (C.c_int32 * K)(*[int(v) for v in lens.trips.cache[("trace", 0.589, 0, K, True)]])
+    trips = (C.c_int32 * K)(*[int(v) for v in lens.trips.cache[("trace", 0.589, 0, K, True, "lean")]])
     L = torch.empty((2, 33, 33), device=DEV); R = torch.empty_like(L)
     dp = _lib.DpParams(*DP)
     _lib.check(_lib.lib().sdirt_psf_lr(lens.dev_lens(0.589), dptr(po), 2, dptr(xy[0]), dptr(xy[1]),
