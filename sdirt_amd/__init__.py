@@ -10,10 +10,11 @@ from .basics import DEFAULT_WAVE, DEPTH, EPSILON, GEO_SPP, WAVE_RGB, Material, R
 from .monte_carlo import (assign_points_to_pixels_big_r, assign_points_to_pixels_small_r,
                           forward_integral, forward_integral_lr)
 from .optics import Lensgroup
-from .render_psf import local_dp_psf_render, local_psf_render, local_psf_render_fast
+from .render_psf import (local_dp_psf_render, local_psf_render, local_psf_render_fast, render_psf,
+                         render_psf_map)
 from .surfaces import Aspheric
 
 __all__ = ["Lensgroup", "Ray", "Material", "Aspheric", "SdirtError", "forward_integral",
            "forward_integral_lr", "assign_points_to_pixels_small_r",
            "assign_points_to_pixels_big_r", "local_psf_render", "local_psf_render_fast",
-           "local_dp_psf_render", "DEFAULT_WAVE", "WAVE_RGB", "GEO_SPP", "EPSILON", "DEPTH"]
+           "local_dp_psf_render", "render_psf", "render_psf_map", "DEFAULT_WAVE", "WAVE_RGB", "GEO_SPP", "EPSILON", "DEPTH"]

@@ -41,3 +41,36 @@ def local_dp_psf_render(input, dp_psf, kernel_size=21):
     """render_psf.py:157-188 (fp32) -> [N, 2C, H, W] = cat(left, right)."""
     rl, rr = _render(input, dp_psf, kernel_size, half=False)
     return torch.cat([rl, rr], dim=1)
+
+
+def render_psf(img, psf):
+    """render_psf.py:12-28: one PSF for the whole image, [B,C,H,W] x [C,ks,ks].  A plain
+    grouped convolution with reflect padding: dense conv work that stock PyTorch-ROCm
+    (MIOpen) already covers -- kept for API completeness, not a custom kernel."""
+    _, ks, _ = psf.shape
+    padding = int(ks / 2)
+    k = torch.flip(psf, [1, 2]).unsqueeze(1)
+    img_pad = torch.nn.functional.pad(img, (padding, padding, padding, padding), mode="reflect")
+    return torch.nn.functional.conv2d(img_pad, k, groups=img.shape[1], padding=0, bias=None)
+
+
+def render_psf_map(img, psf_map, grid):
+    """render_psf.py:31-73: a grid x grid mosaic of PSFs, one per image patch."""
+    assert img.dim() == 4, "Input image should be [B, C, H, W]"
+    Cpsf, Hpsf, Wpsf = psf_map.shape
+    assert Hpsf % grid == 0 and Wpsf % grid == 0, "PSF map size should be divisible by grid"
+    ks = int(Hpsf / grid)
+    assert ks % 2 == 1, "PSF kernel size should be odd"
+    B, C, H, W = img.shape
+    assert C == Cpsf, "PSF map should have the same channel as image"
+    pad = int((ks - 1) / 2)
+    img_pad = torch.nn.functional.pad(img, (pad, pad, pad, pad), mode="reflect")
+    out = torch.zeros_like(img)
+    for i in range(grid):
+        for j in range(grid):
+            k = torch.flip(psf_map[:, i * ks:(i + 1) * ks, j * ks:(j + 1) * ks], [1, 2]).unsqueeze(1)
+            h0, w0 = int(i / grid * H), int(j / grid * W)
+            h1, w1 = int((i + 1) / grid * H), int((j + 1) / grid * W)
+            patch = img_pad[:, :, h0:h1 + 2 * pad, w0:w1 + 2 * pad]
+            out[:, :, h0:h1, w0:w1] = torch.nn.functional.conv2d(patch, k, groups=C, padding="valid")
+    return out

@@ -217,3 +217,16 @@ def test_tracing_without_gpu_fails_loudly():
                                                     torch.ones(4), x_tan=torch.zeros(4))
     with pytest.raises(SdirtError):
         render_psf.local_psf_render_fast(torch.zeros(1, 3, 4, 4), torch.zeros(1, 4, 4, 2, 3, 3), 3)
+
+
+def test_global_psf_convolution_matches_reference_fixture():
+    """render_psf / render_psf_map (render_psf.py:12-73) are stock torch convolutions and run on
+    any device; checked here on CPU against the reference's output."""
+    from conftest import load_golden
+    from sdirt_amd import render_psf, render_psf_map
+    g = load_golden("f7_render")
+    out = render_psf(torch.tensor(g["img"]), torch.tensor(g["psf_global"]))
+    assert np.abs(out.numpy() - g["global"]).max() < 1e-6
+    # a 1x1 "map" is the same thing
+    out2 = render_psf_map(torch.tensor(g["img"]), torch.tensor(g["psf_global"]), 1)
+    assert np.abs(out2.numpy() - g["global"]).max() < 1e-6
