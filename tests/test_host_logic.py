@@ -204,7 +204,8 @@ def test_argument_validation_without_a_device():
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
 def test_tracing_without_gpu_fails_loudly():
     from sdirt_amd import Lensgroup, SdirtError
-    from sdirt_amd import monte_carlo, render_psf
+    from sdirt_amd import monte_carlo
+    from sdirt_amd.render_psf import local_psf_render_fast
     lens = Lensgroup(os.path.join(DATA, "rf50mm.json"), sensor_res=(512, 768),
                      post_computation=False, device="cpu")
     lens.set_state(hfov=0.39, pupil=(22.5, 6.0))
@@ -216,7 +217,7 @@ def test_tracing_without_gpu_fails_loudly():
         monte_carlo.assign_points_to_pixels_small_r(torch.zeros(4, 2), 5, [-1, 1], [-1, 1],
                                                     torch.ones(4), x_tan=torch.zeros(4))
     with pytest.raises(SdirtError):
-        render_psf.local_psf_render_fast(torch.zeros(1, 3, 4, 4), torch.zeros(1, 4, 4, 2, 3, 3), 3)
+        local_psf_render_fast(torch.zeros(1, 3, 4, 4), torch.zeros(1, 4, 4, 2, 3, 3), 3)
 
 
 def test_global_psf_convolution_matches_reference_fixture():
