@@ -193,8 +193,8 @@ def main():
         if world == 1:
             step_no[0] += 1
             return lens.psf_lr(points_local, ks=KS, spp=SPP, dp=DP, out=out)
-        u = sd.broadcast_uniforms(SPP, device)
-        L, R = sharded.render(points_local, u, out)
+        pupil = sd.broadcast_pupil_points(lens, SPP)
+        L, R = sharded.render(points_local, pupil, out)
         if not args.no_gather:
             ready = torch.cuda.Event()
             ready.record(torch.cuda.current_stream(device))

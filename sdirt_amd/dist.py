@@ -54,6 +54,22 @@ def broadcast_uniforms(spp, device, n_center=GEO_SPP, group=None, src=0):
     return u[:spp], u[spp:2 * spp], u[2 * spp:2 * spp + n_center], u[2 * spp + n_center:]
 
 
+def broadcast_pupil_points(lens, spp, n_center=GEO_SPP, group=None, src=0):
+    """Rank `src` draws and maps the primary and the chief-ray pupil sample sets exactly as a
+    single-GPU Lensgroup.psf_lr call would (same RNG order, same mapping); every rank
+    receives the same points: (x2, y2, xc, yc)."""
+    buf = torch.empty(2 * spp + 2 * n_center, dtype=torch.float32, device=lens.device)
+    if dist.get_rank(group) == src:
+        _, pr = lens.entrance_pupil()
+        x2, y2 = lens._pupil_samples(spp, pr)
+        xc, yc = lens._pupil_samples(n_center, pr * 0.25)
+        buf.copy_(torch.cat([x2, y2, xc, yc]))
+    if dist.get_world_size(group) > 1:
+        dist.broadcast(buf, src=src, group=group)
+    return (buf[:spp], buf[spp:2 * spp], buf[2 * spp:2 * spp + n_center],
+            buf[2 * spp + n_center:])
+
+
 def all_gather_shards(local, n_total, world, group=None, out=None, algo=None):
     """local: [n_local, ...] shard of a contiguous partition (shard_bounds) ->
     [n_total, ...] on every rank.  Shards are padded to the largest one so a
@@ -109,28 +125,20 @@ class ShardedPSF:
 
     def __init__(self, render, device, group=None):
         self.render, self.device, self.group = render, torch.device(device), group
+        self.lens = None
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
 
     @classmethod
     def from_lens(cls, lens, ks, wvln=0.589, dp=(0.78, 1.44, 0.3, 0.5), group=None):
-        from . import _lib
-        from .basics import dptr, stream_ptr
         lens.mask_reduce = lambda m: reduce_masks_or(m, group)
 
-        def disc(u_t, u_r, radius):
-            xy = torch.empty((2, u_t.shape[0]), dtype=torch.float32, device=lens.device)
-            _lib.check(_lib.lib().sdirt_pupil_samples(dptr(u_t), dptr(u_r), u_t.shape[0],
-                                                      float(radius), dptr(xy[0]), dptr(xy[1]),
-                                                      stream_ptr(lens.device)))
-            return xy[0], xy[1]
-
-        def render(points_local, u, out=None):
-            _, pr = lens.entrance_pupil()
-            return lens.psf_lr(points_local, ks=ks, wvln=wvln, dp=dp,
-                               pupil_xy=disc(u[0], u[1], pr),
-                               center_pupil_xy=disc(u[2], u[3], pr * 0.25), out=out)
-        return cls(render, lens.device, group)
+        def render(points_local, pupil, out=None):
+            return lens.psf_lr(points_local, ks=ks, wvln=wvln, dp=dp, pupil_xy=(pupil[0], pupil[1]),
+                               center_pupil_xy=(pupil[2], pupil[3]), out=out)
+        self = cls(render, lens.device, group)
+        self.lens = lens
+        return self
 
     def local_slice(self, n_total):
         return shard_bounds(n_total, self.world)[self.rank]
@@ -140,7 +148,10 @@ class ShardedPSF:
         gather, else of this rank's shard."""
         n_total = points.shape[0]
         a, b = self.local_slice(n_total)
-        u = broadcast_uniforms(spp, self.device, group=self.group)
+        if self.lens is not None:
+            u = broadcast_pupil_points(self.lens, spp, group=self.group)
+        else:
+            u = broadcast_uniforms(spp, self.device, group=self.group)
         L, R = self.render(points[a:b], u)
         if not gather or self.world == 1:
             return L, R

@@ -102,6 +102,9 @@ class Lensgroup:
         #: rf50mm -- the reference's PSFs are rendered with THAT pupil, so it is the default.
         #: 'exact' = closed-form float64 intersections (deterministic, unbiased).
         self.pupil_method = "reference"
+        #: where the uniform -> pupil-disc mapping runs: 'device' (default) or 'host' (the
+        #: reference's own torch CPU expressions; see _pupil_samples)
+        self.pupil_mapping = "device"
         #: when a dict, kernel launches are bracketed with HIP events on the launch
         #: stream: {'psf_lr': [(start, end), ...], 'chief_center': [...]}  (bench.py)
         self.kernel_events = None
@@ -291,9 +294,24 @@ class Lensgroup:
         return ray
 
     def _pupil_samples(self, spp, pupil_r):
-        """optics.py:483-488.  The two uniform vectors come from torch's CPU
-        default generator in the reference's order; the disc mapping runs on the GPU."""
-        u = torch.stack((torch.rand(spp), torch.rand(spp))).to(self.device)
+        """optics.py:483-488: spp points on the pupil disc -> device arrays (x2, y2).
+
+        The two uniform vectors always come from torch's CPU default generator in the
+        reference's order (that is what makes seeds line up).  pupil_mapping='device'
+        (default) maps them to the disc with the sdirt_pupil_samples kernel (correctly rounded
+        sin/cos).  'host' evaluates the reference's own CPU tensor expressions
+        (optics.py:483-486) instead: bit-identical sample points to the reference ON THE SAME
+        MACHINE -- torch's sin/cos are MKL kernels whose last bit differs between CPU models
+        (the Xeon that produced tests/golden and the EPYC of the GPU box disagree on ~5 % of
+        the samples) -- at the price of threaded MKL calls (measured 24 ms per call on a
+        256-thread host under a 16-CPU quota)."""
+        u_theta, u_r2 = torch.rand(spp), torch.rand(spp)
+        if self.pupil_mapping == "host":
+            theta = u_theta * 2 * np.pi
+            r = torch.sqrt(u_r2 * pupil_r ** 2)
+            xy = torch.stack((r * torch.cos(theta), r * torch.sin(theta))).to(self.device)
+            return xy[0], xy[1]
+        u = torch.stack((u_theta, u_r2)).to(self.device)
         xy = torch.empty((2, spp), dtype=torch.float32, device=self.device)
         _lib.check(_lib.lib().sdirt_pupil_samples(dptr(u[0]), dptr(u[1]), spp, float(pupil_r),
                                                   dptr(xy[0]), dptr(xy[1]),

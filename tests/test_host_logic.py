@@ -231,3 +231,18 @@ def test_global_psf_convolution_matches_reference_fixture():
     # a 1x1 "map" is the same thing
     out2 = render_psf_map(torch.tensor(g["img"]), torch.tensor(g["psf_global"]), 1)
     assert np.abs(out2.numpy() - g["global"]).max() < 1e-6
+
+
+def test_host_pupil_mapping_expressions_match_the_reference():
+    """pupil_mapping='host' evaluates optics.py:483-486 with torch CPU ops: on the machine that
+    generated the fixtures the sample points are bit-identical, elsewhere (other MKL code
+    path) within 1 ulp."""
+    from conftest import load_golden, load_state, ulp_diff
+    st, g = load_state("rf50mm"), load_golden("f8_rf50_mini_c2")
+    torch.manual_seed(8)
+    u_theta, u_r2 = torch.rand(4096), torch.rand(4096)
+    assert np.array_equal(u_theta.numpy(), g["u_theta"]) and np.array_equal(u_r2.numpy(), g["u_r2"])
+    theta = u_theta * 2 * np.pi
+    r = torch.sqrt(u_r2 * st["pupil_r"] ** 2)
+    x2, y2 = (r * torch.cos(theta)).numpy(), (r * torch.sin(theta)).numpy()
+    assert ulp_diff(x2, g["pupil_x2"]).max() <= 2 and ulp_diff(y2, g["pupil_y2"]).max() <= 2
