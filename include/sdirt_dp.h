@@ -91,7 +91,6 @@ typedef struct sdirt_dp_params {
 
 /* ---- flags ---------------------------------------------------------------- */
 #define SDIRT_PSF_NORMALIZE 1u /* apply optics.py:983-987 to each written grid */
-#define SDIRT_PSF_ACCUMULATE 2u /* internal: grids pre-zeroed, blocks add partial tiles */
 /* By default the fused kernels divide and take square roots with "lean" sequences (rcp /
  * sqrt seed + fma corrections, 6 and 10 instructions) that are PROVEN bit-identical to
  * correctly rounded IEEE results for normal-range operands: all 2^46 mantissa pairs for the

@@ -148,9 +148,6 @@ constexpr int kBlock = 256;
 #ifndef SDIRT_FUSED_BLOCK
 #define SDIRT_FUSED_BLOCK 512
 #endif
-#ifndef SDIRT_PSF_WAVES
-#define SDIRT_PSF_WAVES 1
-#endif
 constexpr int kFused = SDIRT_FUSED_BLOCK;
 
 __device__ __forceinline__ Ray load_ray(const sdirt_rays& R, int64_t i)
@@ -440,7 +437,7 @@ k_chief_center(const DevSurface* __restrict__ lens, int K, TripTable trips,
 //   nsplit  > 1 : tiles are added to the pre-zeroed output with global float
 //                 atomics; the caller normalises afterwards.
 template <bool HAVE_R, bool BIG, class HotMath>
-__global__ void __launch_bounds__(kFused, SDIRT_PSF_WAVES)
+__global__ void __launch_bounds__(kFused)
 k_psf_lr(const DevSurface* __restrict__ lens, int K, TripTable trips,
          const float* __restrict__ po, const float* __restrict__ x2, const float* __restrict__ y2,
          int S, int nsplit, int chunk, float pz, float zs, SplatGeom gm, DevDpParams dp,
