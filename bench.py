@@ -6,8 +6,8 @@ Workload (BASELINE.json configs[1]): rf50mm refocused to 1 m (F/4 stop),
 per point, 65x65 LEFT and RIGHT PSFs, lambda = 0.589 um.  One "step" = one
 Lensgroup.psf_lr call over the rank's 16384 points: draw the pupil uniforms
 (torch CPU generator, the reference's order), chief-ray centre pass (2048 rays
-per point), fused sample->trace->splat->normalise kernel, verification of the
-batch-global Newton trip counts, and -- for N > 1 -- the RCCL all-gather of the
+per point) and the sample->trace->splat->normalise pass in ONE fused kernel launch,
+verification of the batch-global Newton trip counts, and -- for N > 1 -- the RCCL all-gather of the
 PSF shards.  Weak scaling: every rank renders its own 16384-point slab of a
 32x32x(16*N) volume.
 
@@ -241,8 +241,9 @@ def main():
         rays = n_total * SPP * args.steps
         # algorithmic HBM bytes of ONE k_psf_lr launch: read the points,
         # centres and pupil samples once, write the L and R tiles once.
-        alg_bytes = n_local * (12 + 8) + SPP * 8 + 2 * n_local * KS * KS * 4
-        ach = alg_bytes / (k_ms["psf_lr"] * 1e-3) / 1e9
+        alg_bytes = n_local * (12 + 8) + (SPP + 2048) * 8 + 2 * n_local * KS * KS * 4
+        dom = "psf_lr_centered" if "psf_lr_centered" in k_ms else "psf_lr"
+        ach = alg_bytes / (k_ms[dom] * 1e-3) / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
         if os.path.exists(pmc) and args.workload == "c2":
@@ -268,7 +269,9 @@ def main():
             "kernels_ms": k_ms, "kernel_launches": n_launch,
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_psf_lr", "algorithmic_bytes_per_launch": alg_bytes,
+                         "kernel": "k_psf_lr<R,small-r,Lean,CENTER> (chief-ray pass + primary pass "
+                                   "of a point in one workgroup)",
+                         "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "scalar-per-ray fp32 math: the kernel is VALU-bound by "
                                  "construction (~6.4 k VALU instr/ray vs 8.25 B/ray), DESIGN.md §3"},
         }

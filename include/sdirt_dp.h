@@ -218,6 +218,24 @@ int sdirt_psf_lr(const sdirt_lens* lens, const float* point_obj /*dev [N,3]*/, i
                  float* r_psf /*dev or NULL*/, uint32_t* conv_mask /*dev [K] or NULL*/,
                  void* stream);
 
+/* Lensgroup.psf_diff with center=True in ONE call: the chief-ray pass (sdirt_chief_center,
+ * through lens_center = the lens at the default wavelength, optics.py:900) and the primary
+ * pass.  When one workgroup owns a point (always, unless few points carry very many samples)
+ * both passes run inside a single kernel launch -- no second launch, no host round trip between
+ * them; otherwise the centre kernel is enqueued first.  center [N,2] receives the centres;
+ * conv_mask / conv_mask_center as in sdirt_trace, one per pass. */
+int sdirt_psf_lr_centered(const sdirt_lens* lens, const sdirt_lens* lens_center,
+                          const float* point_obj /*dev [N,3]*/, int64_t n_points,
+                          const float* x2 /*dev [S]*/, const float* y2 /*dev [S]*/, int64_t spp,
+                          const float* xc /*dev [Sc]*/, const float* yc /*dev [Sc]*/,
+                          int64_t spp_center, double pupil_z, double d_sensor, double ps, int32_t ks,
+                          const sdirt_dp_params* dp /*host or NULL*/,
+                          const int32_t* trips /*host [K]*/, const int32_t* trips_center /*host [K]*/,
+                          uint32_t flags, float* center /*dev [N,2], out*/,
+                          int32_t* any_valid /*dev or NULL*/, float* l_psf /*dev [N,ks,ks]*/,
+                          float* r_psf /*dev or NULL*/, uint32_t* conv_mask /*dev [K] or NULL*/,
+                          uint32_t* conv_mask_center /*dev [K] or NULL*/, void* stream);
+
 /* ---- diagnostics ----------------------------------------------------------- */
 
 /* Counts how often the lean arithmetic (the default, see SDIRT_PSF_STRICT_IEEE) differs from correctly rounded IEEE:

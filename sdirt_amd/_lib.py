@@ -67,6 +67,9 @@ SIGNATURES = {
                                      _P, _P, _P, _P]),
     "sdirt_psf_lr": (C.c_int, [_P, _P, _I64, _P, _P, _I64, _D, _D, _D, _I32, _P,
                                C.POINTER(DpParams), C.POINTER(_I32), _U32, _P, _P, _P, _P]),
+    "sdirt_psf_lr_centered": (C.c_int, [_P, _P, _P, _I64, _P, _P, _I64, _P, _P, _I64, _D, _D, _D, _I32,
+                                        C.POINTER(DpParams), C.POINTER(_I32), C.POINTER(_I32), _U32,
+                                        _P, _P, _P, _P, _P, _P, _P]),
     "sdirt_selftest_math": (C.c_int, [_I32, C.c_uint64, C.c_uint64, _I32, _P, _P]),
     "sdirt_local_psf_render": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P, _P]),
 }

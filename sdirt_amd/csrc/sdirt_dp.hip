@@ -383,7 +383,7 @@ __global__ void __launch_bounds__(kBlock) k_psf_normalize(float* __restrict__ ps
 // psf_center: one workgroup per point, Sc rays, fp64 partial sums reduced in a
 // fixed order (deterministic).
 template <class HotMath>
-__global__ void __launch_bounds__(kFused)
+__global__ void __launch_bounds__(kFused, 8)
 k_chief_center(const DevSurface* __restrict__ lens, int K, TripTable trips,
                const float* __restrict__ po, const float* __restrict__ xc,
                const float* __restrict__ yc, int Sc, float pz, float zs,
@@ -436,29 +436,88 @@ k_chief_center(const DevSurface* __restrict__ lens, int K, TripTable trips,
 //   nsplit == 1 : the tile is complete in LDS -> normalise (flag) and store.
 //   nsplit  > 1 : tiles are added to the pre-zeroed output with global float
 //                 atomics; the caller normalises afterwards.
-template <bool HAVE_R, bool BIG, class HotMath>
-__global__ void __launch_bounds__(kFused)
+// Arguments of the optional in-kernel chief-ray pass (CENTER instantiations, nsplit == 1): the
+// workgroup first traces the Sc shrunk-pupil samples of its point through the GREEN lens table
+// (optics.py:900), reduces the centroid exactly like k_chief_center, and only then splats.
+struct CenterArgs {
+    const DevSurface* lens_c;
+    TripTable trips_c;
+    const float* xc;
+    const float* yc;
+    int Sc;
+    float* center_out;       // [N,2]
+    int32_t* any_valid;
+    uint32_t* conv_mask_c;
+};
+
+// __launch_bounds__(512, 8): four workgroups per CU = 8 waves per SIMD; without the hint the
+// CENTER instantiations use 101 SGPRs, which the hardware admits only 7 waves per SIMD for.
+template <bool HAVE_R, bool BIG, class HotMath, bool CENTER>
+__global__ void __launch_bounds__(kFused, 8)
 k_psf_lr(const DevSurface* __restrict__ lens, int K, TripTable trips,
          const float* __restrict__ po, const float* __restrict__ x2, const float* __restrict__ y2,
          int S, int nsplit, int chunk, float pz, float zs, SplatGeom gm, DevDpParams dp,
          const float* __restrict__ center, uint32_t flags, float* __restrict__ lout,
-         float* __restrict__ rout, uint32_t* __restrict__ conv_mask)
+         float* __restrict__ rout, uint32_t* __restrict__ conv_mask, CenterArgs ca)
 {
     extern __shared__ __attribute__((aligned(16))) float tiles[];   // [L | R] ks*ks each
     __shared__ uint32_t lds_mask[SDIRT_MAX_SURFACES];
     __shared__ float red[kFused / 64];
+    __shared__ float c_sh[2];
     const int tile = gm.ks * gm.ks;
     float* tl = tiles;
     float* trr = tiles + tile;
     const int n = blockIdx.x / nsplit;
     const int j = blockIdx.x - n * nsplit;
+    const float px = po[3 * n], py = po[3 * n + 1], pzo = po[3 * n + 2];
+
+    if (CENTER) {
+        // ---- chief-ray centre of this point (same arithmetic and reduction order as
+        // k_chief_center; the fp64 scratch aliases the not-yet-used tile memory)
+        double* redd = reinterpret_cast<double*>(tiles);             // [3][kFused]
+        if (threadIdx.x < SDIRT_MAX_SURFACES) lds_mask[threadIdx.x] = 0;
+        if (threadIdx.x == 0) c_sh[0] = 0.0f;
+        __syncthreads();
+        double sx = 0.0, sy = 0.0, sr = 0.0;
+        int any = 0;
+        for (int s = threadIdx.x; s < ca.Sc; s += blockDim.x) {
+            Ray r = make_ray<HotMath>(px, py, pzo, ca.xc[s], ca.yc[s], pz);
+            trace_ray<true, HotMath>(ca.lens_c, 0, K, ca.trips_c, r, ca.conv_mask_c ? lds_mask : nullptr);
+            propagate_to<HotMath>(r, zs);
+            sx += (double)(r.ox * r.ra);
+            sy += (double)(r.oy * r.ra);
+            sr += (double)r.ra;
+            any |= (r.ra == 1.0f);
+        }
+        redd[threadIdx.x] = sx; redd[kFused + threadIdx.x] = sy; redd[2 * kFused + threadIdx.x] = sr;
+        if (any) c_sh[0] = 1.0f;                                     // benign race: all write 1
+        __syncthreads();
+        for (int off = kFused / 2; off > 0; off >>= 1) {
+            if ((int)threadIdx.x < off) {
+                redd[threadIdx.x] += redd[threadIdx.x + off];
+                redd[kFused + threadIdx.x] += redd[kFused + threadIdx.x + off];
+                redd[2 * kFused + threadIdx.x] += redd[2 * kFused + threadIdx.x + off];
+            }
+            __syncthreads();
+        }
+        if (ca.conv_mask_c && (int)threadIdx.x < K && lds_mask[threadIdx.x])
+            atomicOr(&ca.conv_mask_c[threadIdx.x], lds_mask[threadIdx.x]);
+        const float any_f = c_sh[0];
+        const float den = (float)redd[2 * kFused] + (float)1e-9;
+        const float ccx = -((float)redd[0] / den), ccy = -((float)redd[kFused] / den);
+        __syncthreads();                                             // everyone has read redd / c_sh
+        if (threadIdx.x == 0) {
+            ca.center_out[2 * n] = ccx; ca.center_out[2 * n + 1] = ccy;
+            c_sh[0] = ccx; c_sh[1] = ccy;
+            if (ca.any_valid && any_f != 0.0f) atomicOr(ca.any_valid, 1);
+        }
+    }
 
     for (int i = threadIdx.x; i < (HAVE_R ? 2 : 1) * tile; i += blockDim.x) tiles[i] = 0.0f;
     if (threadIdx.x < SDIRT_MAX_SURFACES) lds_mask[threadIdx.x] = 0;
     __syncthreads();
 
-    const float px = po[3 * n], py = po[3 * n + 1], pzo = po[3 * n + 2];
-    const float cx = center[2 * n], cy = center[2 * n + 1];
+    const float cx = CENTER ? c_sh[0] : center[2 * n], cy = CENTER ? c_sh[1] : center[2 * n + 1];
     const int s_end = min(S, (j + 1) * chunk);
     auto splat = [&](float sx, float sy, float dx, float dz, float ra) {
         SplatTaps tp;
@@ -1010,19 +1069,26 @@ int sdirt_chief_center(const sdirt_lens* lens, const float* point_obj, int64_t N
     return SDIRT_OK;
 }
 
-int sdirt_psf_lr(const sdirt_lens* lens, const float* point_obj, int64_t N, const float* x2,
-                 const float* y2, int64_t S, double pupil_z, double d_sensor, double ps, int32_t ks,
-                 const float* center, const sdirt_dp_params* dp, const int32_t* trips,
-                 uint32_t flags, float* l_psf, float* r_psf, uint32_t* conv_mask, void* stream)
+// Shared launcher of sdirt_psf_lr / sdirt_psf_lr_centered.  `cen` != nullptr requests the
+// chief-ray pass: inside the same kernel when one workgroup owns a point (nsplit == 1), as a
+// preceding k_chief_center launch otherwise.
+struct CenterRequest {
+    const sdirt_lens* lens_c;
+    const float* xc;
+    const float* yc;
+    int64_t Sc;
+    TripTable trips_c;
+    float* center_out;
+    int32_t* any_valid;
+    uint32_t* conv_mask_c;
+};
+
+static int launch_psf(const sdirt_lens* lens, const float* point_obj, int64_t N, const float* x2,
+                      const float* y2, int64_t S, double pupil_z, double d_sensor, double ps,
+                      int32_t ks, const float* center, const CenterRequest* cen,
+                      const sdirt_dp_params* dp, const TripTable& tt, uint32_t flags, float* l_psf,
+                      float* r_psf, uint32_t* conv_mask, void* stream)
 {
-    if (!lens || !point_obj || !x2 || !y2 || !center || !l_psf || N < 0 || S < 0 ||
-        S > (1ll << 30) || N > (1ll << 30))
-        return fail(SDIRT_ERR_INVALID_ARGUMENT, "bad argument");
-    if (int rc = check_ks(ks)) return rc;
-    if (dp && !(dp->r > 0.0)) return fail(SDIRT_ERR_INVALID_ARGUMENT, "dp->r must be > 0");
-    TripTable tt;
-    if (int rc = make_trips(lens, trips, tt)) return rc;
-    if (N == 0) return SDIRT_OK;
     const bool have_r = r_psf != nullptr;
     const int tile = ks * ks;
     const size_t lds = sizeof(float) * tile * (have_r ? 2 : 1);
@@ -1043,6 +1109,22 @@ int sdirt_psf_lr(const sdirt_lens* lens, const float* point_obj, int64_t N, cons
     if (nsplit < 1) nsplit = 1;
 
     hipStream_t st = as_stream(stream);
+    const bool lean = (flags & SDIRT_PSF_STRICT_IEEE) == 0;
+    const bool fuse_center = cen != nullptr && nsplit == 1;
+    if (cen && !fuse_center) {                       // split spp axis: centre as its own launch
+        if (lean)
+            k_chief_center<Lean><<<(int)N, kFused, 0, st>>>(
+                cen->lens_c->dev, cen->lens_c->n_surfaces, cen->trips_c, point_obj, cen->xc, cen->yc,
+                (int)cen->Sc, (float)pupil_z, (float)d_sensor, cen->center_out, cen->any_valid,
+                cen->conv_mask_c);
+        else
+            k_chief_center<Ieee><<<(int)N, kFused, 0, st>>>(
+                cen->lens_c->dev, cen->lens_c->n_surfaces, cen->trips_c, point_obj, cen->xc, cen->yc,
+                (int)cen->Sc, (float)pupil_z, (float)d_sensor, cen->center_out, cen->any_valid,
+                cen->conv_mask_c);
+        LAUNCH_CHECK();
+        center = cen->center_out;
+    }
     if (nsplit > 1) {
         HIP_TRY(hipMemsetAsync(l_psf, 0, sizeof(float) * (size_t)N * tile, st));
         if (have_r) HIP_TRY(hipMemsetAsync(r_psf, 0, sizeof(float) * (size_t)N * tile, st));
@@ -1051,22 +1133,33 @@ int sdirt_psf_lr(const sdirt_lens* lens, const float* point_obj, int64_t N, cons
     const DevDpParams dpp = make_dp(dp);
     const int grid = (int)(N * nsplit);
     const bool both = have_r && dpp.have_r;
-    const size_t lds_bytes = both ? lds : sizeof(float) * tile;
-    const bool lean = (flags & SDIRT_PSF_STRICT_IEEE) == 0;
-#define SDIRT_LAUNCH_PSF(HR, BG, MM)                                                              \
+    size_t lds_bytes = both ? lds : sizeof(float) * tile;
+    CenterArgs ca;
+    std::memset(&ca, 0, sizeof(ca));
+    if (fuse_center) {
+        ca.lens_c = cen->lens_c->dev; ca.trips_c = cen->trips_c; ca.xc = cen->xc; ca.yc = cen->yc;
+        ca.Sc = (int)cen->Sc; ca.center_out = cen->center_out; ca.any_valid = cen->any_valid;
+        ca.conv_mask_c = cen->conv_mask_c;
+        lds_bytes = std::max(lds_bytes, sizeof(double) * 3 * kFused);   // fp64 reduction scratch
+    }
+#define SDIRT_LAUNCH_PSF(HR, BG, MM, CT)                                                          \
     do {                                                                                          \
         if (lds_bytes > 48 * 1024) /* large tiles: opt in to the full 160 KiB of LDS */           \
-            HIP_TRY(hipFuncSetAttribute((const void*)k_psf_lr<HR, BG, MM>,                        \
+            HIP_TRY(hipFuncSetAttribute((const void*)k_psf_lr<HR, BG, MM, CT>,                    \
                                         hipFuncAttributeMaxDynamicSharedMemorySize,               \
                                         160 * 1024 - 1024));                                      \
-        k_psf_lr<HR, BG, MM><<<grid, kFused, lds_bytes, st>>>(                                    \
+        k_psf_lr<HR, BG, MM, CT><<<grid, kFused, lds_bytes, st>>>(                                \
             lens->dev, lens->n_surfaces, tt, point_obj, x2, y2, (int)S, nsplit, chunk,            \
             (float)pupil_z, (float)d_sensor, gm, dpp, center, flags, l_psf,                       \
-            both ? r_psf : nullptr, conv_mask);                                                   \
+            both ? r_psf : nullptr, conv_mask, ca);                                               \
+    } while (0)
+#define SDIRT_LAUNCH_PSF_C(HR, BG, MM)                                                            \
+    do {                                                                                          \
+        if (fuse_center) SDIRT_LAUNCH_PSF(HR, BG, MM, true); else SDIRT_LAUNCH_PSF(HR, BG, MM, false); \
     } while (0)
 #define SDIRT_LAUNCH_PSF_M(HR, BG)                                                                \
     do {                                                                                          \
-        if (lean) SDIRT_LAUNCH_PSF(HR, BG, Lean); else SDIRT_LAUNCH_PSF(HR, BG, Ieee);            \
+        if (lean) SDIRT_LAUNCH_PSF_C(HR, BG, Lean); else SDIRT_LAUNCH_PSF_C(HR, BG, Ieee);        \
     } while (0)
     if (both) {
         if (dpp.big) SDIRT_LAUNCH_PSF_M(true, true); else SDIRT_LAUNCH_PSF_M(true, false);
@@ -1076,6 +1169,7 @@ int sdirt_psf_lr(const sdirt_lens* lens, const float* point_obj, int64_t N, cons
         if (have_r) HIP_TRY(hipMemsetAsync(r_psf, 0, sizeof(float) * (size_t)N * tile, st));
     }
 #undef SDIRT_LAUNCH_PSF_M
+#undef SDIRT_LAUNCH_PSF_C
 #undef SDIRT_LAUNCH_PSF
     LAUNCH_CHECK();
     if (nsplit > 1 && (flags & SDIRT_PSF_NORMALIZE)) {
@@ -1084,6 +1178,49 @@ int sdirt_psf_lr(const sdirt_lens* lens, const float* point_obj, int64_t N, cons
         LAUNCH_CHECK();
     }
     return SDIRT_OK;
+}
+
+int sdirt_psf_lr(const sdirt_lens* lens, const float* point_obj, int64_t N, const float* x2,
+                 const float* y2, int64_t S, double pupil_z, double d_sensor, double ps, int32_t ks,
+                 const float* center, const sdirt_dp_params* dp, const int32_t* trips,
+                 uint32_t flags, float* l_psf, float* r_psf, uint32_t* conv_mask, void* stream)
+{
+    if (!lens || !point_obj || !x2 || !y2 || !center || !l_psf || N < 0 || S < 0 ||
+        S > (1ll << 30) || N > (1ll << 30))
+        return fail(SDIRT_ERR_INVALID_ARGUMENT, "bad argument");
+    if (int rc = check_ks(ks)) return rc;
+    if (dp && !(dp->r > 0.0)) return fail(SDIRT_ERR_INVALID_ARGUMENT, "dp->r must be > 0");
+    TripTable tt;
+    if (int rc = make_trips(lens, trips, tt)) return rc;
+    if (N == 0) return SDIRT_OK;
+    return launch_psf(lens, point_obj, N, x2, y2, S, pupil_z, d_sensor, ps, ks, center, nullptr, dp,
+                      tt, flags, l_psf, r_psf, conv_mask, stream);
+}
+
+int sdirt_psf_lr_centered(const sdirt_lens* lens, const sdirt_lens* lens_center,
+                          const float* point_obj, int64_t N, const float* x2, const float* y2,
+                          int64_t S, const float* xc, const float* yc, int64_t Sc, double pupil_z,
+                          double d_sensor, double ps, int32_t ks, const sdirt_dp_params* dp,
+                          const int32_t* trips, const int32_t* trips_center, uint32_t flags,
+                          float* center, int32_t* any_valid, float* l_psf, float* r_psf,
+                          uint32_t* conv_mask, uint32_t* conv_mask_center, void* stream)
+{
+    if (!lens || !lens_center || !point_obj || !x2 || !y2 || !xc || !yc || !center || !l_psf ||
+        N < 0 || S < 0 || Sc < 0 || S > (1ll << 30) || Sc > (1ll << 30) || N > (1ll << 30))
+        return fail(SDIRT_ERR_INVALID_ARGUMENT, "bad argument");
+    if (lens_center->n_surfaces != lens->n_surfaces)
+        return fail(SDIRT_ERR_INVALID_ARGUMENT, "lens and lens_center differ in surface count");
+    if (int rc = check_ks(ks)) return rc;
+    if (dp && !(dp->r > 0.0)) return fail(SDIRT_ERR_INVALID_ARGUMENT, "dp->r must be > 0");
+    TripTable tt;
+    CenterRequest cr;
+    if (int rc = make_trips(lens, trips, tt)) return rc;
+    if (int rc = make_trips(lens_center, trips_center, cr.trips_c)) return rc;
+    if (N == 0) return SDIRT_OK;
+    cr.lens_c = lens_center; cr.xc = xc; cr.yc = yc; cr.Sc = Sc; cr.center_out = center;
+    cr.any_valid = any_valid; cr.conv_mask_c = conv_mask_center;
+    return launch_psf(lens, point_obj, N, x2, y2, S, pupil_z, d_sensor, ps, ks, nullptr, &cr, dp, tt,
+                      flags, l_psf, r_psf, conv_mask, stream);
 }
 
 int sdirt_selftest_math(int32_t mode, uint64_t first, uint64_t count, int32_t exp_span,

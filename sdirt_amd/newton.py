@@ -100,3 +100,22 @@ class TripPlanner:
             self.relaunches += 1
             trips = new
         raise RuntimeError("Newton trip-table speculation did not converge")  # pragma: no cover
+
+    def run_many(self, keys, curved, order, launch, max_rounds=None):
+        """Several independent passes verified in ONE launch/readback round (the chief-ray pass
+        and the primary pass of a psf call).  launch(list_of_trip_tables) -> list of mask
+        arrays, one per key.  All passes are re-launched together when any table was wrong."""
+        K = len(curved)
+        tables = [self.initial(k, curved) for k in keys]
+        rounds = max_rounds if max_rounds is not None else 2 * K + 2
+        for _ in range(rounds):
+            masks = launch(tables)
+            self.launches += 1
+            results = [verify(t, m, order, curved) for t, m in zip(tables, masks)]
+            if all(ok for ok, _ in results):
+                for k, t in zip(keys, tables):
+                    self.cache[k] = t.copy()
+                return tables
+            self.relaunches += 1
+            tables = [t if ok else new for t, (ok, new) in zip(tables, results)]
+        raise RuntimeError("Newton trip-table speculation did not converge")  # pragma: no cover

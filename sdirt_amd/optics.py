@@ -483,6 +483,7 @@ class Lensgroup:
                       for v in pupil_xy]
             spp = x2.shape[0]
         cen = torch.empty((N, 2), dtype=torch.float32, device=self.device)
+        xc = yc = None
         if center:
             _, pupilr_c = self.entrance_pupil(shrink_pupil=True)
             if center_pupil_xy is None:
@@ -490,7 +491,6 @@ class Lensgroup:
             else:
                 xc, yc = [torch.as_tensor(v).to(self.device, torch.float32).contiguous()
                           for v in center_pupil_xy]
-            self._chief_center(po, xc, yc, pupilz, cen)
         else:
             pts = points.to(self.device, torch.float32)
             cen[:, 0] = pts[:, 0] * (self.sensor_size[1] / 2)      # optics.py:973-975
@@ -506,18 +506,54 @@ class Lensgroup:
             L = torch.empty((N, ks, ks), dtype=torch.float32, device=self.device)
             R = torch.empty_like(L) if need_r else None
         dpp = None if (dp is None or _default_r_zero) else _lib.DpParams(*[float(v) for v in dp])
+        dp_ref = C.byref(dpp) if dpp is not None else None
         handle = self.dev_lens(wvln)
         flags = (_lib.PSF_NORMALIZE if normalize else 0) | self._math_flags()
-
-        def enqueue(trips, mask_ptr):
-            with self._timed("psf_lr"):
-                _lib.check(_lib.lib().sdirt_psf_lr(
-                    handle, dptr(po), N, dptr(x2), dptr(y2), spp, float(pupilz),
-                    float(self.d_sensor), float(self.pixel_size), ks, dptr(cen),
-                    C.byref(dpp) if dpp is not None else None, trips, flags, dptr(L), dptr(R),
-                    mask_ptr, stream_ptr(self.device)))
         wkey = round(float(wvln if wvln < 10 else wvln * 1e-3), 6)
-        self._run_with_trips(("psf", wkey, self.precision), range(len(self.surfaces)), enqueue)
+        K = len(self.surfaces)
+        if center:
+            # chief-ray pass (always through the green lens, optics.py:900) and primary pass in
+            # one C call -- one kernel launch when a workgroup owns a point -- and ONE
+            # verification round for both trip tables
+            handle_c = self.dev_lens(DEFAULT_WAVE)
+            anyv = torch.zeros(1, dtype=torch.int32, device=self.device)
+            masks = torch.zeros((2, _lib.MAX_SURFACES), dtype=torch.int32, device=self.device)
+            reference = self.trip_policy == "reference"
+
+            def enqueue2(tp, tc):
+                with self._timed("psf_lr_centered"):
+                    _lib.check(_lib.lib().sdirt_psf_lr_centered(
+                        handle, handle_c, dptr(po), N, dptr(x2), dptr(y2), spp, dptr(xc), dptr(yc),
+                        xc.shape[0], float(pupilz), float(self.d_sensor), float(self.pixel_size), ks,
+                        dp_ref, (C.c_int32 * K)(*[int(t) for t in tp]),
+                        (C.c_int32 * K)(*[int(t) for t in tc]), flags, dptr(cen), dptr(anyv),
+                        dptr(L), dptr(R), dptr(masks[0]) if reference else None,
+                        dptr(masks[1]) if reference else None, stream_ptr(self.device)))
+
+            if reference:
+                def launch(tables):
+                    masks.zero_()
+                    anyv.zero_()
+                    enqueue2(tables[0], tables[1])
+                    m = masks[:, :K]
+                    if self.mask_reduce is not None:
+                        m = self.mask_reduce(m.reshape(-1)).reshape(2, K)
+                    m = m.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+                    return [m[0], m[1]]
+                self.trips.run_many([("psf", wkey, self.precision), ("center", self.precision)],
+                                    self._curved(), list(range(K)), launch)
+                assert int(anyv.item()) == 1, "No sampled rays is valid."   # optics.py:902
+            else:
+                full = np.where(self._curved(), NEWTON_MAXITER, 0)
+                enqueue2(full, full)
+        else:
+            def enqueue(trips, mask_ptr):
+                with self._timed("psf_lr"):
+                    _lib.check(_lib.lib().sdirt_psf_lr(
+                        handle, dptr(po), N, dptr(x2), dptr(y2), spp, float(pupilz),
+                        float(self.d_sensor), float(self.pixel_size), ks, dptr(cen), dp_ref, trips,
+                        flags, dptr(L), dptr(R), mask_ptr, stream_ptr(self.device)))
+            self._run_with_trips(("psf", wkey, self.precision), range(K), enqueue)
         if R is None and want_r:
             R = torch.zeros_like(L)
         if single_point:
