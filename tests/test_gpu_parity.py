@@ -239,11 +239,15 @@ def test_rgb(oracle):
     assert np.abs(psf.cpu().numpy() - g["psf"]).max() <= 5e-4
 
 
-@pytest.mark.parametrize("lens_name,n,spp,ks", [("rf50mm", 192, 4096, 65), ("rf35mm", 96, 2048, 33)])
+@pytest.mark.parametrize("lens_name,n,spp,ks", [("rf50mm", 192, 4096, 65), ("rf35mm", 96, 2048, 33),
+                                                ("rf50mm", 1100, 1024, 21)])
 def test_random_points_fused_vs_oracle(oracle, lens_name, n, spp, ks):
     """Random points over the whole field and depth range, BASELINE config-2 sampling density:
     the fused HIP kernels (own disc mapping, own centres, speculate+verify trips) against the
-    CPU oracle running the reference's global-trip-count rule on the same batch."""
+    CPU oracle running the reference's global-trip-count rule on the same batch.  The first two
+    cases split the spp axis over several workgroups per point (centre kernel + psf kernel +
+    normalise kernel); the 1100-point case takes the single-launch route where one workgroup
+    does the chief-ray pass and the primary pass of its point."""
     st = load_state(lens_name)
     lens = make_lens(lens_name, DEV, st)
     g = torch.Generator().manual_seed(77)
