@@ -154,6 +154,24 @@ def test_edge_cases(lens):
     assert L.shape == (1, 21, 21) and float(L.max()) > 0.99
 
 
+def test_single_launch_route_small_tiles_left_only(lens):
+    """N >= 1024 -> one workgroup per point does the chief-ray pass and the primary pass; with
+    the default param_list=None only the L tile exists (smaller than the fp64 reduction
+    scratch that aliases it).  Must equal the L of the two-sided call."""
+    g = torch.Generator().manual_seed(31)
+    pts = torch.stack([(torch.rand(1100, generator=g) - 0.5) * 1.8,
+                       (torch.rand(1100, generator=g) - 0.5) * 1.8,
+                       -(300 + torch.rand(1100, generator=g) * 9000)], -1)
+    torch.manual_seed(12)
+    a = lens.psf(pts, ks=9, spp=512)
+    torch.manual_seed(12)
+    b, _ = lens.psf_lr(pts, ks=9, spp=512, dp=DP)
+    assert a.shape == (1100, 9, 9) and torch.allclose(a, b, atol=3e-6)
+    torch.manual_seed(12)
+    c = lens.psf(pts[:7], ks=9, spp=512)                 # split-spp route, same points
+    assert torch.allclose(a[:7], c, atol=1e-4)           # other batch -> other global trip table
+
+
 def test_caller_owned_output_buffers(lens):
     pts = torch.tensor([[0.1, 0.2, -900.0], [-0.4, 0.3, -6000.0]])
     L = torch.full((2, 17, 17), -1.0, device=DEV)
