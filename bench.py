@@ -181,33 +181,36 @@ def main():
         comm_stream = torch.cuda.Stream(device)
         gather_buf = [tuple(torch.empty((n_total, KS, KS), dtype=torch.float32, device=device)
                             for _ in range(2)) for _ in range(2)]          # (L_all, R_all) x 2
-        in_flight = []          # (event, tensors kept alive until their gather has finished)
     step_no = [0]
     # output buffers are owned by the caller and re-used (two sets: the previous step's PSFs
     # may still be feeding the all-gather / the consumer while the next step renders)
     out_bufs = [tuple(torch.empty((n_local, KS, KS), dtype=torch.float32, device=device)
                       for _ in range(2)) for _ in range(2)]
 
+    gather_done = [None, None]      # per buffer set: event of the last gather that read it
+
     def step():
-        out = out_bufs[step_no[0] % 2]
+        idx = step_no[0] % 2
+        out = out_bufs[idx]
         if world == 1:
             step_no[0] += 1
             return lens.psf_lr(points_local, ks=KS, spp=SPP, dp=DP, out=out)
+        if gather_done[idx] is not None:
+            # the gather of two steps ago still reads these tensors on the comm stream
+            torch.cuda.current_stream(device).wait_event(gather_done[idx])
         pupil = sd.broadcast_pupil_points(lens, SPP)
         L, R = sharded.render(points_local, pupil, out)
         if not args.no_gather:
             ready = torch.cuda.Event()
             ready.record(torch.cuda.current_stream(device))
-            buf = gather_buf[step_no[0] % 2]
+            buf = gather_buf[idx]
             with torch.cuda.stream(comm_stream):
                 comm_stream.wait_event(ready)
                 sd.all_gather_shards(L, n_total, world, out=buf[0])     # no staging copy:
                 sd.all_gather_shards(R, n_total, world, out=buf[1])     # shards go straight out
                 done = torch.cuda.Event()
                 done.record(comm_stream)
-            in_flight.append((done, L, R))
-            while len(in_flight) > 2:            # buffer reuse: wait for the gather two steps back
-                in_flight.pop(0)[0].synchronize()
+            gather_done[idx] = done
         step_no[0] += 1
         return L, R
 
