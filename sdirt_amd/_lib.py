@@ -81,6 +81,15 @@ def lib():
     """The loaded library, with argtypes set.  Raises SdirtError if not built."""
     global _lib
     if _lib is None:
+        if not os.path.exists(LIB_PATH) and not os.environ.get("SDIRT_AMD_LIB"):
+            # not built yet: try once with the in-tree Makefile (hipcc cross-compiles without a
+            # GPU); anything else is a hard error -- there is no CPU implementation to fall back to
+            import subprocess
+            try:
+                subprocess.check_call(["make", "-C", os.path.join(HERE, "csrc")],
+                                      stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            except (OSError, subprocess.CalledProcessError):
+                pass
         if not os.path.exists(LIB_PATH):
             raise SdirtError(
                 f"{LIB_PATH} is missing: build it with `make -C sdirt_amd/csrc` "
