@@ -1,14 +1,27 @@
-"""The PSF-producing half of the reference's PSFNet (deeplens/psfnet.py): the
-lens state it sets up and the training / test data generators that call the
-ray-traced PSF.  The MLP itself, its optimiser loop, checkpoints and the image
-renderer built on it are consumers of this path (stock PyTorch) and are not
-re-implemented here; `get_training_data` hands them batches straight from the
-HIP kernels, already on the GPU.
+"""PSFNet (deeplens/psfnet.py): the lens + the network that represents its PSF field.
+
+The lens half sets up the state the ray-traced PSF path needs and generates
+training / test batches straight from the HIP kernels (already on the GPU).  The
+network half -- init / load, the fitting loop, `pred` with the mirror trick for
+the right sub-pixel, and `render` (depth map -> per-pixel L/R kernels -> the
+per-pixel convolution kernel of render_psf.py) -- keeps the reference's
+signatures; the MLP layers are stock torch.nn GEMMs.
+
+Not rebuilt (comparison baselines outside the path, psfnet.py:381-527, 768-868):
+pred_DPDNet / pred_Modeling / pred_Learn2reduce (need deeplens/related_psf),
+ThinLens, the matplotlib visualisers, and the map-network variant
+(get_training_psf_map / calc_psf_map, which the reference itself cannot run: wrong
+kwarg at psfnet.py:307).
 """
+import logging
+import os
+
 import numpy as np
 import torch
 
 from .optics import Lensgroup
+from .psfnet_arch import MLP, MLPConv, initialize_weights
+from .render_psf import local_psf_render_fast
 
 DMIN = 200      # [mm]  psfnet.py:15
 DMAX = 20000    # [mm]  psfnet.py:16
@@ -17,13 +30,18 @@ _PSFNET_SENSOR_Z = {"rf35mm": 80.447, "rf50mm": 62.25}          # psfnet.py:42-4
 
 
 class PSFNet(Lensgroup):
-    """psfnet.py:18-57 without the network: Lensgroup + kernel size + depth range."""
+    """psfnet.py:18-57: Lensgroup + kernel size + depth range + the PSF network."""
 
     def __init__(self, filename, model_name="mlp", kernel_size=11, sensor_res=(512, 512),
-                 device="cuda"):
-        super().__init__(filename=filename, sensor_res=sensor_res, device=device)
+                 device="cuda", **lens_kwargs):
+        super().__init__(filename=filename, sensor_res=sensor_res, device=device, **lens_kwargs)
+        self.in_features = 4
         self.kernel_size = kernel_size
         self.model_name = model_name
+        self.init_net()
+        self.spp = 4096
+        self.patch_size = 64
+        self.psf_grid = [sensor_res[0] // self.patch_size, sensor_res[1] // self.patch_size]
         self.d_max = -DMAX
         self.d_min = -DMIN
         for key, z in _PSFNET_SENSOR_Z.items():
@@ -71,3 +89,189 @@ class PSFNet(Lensgroup):
         inp = torch.stack((x, y, z), dim=-1)
         points = torch.stack((x, y, self.z2depth(z)), dim=-1)
         return inp, self.psf(points=points, ks=self.kernel_size, spp=spp)
+
+    # ------------------------------------------------------------------ network
+    def init_net(self):
+        """psfnet.py:63-90.  Input (x, y, z) in [-1,1]^2 x [0,1] -> ks x ks kernel."""
+        ks = self.kernel_size
+        if self.model_name == "mlp":
+            self.psfnet = MLP(in_features=3, out_features=ks ** 2, hidden_features=512,
+                              hidden_layers=8)
+        elif self.model_name == "mlpconv":
+            self.psfnet = MLPConv(in_features=3, ks=ks, channels=1)
+        elif self.model_name == "siren":
+            raise NotImplementedError
+        else:
+            # 'mlp+lum' cannot be constructed in the reference either (psfnet_arch.py:63)
+            raise Exception("Unsupported PSF network architecture.")
+        self.psfnet.apply(initialize_weights)
+        self.psfnet.to(self.device)
+
+    def load_net(self, net_path):
+        """psfnet.py:92-99: copy every tensor of the checkpoint whose shape matches."""
+        own = self.psfnet.state_dict()
+        ckpt = torch.load(net_path, map_location=self.device)
+        own.update({k: v for k, v in ckpt.items() if k in own and own[k].shape == v.shape})
+        self.psfnet.load_state_dict(own)
+
+    def train_psfnet(self, iters=10000, bs=128, lr=1e-4, spp=2048, evaluate_every=1000,
+                     result_dir="./results/temp"):
+        """psfnet.py:101-168: fit the network to PSFs ray-traced on the fly.  AdamW, cosine
+        schedule over iters//3, MSE on max-normalised kernels, fp16 autocast + loss scaling on
+        the GPU.  Every `evaluate_every` steps: checkpoint + L1/L2 of sum-normalised kernels
+        on the 1024-point test set (logged; the reference also writes a matplotlib figure).
+        Returns the list of per-step training losses."""
+        psfnet = self.psfnet
+        psfnet.train()
+        on_gpu = torch.device(self.device).type == "cuda"
+        l2, l1 = torch.nn.MSELoss(reduction="mean"), torch.nn.L1Loss(reduction="mean")
+        optim = torch.optim.AdamW(psfnet.parameters(), lr)
+        sche = torch.optim.lr_scheduler.CosineAnnealingLR(optim, T_max=int(iters) // 3, eta_min=0)
+        scaler = torch.amp.GradScaler("cuda", enabled=on_gpu)
+        amp = lambda: torch.autocast("cuda", dtype=torch.float16, enabled=on_gpu)  # noqa: E731
+        losses = []
+        for i in range(iters + 1):
+            with amp():
+                inp, psf = self.get_training_data(bs=bs, spp=spp)
+                inp, psf = inp.to(self.device), psf.to(self.device)
+                loss = l2(psfnet(inp), psf)
+                optim.zero_grad()
+            scaler.scale(loss).backward()
+            scaler.step(optim)
+            scaler.update()
+            sche.step()
+            losses.append(loss.detach())
+            if (i + 1) % evaluate_every == 0:
+                with torch.no_grad(), amp():
+                    psfnet.eval()
+                    torch.save(psfnet.state_dict(),
+                               os.path.join(result_dir, f"iter{i + 1}_PSFNet_{self.model_name}.pkl"))
+                    inp, psf = self.get_test_data()
+                    inp, psf = inp.to(self.device), psf.to(self.device)
+                    pred = psfnet(inp)
+                    psf = psf / psf.sum((-1, -2), keepdim=True)
+                    pred = pred / pred.sum((-1, -2), keepdim=True)
+                    logging.info(f"{i}, {l1(pred, psf).item()}, {l2(pred, psf).item()}")
+                    psfnet.train()
+        torch.save(psfnet.state_dict(), os.path.join(result_dir, f"PSFNet_{self.model_name}.pkl"))
+        return [float(v) for v in losses]
+
+    def pred(self, inp):
+        """psfnet.py:317-336: network kernels for the left sub-pixel at (x, y, z) and, by the
+        sensor's mirror symmetry, for the right one as fliplr of the kernel at (-x, y, z);
+        each (L, R) pair is normalised by its joint sum.  inp [..., 3] -> [..., 2, ks, ks].
+        As in the reference, `inp[..., 0]` is negated in place."""
+        mirrored = inp.clone()
+        mirrored[..., 0] = mirrored[..., 0] * (-1)
+        both = self.psfnet(torch.stack((inp, mirrored)))          # one GEMM chain for L and R
+        inp[..., 0] = mirrored[..., 0]
+        psf = torch.stack((both[0], torch.flip(both[1], dims=[-1])), dim=-3)
+        psf = psf / (psf.sum(-1).sum(-1).unsqueeze(-1).unsqueeze(-1) + 1e-9)
+        assert psf.shape[-1] == self.kernel_size
+        return psf
+
+    def pred_coc(self, inp, is_z=True):
+        """psfnet.py:338-379: thin-lens baseline -- Gaussian of the circle of confusion clipped
+        to its radius, halved left/right of the kernel centre according to the side of focus.
+        inp [B,W,H,3] (z or depth last) -> [B,W,H,2,ks,ks]."""
+        ks, dev = self.kernel_size, inp.device
+        ax = torch.linspace(-ks / 2 + 1 / 2, ks / 2 - 1 / 2, ks, device=dev)
+        gx, gy = torch.meshgrid(ax, ax, indexing="xy")
+        z = inp[..., -1]
+        foc_dist = torch.tensor(self.foc_d).to(dev)
+        ps = self.sensor_size[0] / self.sensor_res[0]
+        depth = z * (self.d_max - self.d_min) + self.d_min if is_z else z
+        coc = torch.abs(depth - foc_dist) * self.foclen ** 2 / (-depth * self.fnum * (-foc_dist - self.foclen))
+        radius = (torch.clamp(coc / ps, min=0.1) / 2).unsqueeze(-1).unsqueeze(-1)
+        rr = gx ** 2 + gy ** 2
+        thin = torch.exp(-rr / (2 * radius ** 2)) * (rr < radius ** 2)
+        keep_right = torch.ones(ks, ks, device=dev)
+        keep_right[..., 0:ks // 2] = 0                            # the reference's `l_mask`
+        keep_left = torch.ones(ks, ks, device=dev)
+        keep_left[..., ks // 2 + 1:] = 0                          # the reference's `r_mask`
+        near = (depth > foc_dist).unsqueeze(-1).unsqueeze(-1)
+        far = (depth < foc_dist).unsqueeze(-1).unsqueeze(-1)
+        one = torch.ones_like(thin)
+        psf_l = thin * torch.where(near, keep_right, one) * torch.where(far, keep_left, one)
+        psf_r = thin * torch.where(near, keep_left, one) * torch.where(far, keep_right, one)
+        psf = torch.stack((psf_l, psf_r), dim=-3)
+        return psf / (psf.sum(-1).sum(-1).unsqueeze(-1).unsqueeze(-1) + 1e-6)
+
+    # ------------------------------------------------------------------ tone curves
+    _TONE_LO = (0.89129432, 0.27217316, -0.00246187)              # psfnet.py:591
+    _TONE_HI = (5.94018909e-01, 1.20060450e+01, -5.24983855e-03)  # psfnet.py:592
+
+    def fit_degamma(self, x):
+        """psfnet.py:589-598: 8-bit code value -> luminance, blend of two rational fits."""
+        (a1, b1, c1), (a2, b2, c2) = self._TONE_LO, self._TONE_HI
+        lo = 1 / (1 / (a1 * x + b1) + c1)
+        hi = 1 / (1 / (a2 * x + b2) + c2)
+        t = torch.clamp(x / 100, max=1)
+        return hi * t + lo * (1 - t)
+
+    def degamma(self, img_gamma):
+        return self.fit_degamma(img_gamma * 255.)
+
+    def fit_gamma(self, l):
+        """psfnet.py:605-615: inverse of fit_degamma."""
+        (a1, b1, c1), (a2, b2, c2) = self._TONE_LO, self._TONE_HI
+        x1 = (1 / (1 / (l + 1e-9) - c1) - b1) / a1
+        x2 = (1 / (1 / (l + 1e-9) - c2) - b2) / a2
+        t = torch.clamp((x1 + x2) / 2 / 100, max=1)
+        return x2 * t + x1 * (1 - t)
+
+    def gamma(self, img_degamma):
+        return self.fit_gamma(img_degamma) / 255.
+
+    def noise(self, render, shape):
+        """psfnet.py:627-640: Gaussian noise with a left/right ramp (training augmentation)."""
+        N, C, H, W = shape
+        noise_map = torch.randn_like(render) * (0.05 * np.random.rand())
+        lo, hi = np.random.rand() / 2, np.random.rand() / 2 + 0.5
+        ramp = torch.linspace(lo, hi, W).repeat(N, C, H, 1)
+        weight = torch.cat([ramp, torch.flip(ramp, [-1])], dim=1).to(render.device)
+        render += noise_map * weight
+        return render
+
+    @torch.no_grad()
+    def render(self, img, depth, foc_dist, train=False):
+        """psfnet.py:642-714, batched branch: all-in-focus img [N,C,H,W] + depth [N,1,H,W] (mm,
+        negative) + foc_dist [N] -> dual-pixel capture [N,2C,H,W] (left views, then right).
+        Per pixel: network L/R kernels at (x, y, z(depth)), convolution in linear light."""
+        if img.dim() != 4:
+            # psfnet.py:659-675 feeds a 4-vector (x, y, z, foc_z) to the 3-input network and
+            # fails there; only the batched branch is usable in the reference
+            raise ValueError("render expects img [N,C,H,W], depth [N,1,H,W], foc_dist [N]")
+        depth = depth + self.d_sensor
+        N, C, H, W = img.shape
+        z = self.depth2z(depth).squeeze(1)
+        x, y = torch.meshgrid(torch.linspace(-1, 1, W), torch.linspace(1, -1, H), indexing="xy")
+        x = x.unsqueeze(0).repeat(N, 1, 1).to(img.device)
+        y = y.unsqueeze(0).repeat(N, 1, 1).to(img.device)
+        o = torch.stack((x, y, z), -1).float()
+        psf = self.pred(o)
+        render_lr = local_psf_render_fast(self.degamma(img), psf, self.kernel_size)
+        render = self.gamma(torch.cat(render_lr, dim=1))
+        if train:
+            render = self.noise(render, img.shape)
+        return torch.clip(render, 0.0, 1.0)
+
+    # ------------------------------------------------------------------ checks the reference ships
+    def compare_psf(self, spp=None):
+        """psfnet.py:529-568 without the figures: ray-traced vs predicted (L, R) kernels at three
+        field points and two depths -> {depth: (traced [3,2,ks,ks], predicted [3,2,ks,ks])}."""
+        from .basics import GEO_SPP
+        spp = spp or GEO_SPP * 100
+        x = torch.tensor([0, 0.4, 0.8])
+        out = {}
+        for d_ori in (-500.0, -20000.0):
+            depth = d_ori + self.d_sensor
+            pts = torch.stack((x, x, torch.full_like(x, depth)), dim=-1)
+            psfl = self.psf(points=pts, ks=self.kernel_size, center=True, spp=spp)
+            pts[..., 0] = pts[..., 0] * (-1)
+            psfr = torch.flip(self.psf(points=pts, ks=self.kernel_size, center=True, spp=spp),
+                              dims=[-1])
+            z = self.depth2z(torch.tensor(depth))
+            inp = torch.stack((x, x, torch.full_like(x, z)), dim=-1).to(self.device)
+            out[int(d_ori)] = (torch.stack((psfl, psfr), dim=1), self.pred(inp).detach())
+        return out

@@ -113,3 +113,58 @@ def test_psfnet_data_generators():
     inp2, psf2 = lens.get_test_data(bs=1024, spp=256)
     assert inp2.shape == (1024, 3) and psf2.shape == (1024, 21, 21)
     assert float(lens.z2depth(torch.tensor(0.0))) == -200 and float(lens.z2depth(torch.tensor(1.0))) == -20000
+
+
+def _psfnet_with_fixture_net(fx, prefix="w/"):
+    from test_psfnet_cpu import make_psfnet, small_net
+    m = make_psfnet(int(fx["ks"]), device=DEV)
+    m.psfnet = small_net(fx, prefix).to(DEV)
+    return m
+
+
+def test_psfnet_pred_and_render_against_reference():
+    """psfnet.py:317-336 and 642-714 on the f9 fixture (small seeded MLP, 8x12 image, ks 7).
+    The reference values are its CPU fp32 results; on the GPU the network runs under fp16
+    autocast as the reference does on CUDA (psfnet_arch.py:46), hence fp16 tolerances."""
+    fx = load_golden("f9_psfnet_forward")
+    m = _psfnet_with_fixture_net(fx)
+    inp = t(fx["pred_inp"].copy())
+    with torch.no_grad():
+        psf = m.pred(inp)
+    assert psf.shape == fx["pred"].shape
+    assert torch.equal(inp[..., 0].cpu(), torch.from_numpy(-fx["pred_inp"][..., 0]))
+    assert np.abs(psf.float().cpu().numpy() - fx["pred"]).max() < 2e-3 * fx["pred"].max()
+    out = m.render(t(fx["img"]), t(fx["depth"]), t(fx["foc_dist"]))
+    assert out.shape == fx["render"].shape and out.dtype == torch.float32
+    # fp16 kernels and fp16 products in linear light, then the gamma curve (slope <= ~4 here)
+    assert np.abs(out.cpu().numpy() - fx["render"]).max() < 4e-3
+    assert np.abs(out.cpu().numpy() - fx["render"]).mean() < 5e-4
+    # fp32 network (autocast off) narrows the gap to the convolution's own fp16 rounding
+    with torch.autocast("cuda", enabled=False):
+        m.psfnet.forward = lambda x: m.psfnet.net(x).reshape(*x.shape[:-1], m.psfnet.ks, m.psfnet.ks)
+        out32 = m.render(t(fx["img"]), t(fx["depth"]), t(fx["foc_dist"]))
+    assert np.abs(out32.cpu().numpy() - fx["render"]).max() < 3e-3
+
+
+def test_psfnet_fits_ray_traced_psfs_on_the_gpu(tmp_path):
+    """train_psfnet (psfnet.py:101-168) end to end: batches come from the HIP PSF kernels,
+    the loss of a small network drops, the checkpoint round-trips through load_net."""
+    from sdirt_amd.psfnet import PSFNet
+    from sdirt_amd.psfnet_arch import MLP, initialize_weights
+    torch.manual_seed(0); np.random.seed(0)
+    m = PSFNet(os.path.join(DATA, "rf50mm.json"), sensor_res=(512, 768), kernel_size=11, device=DEV)
+    m.refocus(-1000 + m.d_sensor)
+    m.psfnet = MLP(3, 121, hidden_features=128, hidden_layers=2).to(DEV)
+    m.psfnet.apply(initialize_weights)
+    losses = m.train_psfnet(iters=150, bs=64, lr=2e-3, spp=1024, evaluate_every=10 ** 6,
+                            result_dir=str(tmp_path))
+    assert len(losses) == 151 and np.isfinite(losses).all()
+    assert np.mean(losses[-20:]) < 0.7 * np.mean(losses[:5])
+    w = {k: v.clone() for k, v in m.psfnet.state_dict().items()}
+    m.psfnet.apply(initialize_weights)
+    m.load_net(str(tmp_path / "PSFNet_mlp.pkl"))
+    assert all(torch.equal(w[k], v) for k, v in m.psfnet.state_dict().items())
+    cmp = m.compare_psf(spp=4096)
+    assert set(cmp) == {-500, -20000}
+    traced, predicted = cmp[-500]
+    assert traced.shape == (3, 2, 11, 11) and predicted.shape == (3, 2, 11, 11)

@@ -1,0 +1,115 @@
+"""PSF-network consumers against fixtures generated from the reference by
+oracle/gen_golden_psfnet.py.  CPU: fp32, no autocast -- the reference's own CPU behaviour."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import DATA, load_golden, load_state
+
+
+def make_psfnet(ks, device="cpu"):
+    from sdirt_amd.psfnet import PSFNet
+    st = load_state("rf50mm")
+    m = PSFNet(os.path.join(DATA, "rf50mm.json"), sensor_res=(512, 768), kernel_size=ks,
+               device=device, post_computation=False)
+    m.set_state(d_sensor=st["d_sensor"], hfov=st["hfov"], pupil=(st["pupil_z"], st["pupil_r"]),
+                exit_pupil=(st["exit_pupil_z"], st["exit_pupil_r"]))
+    return m
+
+
+def small_net(fx, prefix="w/"):
+    from sdirt_amd.psfnet_arch import MLP
+    net = MLP(3, int(fx["ks"]) ** 2, hidden_features=int(fx["hidden"]), hidden_layers=int(fx["layers"]))
+    sd = {k[len(prefix):]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith(prefix)}
+    assert set(sd) == set(net.state_dict())           # the reference's parameter names
+    net.load_state_dict(sd)
+    return net
+
+
+def test_init_net_draws_the_reference_weights():
+    fx = load_golden("f9_psfnet_init")
+    m = make_psfnet(21)
+    torch.manual_seed(0)
+    m.init_net()
+    sd = m.psfnet.state_dict()
+    keys = [k[len("shape/"):] for k in fx.files if k.startswith("shape/")]
+    assert sorted(keys) == sorted(sd)
+    for k in keys:
+        assert tuple(fx["shape/" + k]) == tuple(sd[k].shape)
+        np.testing.assert_array_equal(sd[k].reshape(-1)[:4].numpy(), fx["head/" + k])
+        assert sd[k].double().sum().item() == pytest.approx(float(fx["sum/" + k]), rel=1e-12, abs=1e-12)
+        assert sd[k].double().abs().sum().item() == pytest.approx(float(fx["abs/" + k]), rel=1e-12)
+
+
+def test_unknown_architectures_raise_like_the_reference():
+    m = make_psfnet(7)
+    m.model_name = "siren"
+    with pytest.raises(NotImplementedError):
+        m.init_net()
+    m.model_name = "resnet"
+    with pytest.raises(Exception, match="Unsupported PSF network"):
+        m.init_net()
+
+
+def test_pred_and_pred_coc_match_the_reference():
+    fx = load_golden("f9_psfnet_forward")
+    m = make_psfnet(int(fx["ks"]))
+    m.psfnet = small_net(fx)
+    m.foclen, m.fnum = float(fx["foclen"]), float(fx["fnum"])
+    inp = torch.from_numpy(fx["pred_inp"].copy())
+    with torch.no_grad():
+        out = m.pred(inp)
+    np.testing.assert_array_equal(inp[..., 0].numpy(), -fx["pred_inp"][..., 0])   # in-place mirror
+    assert out.shape == fx["pred"].shape
+    np.testing.assert_allclose(out.numpy(), fx["pred"], rtol=2e-5, atol=1e-7)
+    coc = m.pred_coc(torch.from_numpy(fx["pred_inp"].copy()))
+    np.testing.assert_allclose(coc.numpy(), fx["pred_coc"], rtol=2e-5, atol=1e-7)
+
+
+def test_tone_curves_match_the_reference():
+    fx = load_golden("f9_psfnet_forward")
+    m = make_psfnet(int(fx["ks"]))
+    x = torch.from_numpy(fx["tone_in"].copy())
+    lin = m.degamma(x)
+    np.testing.assert_allclose(lin.numpy(), fx["degamma"], rtol=1e-6)
+    np.testing.assert_allclose(m.gamma(lin).numpy(), fx["gamma"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_array_equal(x.numpy(), fx["tone_in"])                      # inputs untouched
+
+
+def test_train_psfnet_takes_the_reference_optimiser_steps(tmp_path):
+    fx = load_golden("f9_psfnet_train")
+    m = make_psfnet(int(fx["ks"]))
+    m.psfnet = small_net(fx, "w0/")
+    feed = iter(zip(torch.from_numpy(fx["inp"].copy()), torch.from_numpy(fx["psf"].copy())))
+    m.get_training_data = lambda bs, spp: next(feed)
+    losses = m.train_psfnet(iters=int(fx["iters"]), bs=8, lr=float(fx["lr"]), spp=16,
+                            evaluate_every=10 ** 6, result_dir=str(tmp_path))
+    assert len(losses) == int(fx["iters"]) + 1
+    saved = torch.load(tmp_path / "PSFNet_mlp.pkl")
+    for k, v in m.psfnet.state_dict().items():
+        np.testing.assert_allclose(v.numpy(), fx["w1/" + k], rtol=1e-5, atol=1e-7)
+        assert torch.equal(saved[k], v)
+
+
+def test_load_net_keeps_mismatched_tensors(tmp_path):
+    fx = load_golden("f9_psfnet_forward")
+    m = make_psfnet(int(fx["ks"]))
+    m.psfnet = small_net(fx)
+    ckpt = {k: v.clone() + 1 for k, v in m.psfnet.state_dict().items()}
+    last = sorted(ckpt)[-1]
+    ckpt[last] = torch.zeros(3)                                    # wrong shape -> ignored
+    before = m.psfnet.state_dict()[last].clone()
+    torch.save(ckpt, tmp_path / "c.pkl")
+    m.load_net(str(tmp_path / "c.pkl"))
+    sd = m.psfnet.state_dict()
+    assert torch.equal(sd[last], before)
+    first = sorted(ckpt)[0]
+    assert torch.equal(sd[first], ckpt[first])
+
+
+def test_render_rejects_what_the_reference_cannot_run():
+    m = make_psfnet(7)
+    with pytest.raises(ValueError):
+        m.render(torch.zeros(3, 8, 12), torch.zeros(8, 12), -1000.0)
