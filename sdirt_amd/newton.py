@@ -14,8 +14,9 @@ loop would have produced for this batch:
     T is right for a surface  <=>  bits 1..T-1 are set and (bit T is clear or T == 10),
     provided every surface upstream was right (their output rays feed this one).
 
-`TripPlanner.run` speculates (cached table from the last call, or a cheap pilot
-launch), launches, verifies, and re-launches only when the verification fails;
+`TripPlanner.run` speculates (the table verified most often for this kind of
+call so far, or 10 trips everywhere on first use), launches, verifies, and
+re-launches only when the verification fails;
 in steady state (same lens, similar batches) that is one launch per call plus
 one K-word readback -- the reference synchronises on every Newton iteration.
 """
@@ -59,10 +60,11 @@ def verify(trips, masks, order, curved):
             if T >= 1 and (j == T or (j is None and T == NEWTON_MAXITER)):
                 continue                      # exactly what the reference would run
             failed = True
-        # first wrong surface: exact correction when a clear bit was seen, else run
-        # the full 10 trips to learn the whole mask.  Downstream surfaces: their
-        # masks came from slightly different rays, use them as the next guess.
-        new[k] = j if j is not None else NEWTON_MAXITER
+        # first wrong surface: exact correction when a clear bit was seen; when every trip
+        # that ran still had an open ray, one more trip is by far the likeliest answer (a
+        # batch flips between neighbouring counts when its slowest ray changes).  Downstream
+        # surfaces: their masks came from slightly different rays, use them as the next guess.
+        new[k] = j if j is not None else min(max(T, 0) + 1, NEWTON_MAXITER)
     return (not failed), new
 
 
@@ -76,15 +78,32 @@ class TripPlanner:
     """
 
     def __init__(self):
-        self.cache = {}
+        self.cache = {}          # key -> last verified table
+        self.votes = {}          # key -> {table: times verified}
         self.launches = 0
         self.relaunches = 0
 
     def initial(self, key, curved):
+        """Batches of one workload flip between a few neighbouring tables (the slowest ray of
+        the batch decides); the table that was right most often is the better bet than the
+        last one (ties: the most recent)."""
         t = self.cache.get(key)
         if t is None or len(t) != len(curved):
-            t = np.where(np.asarray(curved), NEWTON_MAXITER, 0).astype(np.int32)
+            return np.where(np.asarray(curved), NEWTON_MAXITER, 0).astype(np.int32)
+        votes = self.votes.get(key, {})
+        best = max(votes.values(), default=0)
+        if votes.get(tuple(int(x) for x in t), 0) < best:
+            t = next(tab for tab, n in votes.items() if n == best)
         return np.asarray(t, np.int32).copy()
+
+    def learn(self, key, trips):
+        self.cache[key] = np.asarray(trips, np.int32).copy()
+        votes = self.votes.setdefault(key, {})
+        tab = tuple(int(x) for x in trips)
+        votes[tab] = votes.get(tab, 0) + 1
+        if votes[tab] >= 64:     # keep the statistics adaptive
+            for k in list(votes):
+                votes[k] //= 2
 
     def run(self, key, curved, order, launch, max_rounds=None):
         K = len(curved)
@@ -95,7 +114,7 @@ class TripPlanner:
             self.launches += 1
             ok, new = verify(trips, masks, order, curved)
             if ok:
-                self.cache[key] = trips.copy()
+                self.learn(key, trips)
                 return trips
             self.relaunches += 1
             trips = new
@@ -114,7 +133,7 @@ class TripPlanner:
             results = [verify(t, m, order, curved) for t, m in zip(tables, masks)]
             if all(ok for ok, _ in results):
                 for k, t in zip(keys, tables):
-                    self.cache[k] = t.copy()
+                    self.learn(k, t)
                 return tables
             self.relaunches += 1
             tables = [t if ok else new for t, (ok, new) in zip(tables, results)]

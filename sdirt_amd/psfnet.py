@@ -115,44 +115,109 @@ class PSFNet(Lensgroup):
         self.psfnet.load_state_dict(own)
 
     def train_psfnet(self, iters=10000, bs=128, lr=1e-4, spp=2048, evaluate_every=1000,
-                     result_dir="./results/temp"):
+                     result_dir="./results/temp", pipelined=None):
         """psfnet.py:101-168: fit the network to PSFs ray-traced on the fly.  AdamW, cosine
         schedule over iters//3, MSE on max-normalised kernels, fp16 autocast + loss scaling on
         the GPU.  Every `evaluate_every` steps: checkpoint + L1/L2 of sum-normalised kernels
         on the 1024-point test set (logged; the reference also writes a matplotlib figure).
-        Returns the list of per-step training losses."""
+        Returns the list of per-step training losses.
+
+        pipelined (default: on for CUDA devices): the loop is launch-bound at the reference's
+        batch size (64 rows through 11 small GEMMs, forward and backward), so forward + backward
+        are captured once in a hipGraph and replayed, the optimiser runs as one fused kernel
+        without reading the inf-check back, and batch i+1 is ray-traced on a second stream
+        while step i runs.  Same draws from the RNGs in the same order, same arithmetic per
+        step; `pipelined=False` is the plain loop."""
         psfnet = self.psfnet
         psfnet.train()
         on_gpu = torch.device(self.device).type == "cuda"
+        pipelined = on_gpu if pipelined is None else (pipelined and on_gpu)
         l2, l1 = torch.nn.MSELoss(reduction="mean"), torch.nn.L1Loss(reduction="mean")
-        optim = torch.optim.AdamW(psfnet.parameters(), lr)
+        optim = torch.optim.AdamW(psfnet.parameters(), lr, **({"fused": True} if pipelined else {}))
         sche = torch.optim.lr_scheduler.CosineAnnealingLR(optim, T_max=int(iters) // 3, eta_min=0)
         scaler = torch.amp.GradScaler("cuda", enabled=on_gpu)
         amp = lambda: torch.autocast("cuda", dtype=torch.float16, enabled=on_gpu)  # noqa: E731
-        losses = []
-        for i in range(iters + 1):
-            with amp():
-                inp, psf = self.get_training_data(bs=bs, spp=spp)
+
+        def evaluate(i):
+            with torch.no_grad(), amp():
+                psfnet.eval()
+                torch.save(psfnet.state_dict(),
+                           os.path.join(result_dir, f"iter{i + 1}_PSFNet_{self.model_name}.pkl"))
+                inp, psf = self.get_test_data()
                 inp, psf = inp.to(self.device), psf.to(self.device)
-                loss = l2(psfnet(inp), psf)
-                optim.zero_grad()
-            scaler.scale(loss).backward()
-            scaler.step(optim)
-            scaler.update()
-            sche.step()
-            losses.append(loss.detach())
-            if (i + 1) % evaluate_every == 0:
-                with torch.no_grad(), amp():
-                    psfnet.eval()
-                    torch.save(psfnet.state_dict(),
-                               os.path.join(result_dir, f"iter{i + 1}_PSFNet_{self.model_name}.pkl"))
-                    inp, psf = self.get_test_data()
+                pred = psfnet(inp)
+                psf = psf / psf.sum((-1, -2), keepdim=True)
+                pred = pred / pred.sum((-1, -2), keepdim=True)
+                logging.info(f"{i}, {l1(pred, psf).item()}, {l2(pred, psf).item()}")
+                psfnet.train()
+
+        losses = []
+        if not pipelined:
+            for i in range(iters + 1):
+                with amp():
+                    inp, psf = self.get_training_data(bs=bs, spp=spp)
                     inp, psf = inp.to(self.device), psf.to(self.device)
-                    pred = psfnet(inp)
-                    psf = psf / psf.sum((-1, -2), keepdim=True)
-                    pred = pred / pred.sum((-1, -2), keepdim=True)
-                    logging.info(f"{i}, {l1(pred, psf).item()}, {l2(pred, psf).item()}")
-                    psfnet.train()
+                    loss = l2(psfnet(inp), psf)
+                    optim.zero_grad()
+                scaler.scale(loss).backward()
+                scaler.step(optim)
+                scaler.update()
+                sche.step()
+                losses.append(loss.detach())
+                if (i + 1) % evaluate_every == 0:
+                    evaluate(i)
+        else:
+            main = torch.cuda.current_stream(self.device)
+            side = torch.cuda.Stream(self.device)
+
+            def produce():
+                # the ray tracer's only host wait (the Newton trip check, newton.py) then blocks
+                # on `side`, while `main` keeps running the captured step
+                with torch.cuda.stream(side):
+                    inp, psf = self.get_training_data(bs=bs, spp=spp)
+                    inp = inp.to(self.device, non_blocking=True)
+                    ready = torch.cuda.Event()
+                    ready.record(side)
+                return inp, psf, ready
+
+            side.wait_stream(main)
+            first = produce()
+            static_inp = torch.empty_like(first[0])
+            static_psf = torch.empty_like(first[1])
+            main.wait_event(first[2])
+            static_inp.copy_(first[0]); static_psf.copy_(first[1])
+
+            def fwd_bwd():
+                with amp():
+                    loss = l2(psfnet(static_inp), static_psf)
+                scaler.scale(loss).backward()
+                return loss
+
+            side.wait_stream(main)
+            with torch.cuda.stream(side):                     # warm-up off the capture stream
+                for _ in range(3):
+                    optim.zero_grad(set_to_none=True)
+                    fwd_bwd()
+            main.wait_stream(side)
+            optim.zero_grad(set_to_none=True)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                static_loss = fwd_bwd()
+            nxt = first
+            for i in range(iters + 1):
+                inp, psf, ready = nxt
+                main.wait_event(ready)
+                static_inp.copy_(inp); static_psf.copy_(psf)
+                inp.record_stream(main); psf.record_stream(main)
+                graph.replay()                                 # grads are rewritten, not accumulated
+                if i < iters:
+                    nxt = produce()
+                scaler.step(optim)
+                scaler.update()
+                sche.step()
+                losses.append(static_loss.detach().clone())
+                if (i + 1) % evaluate_every == 0:
+                    evaluate(i)
         torch.save(psfnet.state_dict(), os.path.join(result_dir, f"PSFNet_{self.model_name}.pkl"))
         return [float(v) for v in losses]
 

@@ -104,9 +104,9 @@ def test_verify_accepts_exact_table_and_corrects_wrong_ones():
     # too many trips on surface 1: the first clear bit is the reference's count
     ok, new = verify([10, 6, 0, 4], masks_for([10, 6, 0, 4], need), range(4), curved)
     assert not ok and new[1] == 3
-    # too few: ask for the full mask
+    # too few: one more trip is the next guess
     ok, new = verify([10, 2, 0, 4], masks_for([10, 2, 0, 4], need), range(4), curved)
-    assert not ok and new[1] == 10
+    assert not ok and new[1] == 3
     # never converging surface stays at the cap and is accepted (rule `it < 10`)
     ok, new = verify([10, 3, 0, 4], masks_for([10, 3, 0, 4], [11, 3, 0, 4]), range(4), curved)
     assert ok
@@ -132,7 +132,33 @@ def test_trip_planner_converges_and_caches():
     # batch changes (one surface now needs one trip more): one corrective relaunch
     need[2] = 5
     got = pl.run("k", curved, range(12), launch)
-    assert list(got) == need and len(calls) <= 6
+    assert list(got) == need and len(calls) == 5                  # wrong + corrected
+    # two trips short costs two corrections, never a wrong answer
+    need[2] = 7
+    got = pl.run("k", curved, range(12), launch)
+    assert list(got) == need
+
+
+def test_trip_planner_bets_on_the_most_frequent_table():
+    """Batches that flip between two neighbouring tables: speculate the commoner one."""
+    from sdirt_amd.newton import TripPlanner
+    curved = [True, True]
+    tables = {"a": [10, 3], "b": [10, 4]}
+    pl, launched = TripPlanner(), []
+    for which in "aaabaaabaaab":
+        need = tables[which]
+
+        def launch(trips, need=need):
+            launched.append(list(trips))
+            return masks_for(trips, need)
+        assert list(pl.run("k", curved, range(2), launch)) == need
+    # after the first 'b', a last-value predictor would also miss the 'a' that follows it
+    first_guesses = []
+    i = 0
+    for which in "aaabaaabaaab":
+        first_guesses.append(launched[i])
+        i += 1 if launched[i] == tables[which] else 2
+    assert first_guesses[4:] == [tables["a"]] * 8
 
 
 # ------------------------------------------------------------------ C ABI

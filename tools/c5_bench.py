@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""BASELINE config 5 (image simulation): PSFNet.render on a synthetic RGB-D frame, 512x768,
+ks 21, full-size MLP (3 -> 128 -> 512 x9 -> 441) with seeded random weights (the reference's
+checkpoints are not in its repository).  Times the stages with HIP events."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from sdirt_amd.psfnet import PSFNet
+from sdirt_amd.render_psf import local_psf_render_fast
+
+dev = "cuda:0"
+H, W, ks = 512, 768, 21
+torch.manual_seed(0)
+m = PSFNet(os.path.join(os.path.dirname(__file__), "..", "sdirt_amd", "data", "rf50mm.json"),
+           sensor_res=(H, W), kernel_size=ks, device=dev)
+m.refocus(-1000 + m.d_sensor)
+with torch.no_grad():
+    m.psfnet.net[-2].bias.add_(0.02)
+g = torch.Generator(device=dev).manual_seed(0)
+img = torch.rand(1, 3, H, W, device=dev, generator=g)
+depth = -(500 + 4500 * torch.rand(1, 1, H, W, device=dev, generator=g))
+foc = torch.tensor([-1000.0], device=dev)
+
+
+def timed(fn, n=10, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(n):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(); e1.record()
+        torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
+    return float(np.median(ts))
+
+
+x, y = torch.meshgrid(torch.linspace(-1, 1, W), torch.linspace(1, -1, H), indexing="xy")
+o = torch.stack((x.to(dev)[None], y.to(dev)[None], m.depth2z(depth + m.d_sensor).squeeze(1)), -1).float()
+with torch.no_grad():
+    t_net = timed(lambda: m.psfnet(o))
+    t_pred = timed(lambda: m.pred(o.clone()))
+    psf = m.pred(o.clone())
+    t_conv = timed(lambda: local_psf_render_fast(img, psf, ks))
+    t_all = timed(lambda: m.render(img, depth, foc))
+macs = 3 * 128 + 128 * 512 + 8 * 512 * 512 + 512 * ks * ks
+fl = 2 * macs * H * W
+print(f"psf dtype {psf.dtype}; one network pass {t_net:.2f} ms ({fl / t_net / 1e9:.0f} TFLOP/s); "
+      f"pred (L+R, normalise) {t_pred:.2f} ms; convolution {t_conv:.2f} ms; render total {t_all:.2f} ms "
+      f"-> {1e3 / t_all:.1f} frames/s")
