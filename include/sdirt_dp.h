@@ -259,6 +259,17 @@ int sdirt_local_psf_render(const float* img /*dev*/, const float* psf /*dev*/, i
                            int32_t half_precision, float* out_l /*dev [B,C,H,W]*/,
                            float* out_r /*dev [B,C,H,W]*/, void* stream);
 
+/* PSFNet.pred (deeplens/psfnet.py:317-336: stack(net(x,y,z), fliplr(net(-x,y,z))), each side
+ * divided by its own sum + 1e-9) followed by local_psf_render_fast (render_psf.py:120-155), as
+ * PSFNet.render chains them (psfnet.py:702-707), in one pass over the network's raw outputs.
+ * raw_l, raw_r: fp16 [B*H*W, ks*ks], 16-byte aligned; the flipped / normalised per-pixel kernels
+ * are formed in LDS and never written to memory.  Same fp16 arithmetic as
+ * sdirt_local_psf_render(half_precision=1).  A kernel whose raw sum is 0 renders 0. */
+int sdirt_psfnet_render(const float* img /*dev [B,C,H,W]*/, const void* raw_l /*dev fp16*/,
+                        const void* raw_r /*dev fp16*/, int32_t batch, int32_t channels,
+                        int32_t height, int32_t width, int32_t ks, float* out_l /*dev [B,C,H,W]*/,
+                        float* out_r /*dev [B,C,H,W]*/, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -72,6 +72,7 @@ SIGNATURES = {
                                         _P, _P, _P, _P, _P, _P, _P]),
     "sdirt_selftest_math": (C.c_int, [_I32, C.c_uint64, C.c_uint64, _I32, _P, _P]),
     "sdirt_local_psf_render": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P, _P]),
+    "sdirt_psfnet_render": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P]),
 }
 
 _lib = None

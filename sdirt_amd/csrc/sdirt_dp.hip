@@ -770,6 +770,105 @@ k_local_psf_render_tiled(const float* __restrict__ img, const float* __restrict_
     }
 }
 
+// PSFNet.pred (psfnet.py:317-336) + local_psf_render_fast (render_psf.py:120-155) in one pass
+// over the network's raw fp16 outputs: raw_l = net(x, y, z), raw_r = net(-x, y, z), both
+// [P, ks*ks].  Per pixel: L taps = raw_l / (sum(raw_l) + 1e-9), R taps = fliplr(raw_r) /
+// (sum(raw_r) + 1e-9), then the per-pixel convolution with the fp16 arithmetic of the _fast
+// renderer.  The stacked / flipped / normalised [P,2,ks,ks] tensor the reference materialises
+// (and re-reads twice) never exists: each raw value is read from HBM once, as fp16.
+// A zero-sum kernel renders 0 (the reference's fp16 division would give NaN there).
+template <int C, int PIX, int KS>
+__global__ void __launch_bounds__(kBlock)
+k_psfnet_render(const float* __restrict__ img, const _Float16* __restrict__ raw_l,
+                const _Float16* __restrict__ raw_r, int B, int H, int W, int ks_rt,
+                float* __restrict__ outl, float* __restrict__ outr)
+{
+    const int ks = KS > 0 ? KS : ks_rt;
+    extern __shared__ __attribute__((aligned(16))) _Float16 wh[];   // [2][PIX][ks*ks]
+    const int64_t HW = (int64_t)H * W;
+    const int64_t P = (int64_t)B * HW;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pad = (ks - 1) / 2, kk = ks * ks;
+    const int rows_per_iter = ks <= 64 ? 64 / ks : 1;
+    const int lane_row = ks <= 64 ? lane / ks : 0;
+    const int lane_col = ks <= 64 ? lane - lane_row * ks : lane;
+    const int64_t ngroups = (P + PIX - 1) / PIX;
+    typedef float fl4 __attribute__((ext_vector_type(4)));
+    for (int64_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
+        const int64_t p0 = g * PIX;
+        const int npix = (int)min((int64_t)PIX, P - p0);
+        const int nh = npix * kk;                                   // halves per side
+        const int nv = nh >> 3;                                     // 16-byte vectors per side
+        // PIX is a multiple of 8, so both runs start 16-byte aligned
+        const fl4* sl4 = reinterpret_cast<const fl4*>(raw_l + p0 * kk);
+        const fl4* sr4 = reinterpret_cast<const fl4*>(raw_r + p0 * kk);
+        fl4* dl4 = reinterpret_cast<fl4*>(wh);
+        fl4* dr4 = reinterpret_cast<fl4*>(wh + PIX * kk);
+        constexpr int STAGE_U = 4;
+        for (int base = threadIdx.x; base < nv; base += kBlock * STAGE_U) {
+            fl4 a[STAGE_U], b[STAGE_U];
+#pragma unroll
+            for (int u = 0; u < STAGE_U; ++u)
+                if (base + u * kBlock < nv) {
+                    a[u] = __builtin_nontemporal_load(&sl4[base + u * kBlock]);
+                    b[u] = __builtin_nontemporal_load(&sr4[base + u * kBlock]);
+                }
+#pragma unroll
+            for (int u = 0; u < STAGE_U; ++u)
+                if (base + u * kBlock < nv) { dl4[base + u * kBlock] = a[u]; dr4[base + u * kBlock] = b[u]; }
+        }
+        for (int i = (nv << 3) + threadIdx.x; i < nh; i += blockDim.x) {
+            wh[i] = raw_l[p0 * kk + i];
+            wh[PIX * kk + i] = raw_r[p0 * kk + i];
+        }
+        __syncthreads();
+        for (int q = wave; q < npix; q += kBlock / 64) {
+            const int64_t p = p0 + q;
+            const int b = (int)(p / HW);
+            const int64_t r = p - (int64_t)b * HW;
+            const int y = (int)(r / W), x = (int)(r - (int64_t)y * W);
+            const _Float16* kl = wh + q * kk;
+            const _Float16* kr = wh + PIX * kk + q * kk;
+            float sl = 0.0f, sr = 0.0f;
+            for (int f = lane; f < kk; f += 64) { sl += (float)kl[f]; sr += (float)kr[f]; }
+            const float inv_l = 1.0f / (round_half(wave_sum(sl)) + 1e-9f);
+            const float inv_r = 1.0f / (round_half(wave_sum(sr)) + 1e-9f);
+            float accl[C], accr[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) { accl[c] = 0.0f; accr[c] = 0.0f; }
+#pragma unroll KS > 0 ? 8 : 1
+            for (int i0 = 0; i0 < ks; i0 += rows_per_iter) {
+                for (int j0 = 0; j0 < ks; j0 += 64) {
+                    const int fi = i0 + lane_row, fj = j0 + lane_col;
+                    if (lane_row < rows_per_iter && fi < ks && fj < ks) {
+                        const int yy = min(max(y + (ks - 1 - fi) - pad, 0), H - 1);
+                        const int xx = min(max(x + (ks - 1 - fj) - pad, 0), W - 1);
+                        const float wl = round_half((float)kl[fi * ks + fj] * inv_l);
+                        const float wr = round_half((float)kr[fi * ks + (ks - 1 - fj)] * inv_r);
+                        const float* px = img + ((int64_t)b * C * H + yy) * W + xx;
+#pragma unroll
+                        for (int c = 0; c < C; ++c) {
+                            const float v = round_half(px[(int64_t)c * HW]);
+                            accl[c] += round_half(v * wl);
+                            accr[c] += round_half(v * wr);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const float a = wave_sum(accl[c]), rr = wave_sum(accr[c]);
+                if (lane == 0) {
+                    const int64_t o = ((int64_t)(b * C + c) * H + y) * W + x;
+                    outl[o] = round_half(a);
+                    outr[o] = round_half(rr);
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // ---------------------------------------------------------------------------
 // diagnostics: does the Lean math policy ever differ from IEEE?
 // ---------------------------------------------------------------------------
@@ -1286,6 +1385,50 @@ int sdirt_local_psf_render(const float* img, const float* psf, int32_t B, int32_
 #undef SDIRT_RENDER
 #undef SDIRT_RENDER_H
 #undef SDIRT_RENDER_T
+    LAUNCH_CHECK();
+    return SDIRT_OK;
+}
+
+int sdirt_psfnet_render(const float* img, const void* raw_l, const void* raw_r, int32_t B, int32_t C,
+                        int32_t H, int32_t W, int32_t ks, float* out_l, float* out_r, void* stream)
+{
+    if (!img || !raw_l || !raw_r || !out_l || !out_r || B < 0 || H < 1 || W < 1 || ks < 1 ||
+        (ks & 1) == 0)
+        return fail(SDIRT_ERR_INVALID_ARGUMENT, "bad argument (ks must be odd)");
+    if (((uintptr_t)raw_l | (uintptr_t)raw_r) & 15)
+        return fail(SDIRT_ERR_INVALID_ARGUMENT, "raw_l / raw_r must be 16-byte aligned");
+    if (B == 0) return SDIRT_OK;
+    const int64_t P = (int64_t)B * H * W;
+    hipStream_t st = as_stream(stream);
+    const size_t per_pixel = sizeof(_Float16) * 2 * (size_t)ks * ks;
+    if (per_pixel * 8 > 64 * 1024)
+        return fail(SDIRT_ERR_UNSUPPORTED, "ks=%d: eight pixels' kernels exceed 64 KB of LDS", ks);
+    const _Float16* rl = static_cast<const _Float16*>(raw_l);
+    const _Float16* rr = static_cast<const _Float16*>(raw_r);
+#define SDIRT_PN(CC, PP, KK)                                                                     \
+    do {                                                                                         \
+        const size_t lds = per_pixel * PP;                                                       \
+        const int grid = (int)std::min<int64_t>((P + PP - 1) / PP, 256 * 64);                    \
+        if (lds > 48 * 1024)                                                                     \
+            HIP_TRY(hipFuncSetAttribute((const void*)k_psfnet_render<CC, PP, KK>,                \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)); \
+        k_psfnet_render<CC, PP, KK><<<grid, kBlock, lds, st>>>(img, rl, rr, B, H, W, ks, out_l,  \
+                                                               out_r);                           \
+    } while (0)
+#define SDIRT_PN_C(CC)                                                                           \
+    do {                                                                                         \
+        if (ks == 21 && CC == 3) SDIRT_PN(3, 16, 21);                                            \
+        else if (per_pixel * 16 <= 32 * 1024) SDIRT_PN(CC, 16, 0);                               \
+        else SDIRT_PN(CC, 8, 0);                                                                 \
+    } while (0)
+    switch (C) {
+    case 1: SDIRT_PN_C(1); break;
+    case 3: SDIRT_PN_C(3); break;
+    case 4: SDIRT_PN_C(4); break;
+    default: return fail(SDIRT_ERR_UNSUPPORTED, "channels=%d (supported: 1, 3, 4)", C);
+    }
+#undef SDIRT_PN_C
+#undef SDIRT_PN
     LAUNCH_CHECK();
     return SDIRT_OK;
 }

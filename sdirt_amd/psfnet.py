@@ -21,7 +21,7 @@ import torch
 
 from .optics import Lensgroup
 from .psfnet_arch import MLP, MLPConv, initialize_weights
-from .render_psf import local_psf_render_fast
+from .render_psf import local_psf_render_fast, psfnet_render
 
 DMIN = 200      # [mm]  psfnet.py:15
 DMAX = 20000    # [mm]  psfnet.py:16
@@ -36,6 +36,8 @@ class PSFNet(Lensgroup):
                  device="cuda", **lens_kwargs):
         super().__init__(filename=filename, sensor_res=sensor_res, device=device, **lens_kwargs)
         self.in_features = 4
+        #: render(): fuse pred's flip / normalise into the convolution kernel (GPU only)
+        self.fused_render = True
         self.kernel_size = kernel_size
         self.model_name = model_name
         self.init_net()
@@ -314,8 +316,16 @@ class PSFNet(Lensgroup):
         x = x.unsqueeze(0).repeat(N, 1, 1).to(img.device)
         y = y.unsqueeze(0).repeat(N, 1, 1).to(img.device)
         o = torch.stack((x, y, z), -1).float()
-        psf = self.pred(o)
-        render_lr = local_psf_render_fast(self.degamma(img), psf, self.kernel_size)
+        if img.is_cuda and self.fused_render:
+            # one GEMM chain over [(x,y,z); (-x,y,z)], then flip + normalise + convolve in one
+            # HIP kernel straight from the raw fp16 outputs (sdirt_psfnet_render)
+            mirrored = o.clone()
+            mirrored[..., 0] = -mirrored[..., 0]
+            raw = self.psfnet(torch.stack((o, mirrored)))
+            render_lr = psfnet_render(self.degamma(img), raw[0], raw[1], self.kernel_size)
+        else:
+            psf = self.pred(o)
+            render_lr = local_psf_render_fast(self.degamma(img), psf, self.kernel_size)
         render = self.gamma(torch.cat(render_lr, dim=1))
         if train:
             render = self.noise(render, img.shape)

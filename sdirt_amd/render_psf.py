@@ -43,6 +43,29 @@ def local_dp_psf_render(input, dp_psf, kernel_size=21):
     return torch.cat([rl, rr], dim=1)
 
 
+def psfnet_render(input, raw_l, raw_r, kernel_size):
+    """PSFNet.pred + local_psf_render_fast (psfnet.py:317-336, 702-707; render_psf.py:120-155)
+    in one pass over the network's raw fp16 outputs raw_l = net(x, y, z), raw_r = net(-x, y, z),
+    each [B,H,W,ks,ks]: the stacked, flipped, normalised per-pixel kernels are formed in LDS
+    only.  -> (rl, rr) [B,C,H,W] fp32 holding fp16 values, as local_psf_render_fast returns."""
+    if input.device.type != "cuda":
+        raise _lib.SdirtError("sdirt_amd renders on the GPU only (no CPU fallback)")
+    b, c, h, w = input.shape
+    img = input.to(torch.float32).contiguous()
+    raw_l = raw_l.to(torch.float16).reshape(b, h, w, kernel_size * kernel_size).contiguous()
+    raw_r = raw_r.to(torch.float16).reshape(b, h, w, kernel_size * kernel_size).contiguous()
+    if raw_l.data_ptr() % 16:                  # the kernel stages with 16-byte loads
+        raw_l = raw_l.clone()
+    if raw_r.data_ptr() % 16:
+        raw_r = raw_r.clone()
+    rl = torch.empty((b, c, h, w), dtype=torch.float32, device=input.device)
+    rr = torch.empty_like(rl)
+    _lib.check(_lib.lib().sdirt_psfnet_render(dptr(img), dptr(raw_l), dptr(raw_r), b, c, h, w,
+                                              kernel_size, dptr(rl), dptr(rr),
+                                              stream_ptr(input.device)))
+    return rl, rr
+
+
 def render_psf(img, psf):
     """render_psf.py:12-28: one PSF for the whole image, [B,C,H,W] x [C,ks,ks].  A plain
     grouped convolution with reflect padding: dense conv work that stock PyTorch-ROCm

@@ -139,6 +139,12 @@ def test_psfnet_pred_and_render_against_reference():
     # fp16 kernels and fp16 products in linear light, then the gamma curve (slope <= ~4 here)
     assert np.abs(out.cpu().numpy() - fx["render"]).max() < 4e-3
     assert np.abs(out.cpu().numpy() - fx["render"]).mean() < 5e-4
+    # the fused flip + normalise + convolve kernel against the reference's op-by-op chain
+    m.fused_render = False
+    chained = m.render(t(fx["img"]), t(fx["depth"]), t(fx["foc_dist"]))
+    m.fused_render = True
+    assert (out - chained).abs().max().item() < 1.5e-3
+    assert np.abs(chained.cpu().numpy() - fx["render"]).max() < 4e-3
     # fp32 network (autocast off) narrows the gap to the convolution's own fp16 rounding
     with torch.autocast("cuda", enabled=False):
         m.psfnet.forward = lambda x: m.psfnet.net(x).reshape(*x.shape[:-1], m.psfnet.ks, m.psfnet.ks)
@@ -191,3 +197,24 @@ def test_pipelined_training_loop_equals_the_plain_loop(tmp_path):
     np.testing.assert_allclose(la, lb, rtol=0.05)            # fp16 GEMMs + fused vs foreach AdamW
     for k in wa:
         assert torch.allclose(wa[k], wb[k], atol=5e-3), k
+
+
+@pytest.mark.parametrize("shape", [(1, 3, 40, 56, 21), (2, 1, 9, 13, 5), (1, 4, 7, 33, 9), (1, 3, 5, 7, 31)])
+def test_psfnet_render_kernel_equals_pred_then_render(shape):
+    """sdirt_psfnet_render on random raw outputs == stack / fliplr / normalise in torch (fp16,
+    as PSFNet.pred does on the GPU) followed by the fp16 convolution kernel."""
+    from sdirt_amd.render_psf import local_psf_render_fast, psfnet_render
+    B, C, H, W, ks = shape
+    g = torch.Generator(device=DEV).manual_seed(ks)
+    raw = torch.rand(2, B, H, W, ks, ks, device=DEV, generator=g).half()
+    raw[0, 0, 0, 0] = 0                                               # dead kernel -> renders 0
+    img = torch.rand(B, C, H, W, device=DEV, generator=g)
+    rl, rr = psfnet_render(img, raw[0], raw[1], ks)
+    psf = torch.stack((raw[0], torch.flip(raw[1], dims=[-1])), dim=-3).float()
+    psf = psf / (psf.sum((-1, -2), keepdim=True).half().float() + 1e-9)
+    el, er = local_psf_render_fast(img, psf.half(), kernel_size=ks)
+    assert rl.shape == (B, C, H, W) and torch.isfinite(rl).all() and torch.isfinite(rr).all()
+    assert rl[0, :, 0, 0].abs().max() == 0
+    # identical arithmetic except reciprocal-multiply vs divide before the fp16 rounding of a tap
+    assert (rl - el).abs().max().item() <= 1e-3 and (rr - er).abs().max().item() <= 1e-3
+    assert ((rl == el).float().mean().item() > 0.7) and ((rr == er).float().mean().item() > 0.7)

@@ -46,8 +46,10 @@ with torch.no_grad():
     psf = m.pred(o.clone())
     t_conv = timed(lambda: local_psf_render_fast(img, psf, ks))
     t_all = timed(lambda: m.render(img, depth, foc))
+    m.fused_render = False
+    t_chain = timed(lambda: m.render(img, depth, foc))
 macs = 3 * 128 + 128 * 512 + 8 * 512 * 512 + 512 * ks * ks
 fl = 2 * macs * H * W
 print(f"psf dtype {psf.dtype}; one network pass {t_net:.2f} ms ({fl / t_net / 1e9:.0f} TFLOP/s); "
-      f"pred (L+R, normalise) {t_pred:.2f} ms; convolution {t_conv:.2f} ms; render total {t_all:.2f} ms "
+      f"pred (L+R, normalise) {t_pred:.2f} ms; convolution {t_conv:.2f} ms; render total {t_all:.2f} ms (op-by-op chain {t_chain:.2f} ms) "
       f"-> {1e3 / t_all:.1f} frames/s")
