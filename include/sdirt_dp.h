@@ -270,6 +270,36 @@ int sdirt_psfnet_render(const float* img /*dev [B,C,H,W]*/, const void* raw_l /*
                         int32_t height, int32_t width, int32_t ks, float* out_l /*dev [B,C,H,W]*/,
                         float* out_r /*dev [B,C,H,W]*/, void* stream);
 
+/* ---- the PSF network itself ------------------------------------------------ */
+
+/* The network is described by its layer widths: widths[0..n_layers] = in, hidden..., out.  The
+ * kernel is built for the reference's MLP (deeplens/psfnet_arch.py:26-50; psfnet.py:78):
+ * 3 -> h4 -> 512 -> ... -> 512 -> out with h4 in {32, 64, 96, 128}, n_layers >= 3, out <= 512
+ * (the reference: 3 -> 128 -> 512 x 9 -> ks*ks); other shapes return SDIRT_ERR_UNSUPPORTED. */
+
+/* Bytes of the packed form of the whole network (weights as fp16 MFMA fragments, then biases
+ * as fp32), or -1 if the shape is unsupported. */
+int64_t sdirt_mlp_packed_bytes(const int32_t* widths /*host [n_layers+1]*/, int32_t n_layers);
+
+/* nn.Linear weights (fp32 [out, in] row-major) and biases (fp32 [out]) of every layer ->
+ * `packed`.  Per layer: out padded to 512 rows (128 for the first layer), in to a multiple of 16
+ * columns, zero filled; tile (mt, ks) of 32 outputs x 16 inputs is one contiguous 1 KB block, lane
+ * l = 32 h + r holding W[32 mt + r][16 ks + 8 h + j], j < 8.  Call again whenever the weights change. */
+int sdirt_mlp_pack(const float* const* weights /*host array of dev ptrs*/,
+                   const float* const* biases /*host array of dev ptrs*/,
+                   const int32_t* widths /*host*/, int32_t n_layers,
+                   void* packed /*dev, 16-byte aligned, out*/, void* stream);
+
+/* MLP.forward under fp16 autocast (psfnet_arch.py:46-50: fp16 operands, fp32 accumulation,
+ * bias, ReLU after EVERY layer, activations rounded to fp16) for all rows in one kernel, the
+ * activations of 128 rows at a time held in LDS from the first layer to the last.
+ * inp: dev fp32 [n_points, 3].  mirror != 0 appends the rows (-x, y, z) after the n_points rows
+ * (x, y, z) -- the two passes of PSFNet.pred, psfnet.py:327-329.
+ * out: dev fp16 [(1 + mirror) * n_points, out_features], 16-byte aligned. */
+int sdirt_psfnet_mlp(const void* packed /*dev*/, const int32_t* widths /*host*/, int32_t n_layers,
+                     const float* inp /*dev*/, int64_t n_points, int32_t mirror,
+                     void* out /*dev fp16*/, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,6 +17,8 @@
 #include "../../include/sdirt_dp.h"
 #include "sdirt_device.hpp"
 
+#include "sdirt_host.hpp"
+
 using namespace sdirt;
 
 // ---------------------------------------------------------------------------
@@ -27,35 +29,6 @@ struct sdirt_lens {
     DevSurface* dev;               // device table [n_surfaces]
     std::vector<DevSurface> host;  // host mirror
 };
-
-static thread_local char g_err[512] = "";
-
-static int fail(int code, const char* fmt, ...)
-{
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(g_err, sizeof(g_err), fmt, ap);
-    va_end(ap);
-    return code;
-}
-
-#define HIP_TRY(expr)                                                                         \
-    do {                                                                                      \
-        hipError_t e_ = (expr);                                                               \
-        if (e_ != hipSuccess)                                                                 \
-            return fail(SDIRT_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
-                        __FILE__, __LINE__);                                                  \
-    } while (0)
-
-#define LAUNCH_CHECK()                                                                  \
-    do {                                                                                \
-        hipError_t e_ = hipGetLastError();                                              \
-        if (e_ != hipSuccess)                                                           \
-            return fail(SDIRT_ERR_HIP, "kernel launch failed: %s (%s:%d)",              \
-                        hipGetErrorString(e_), __FILE__, __LINE__);                     \
-    } while (0)
-
-static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 // Per-surface constant block; every double->float rounding happens here, at the
 // same place the reference's torch scalar handling performs it.

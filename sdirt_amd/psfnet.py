@@ -38,6 +38,8 @@ class PSFNet(Lensgroup):
         self.in_features = 4
         #: render(): fuse pred's flip / normalise into the convolution kernel (GPU only)
         self.fused_render = True
+        #: render(): evaluate the MLP with the single-kernel MFMA path instead of torch.nn layers
+        self.fused_mlp = True
         self.kernel_size = kernel_size
         self.model_name = model_name
         self.init_net()
@@ -319,9 +321,13 @@ class PSFNet(Lensgroup):
         if img.is_cuda and self.fused_render:
             # one GEMM chain over [(x,y,z); (-x,y,z)], then flip + normalise + convolve in one
             # HIP kernel straight from the raw fp16 outputs (sdirt_psfnet_render)
-            mirrored = o.clone()
-            mirrored[..., 0] = -mirrored[..., 0]
-            raw = self.psfnet(torch.stack((o, mirrored)))
+            if self.fused_mlp and getattr(self.psfnet, "fused_supported", lambda: False)():
+                # the whole network in one kernel, activations in LDS (sdirt_psfnet_mlp)
+                raw = self.psfnet.forward_fused(o, mirror=True)
+            else:
+                mirrored = o.clone()
+                mirrored[..., 0] = -mirrored[..., 0]
+                raw = self.psfnet(torch.stack((o, mirrored)))
             render_lr = psfnet_render(self.degamma(img), raw[0], raw[1], self.kernel_size)
         else:
             psf = self.pred(o)

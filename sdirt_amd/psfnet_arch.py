@@ -7,9 +7,14 @@ checkpoints (`F4_PSFNet_mlp.pkl`: keys `net.<2i>.weight/bias`) load unchanged:
 The layers are stock torch.nn (hipBLASLt / MIOpen GEMMs on ROCm); the fp16 autocast the
 reference wraps MLP.forward in (psfnet_arch.py:46) is applied on CUDA devices only.
 """
+import ctypes as C
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as nnF
+
+from . import _lib
+from .basics import dptr, stream_ptr
 
 
 def initialize_weights(m):
@@ -48,6 +53,60 @@ class MLP(nn.Module):
         with _autocast_for(inp):
             x = self.net(inp)
         return x.reshape(*x.shape[:-1], self.ks, self.ks)
+
+    # ---- inference in one HIP kernel (sdirt_psfnet_mlp) --------------------------------------
+    def _linears(self):
+        return [m for m in self.net if isinstance(m, nn.Linear)]
+
+    def fused_supported(self):
+        """Shapes sdirt_psfnet_mlp is built for: 3 -> h4 -> 512 -> ... -> 512 -> out."""
+        lin = self._linears()
+        widths = [lin[0].in_features] + [m.out_features for m in lin]
+        return (len(lin) >= 3 and widths[0] == 3 and widths[1] in (32, 64, 96, 128)
+                and all(w == 512 for w in widths[2:-1]) and 1 <= widths[-1] <= 512
+                and all(m.bias is not None for m in lin))
+
+    def _packed(self):
+        """Weights as fp16 MFMA fragments + fp32 biases in one device buffer, rebuilt whenever a
+        parameter was written (optimiser step, load_state_dict) or moved."""
+        lin = self._linears()
+        params = [p for m in lin for p in (m.weight, m.bias)]
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        cached = getattr(self, "_pack_cache", None)
+        if cached is not None and cached[0] == key:
+            return cached[1], cached[2]
+        n = len(lin)
+        widths = (C.c_int32 * (n + 1))(lin[0].in_features, *[m.out_features for m in lin])
+        nbytes = _lib.lib().sdirt_mlp_packed_bytes(widths, n)
+        if nbytes < 0:
+            raise _lib.SdirtError(_lib.lib().sdirt_last_error().decode())
+        dev = lin[0].weight.device
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        ws = [m.weight.detach().float().contiguous() for m in lin]
+        bs = [m.bias.detach().float().contiguous() for m in lin]
+        _lib.check(_lib.lib().sdirt_mlp_pack((C.c_void_p * n)(*[w.data_ptr() for w in ws]),
+                                             (C.c_void_p * n)(*[b.data_ptr() for b in bs]),
+                                             widths, n, dptr(buf), stream_ptr(dev)))
+        self._pack_cache = (key, buf, widths)
+        return buf, widths
+
+    @torch.no_grad()
+    def forward_fused(self, inp, mirror=False):
+        """MLP.forward under fp16 autocast, all layers in one kernel with the activations held in
+        LDS (csrc/sdirt_mlp.hip).  inp [..., 3] fp32 on the GPU -> fp16 [..., ks, ks]; with
+        mirror=True -> [2, ..., ks, ks]: the network at (x, y, z) and at (-x, y, z), the two
+        passes of PSFNet.pred."""
+        if not inp.is_cuda:
+            raise _lib.SdirtError("forward_fused runs on the GPU only")
+        buf, widths = self._packed()
+        flat = inp.detach().reshape(-1, 3).to(torch.float32).contiguous()
+        n, of = flat.shape[0], int(widths[len(widths) - 1])
+        out = torch.empty(((2 if mirror else 1) * n, of), dtype=torch.float16, device=inp.device)
+        _lib.check(_lib.lib().sdirt_psfnet_mlp(dptr(buf), widths, len(widths) - 1, dptr(flat), n,
+                                               1 if mirror else 0, dptr(out), stream_ptr(inp.device)))
+        lead = tuple(inp.shape[:-1])
+        tail = (self.ks, self.ks) if self.ks * self.ks == of else (of,)
+        return out.reshape(((2,) if mirror else ()) + lead + tail)
 
 
 class _BilinearUp(nn.Module):

@@ -218,3 +218,52 @@ def test_psfnet_render_kernel_equals_pred_then_render(shape):
     # identical arithmetic except reciprocal-multiply vs divide before the fp16 rounding of a tap
     assert (rl - el).abs().max().item() <= 1e-3 and (rr - er).abs().max().item() <= 1e-3
     assert ((rl == el).float().mean().item() > 0.7) and ((rr == er).float().mean().item() > 0.7)
+
+
+def _emulate_autocast_mlp(net, x):
+    """Linear + ReLU chain as fp16 autocast computes it: fp16 operands, fp32 sums, fp16 results."""
+    h = x.half()
+    for m in net.net:
+        if isinstance(m, torch.nn.Linear):
+            h = (h.float() @ m.weight.half().float().t() + m.bias.float())
+        else:
+            h = torch.relu(h).half()
+    return h
+
+
+@pytest.mark.parametrize("h4,layers,out,n", [(128, 8, 441, 1000), (32, 1, 25, 77), (64, 2, 512, 256),
+                                              (96, 3, 121, 129)])
+def test_fused_mlp_kernel_equals_the_layer_by_layer_network(h4, layers, out, n):
+    """sdirt_psfnet_mlp (all layers in one kernel, activations in LDS, MFMA) against the same
+    arithmetic done layer by layer in torch, with and without the mirrored second pass."""
+    from sdirt_amd.psfnet_arch import MLP
+    torch.manual_seed(h4 + n)
+    net = MLP(3, out, hidden_features=512, hidden_layers=layers)
+    net.net[0] = torch.nn.Linear(3, h4)
+    net.net[2] = torch.nn.Linear(h4, 512)
+    torch.nn.init.kaiming_uniform_(net.net[0].weight); torch.nn.init.kaiming_uniform_(net.net[2].weight)
+    for m in net._linears():
+        torch.nn.init.uniform_(m.bias, -0.1, 0.1)
+    net = net.to(DEV)
+    assert net.fused_supported()
+    x = torch.rand(n, 3, device=DEV) * 2 - 1
+    ref = _emulate_autocast_mlp(net, x).float()
+    got = net.forward_fused(x).reshape(n, out).float()
+    scale = ref.abs().max().item()
+    assert scale > 0
+    # same operands, same fp32 accumulation up to summation order: differences are single fp16
+    # roundings of the activations, amplified through the layers
+    assert (got - ref).abs().max().item() <= 4e-3 * scale, (got - ref).abs().max().item() / scale
+    assert ((got - ref).abs() <= 1e-3 * scale).float().mean().item() > 0.999
+    both = net.forward_fused(x, mirror=True).reshape(2, n, out).float()
+    assert torch.equal(both[0], got)
+    xm = x.clone(); xm[:, 0] = -xm[:, 0]
+    assert torch.equal(both[1], net.forward_fused(xm).reshape(n, out).float())
+    # and against the stock autocast forward (hipBLASLt): same tolerance class
+    with torch.autocast("cuda", dtype=torch.float16):
+        auto = net.net(x).float()
+    assert (got - auto).abs().max().item() <= 4e-3 * scale
+    # repacking follows weight updates
+    with torch.no_grad():
+        net.net[-2].bias.add_(1.0)
+    assert (net.forward_fused(x).reshape(n, out).float() - got).abs().max().item() > 0.5

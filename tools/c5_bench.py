@@ -46,10 +46,14 @@ with torch.no_grad():
     psf = m.pred(o.clone())
     t_conv = timed(lambda: local_psf_render_fast(img, psf, ks))
     t_all = timed(lambda: m.render(img, depth, foc))
+    t_fmlp = timed(lambda: m.psfnet.forward_fused(o, mirror=True))
+    m.fused_mlp = False
+    t_gemm = timed(lambda: m.render(img, depth, foc))
     m.fused_render = False
     t_chain = timed(lambda: m.render(img, depth, foc))
 macs = 3 * 128 + 128 * 512 + 8 * 512 * 512 + 512 * ks * ks
 fl = 2 * macs * H * W
 print(f"psf dtype {psf.dtype}; one network pass {t_net:.2f} ms ({fl / t_net / 1e9:.0f} TFLOP/s); "
-      f"pred (L+R, normalise) {t_pred:.2f} ms; convolution {t_conv:.2f} ms; render total {t_all:.2f} ms (op-by-op chain {t_chain:.2f} ms) "
+      f"pred (L+R, normalise) {t_pred:.2f} ms; convolution {t_conv:.2f} ms; fused MLP both passes {t_fmlp:.2f} ms ({2 * fl / t_fmlp / 1e9:.0f} TFLOP/s); "
+      f"render total {t_all:.2f} ms (torch.nn layers + fused conv {t_gemm:.2f} ms, op-by-op chain {t_chain:.2f} ms) "
       f"-> {1e3 / t_all:.1f} frames/s")
