@@ -7,12 +7,12 @@
 // and keeps their activations in LDS for the whole network:
 //
 //   X  (LDS, 128 rows x 512 features fp16, row stride 1040 B -> conflict-free ds_read_b128)
-//   wave w of 4 computes output features [128 w, 128 w + 128) of every layer for all 128 rows:
-//   16 accumulator tiles of v_mfma_f32_32x32x16_f16 (A = weights, B = X^T), 256 registers;
+//   wave w of 4 computes output features [128 w, 128 w + 128) of every layer for all 128 rows
+//   with v_mfma_f32_32x32x16_f16 (A = weights, B = X^T), 32 features x 128 rows at a time;
 //   A fragments come straight from L2 (weights pre-packed in fragment order: one contiguous
 //   1 KB block per (32 outputs x 16 inputs) tile, 16 B per lane), B fragments from LDS;
-//   epilogue per layer: + bias, ReLU, round to fp16 (what autocast's Linear + ReLU produce),
-//   barrier, overwrite X in place, barrier.
+//   per layer: bias as the C operand, ReLU, round to fp16 (what autocast's Linear + ReLU
+//   produce) hidden behind the next group's MFMAs, barrier, overwrite X in place, barrier.
 //
 // HBM traffic per row: 12 B in, ks*ks*2 B out.  Weights are re-read from L2 once per 128 rows.
 #include <hip/hip_runtime.h>
@@ -51,82 +51,179 @@ __device__ __forceinline__ f16v mfma(h8 a, h8 b, f16v c)
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 
-// One layer for one wave: features [out_col0, out_col0 + 32 MT) of all 128 rows.
-//   wfrag  this wave's first weight tile, [MT][ksn][64 lanes] fragments;  ksn  k-steps of 16 inputs
-template <int MT>
-__device__ __forceinline__ void layer(const h8* __restrict__ wfrag, const float* __restrict__ bias,
-                                      int ksn, _Float16* X, int lane, int out_col0)
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+
+// ReLU of two fp32 values rounded to fp16 (RNE), as one packed register.  max after the
+// rounding equals rounding after the max; on the packed pair it is one instruction for two values.
+__device__ __forceinline__ h2 relu_pack(float lo, float hi)
 {
+    h2 v = {(_Float16)lo, (_Float16)hi};
+    h2 r;
+    asm("v_pk_max_f16 %0, %1, 0" : "=v"(r) : "v"(v));
+    return r;
+}
+
+// One layer for one wave: output features [out_col0, out_col0 + 32 MT) of all 128 rows.
+//   wfrag  this wave's first weight tile, [MT][KS][64 lanes] fragments;  KS  k-steps of 16 inputs
+// The wave's MT output tiles m are computed ONE AFTER THE OTHER (4 accumulators of 32 features x
+// 128 rows at a time) as a single stream of MT * KS steps t = KS m + ks: the weight fragments are
+// consecutive in memory in exactly that order (D of them in flight), the X fragments repeat every
+// KS steps.  While group m multiplies, the finished accumulators of group m - 1 are read back,
+// rounded to fp16 and clamped, so that this arithmetic hides behind MFMAs; only the last group's
+// conversion is exposed.  The bias is the C operand of a group's first MFMAs.
+//
+// Issue order is written out by hand and pinned (sched_barrier after every piece): one step is
+//   MFMA n=0 | weight fetch for step t+D (+ one bias quad of the next group near a group's end)
+//   MFMA n=1 | X fragments n = 0, 1 of step t+BD
+//   MFMA n=2 | X fragments n = 2, 3 of step t+BD
+//   MFMA n=3 | half a quad of the previous group's conversion (4 VALU)
+// An MFMA occupies the matrix pipe for 32 cycles but the issue port for 8: up to ~5 cheap
+// instructions fit in its shadow.  Bunched at the step boundary instead (what the compiler does
+// when left alone, or when only the loads are fenced) the same instructions stretch one gap in
+// four to 80-100 cycles and the pipe idles a third of the time.
+// Fully unrolled: every register index is static.
+//   flat_of > 0 (last layer): the results go to X as the dense row-major image [128][flat_of]
+//   that the output tile has in global memory, so that it leaves with aligned 16-byte copies.
+//   wnext (optional): where this wave's weight stream continues in the NEXT layer; its first
+//   fragments are fetched during this layer's last steps, into the ring that the next call
+//   receives primed, so that a layer does not start by waiting out an L2 round trip.
+#define SDIRT_PIN() __builtin_amdgcn_sched_barrier(0)
+template <int KS, int MT, int AD = 6, int BD = 2>
+__device__ __forceinline__ void layer(const h8* __restrict__ wfrag, const float* __restrict__ bias,
+                                      _Float16* X, int lane, int out_col0, int flat_of = 0,
+                                      const h8* __restrict__ wnext = nullptr, h8* ring = nullptr,
+                                      bool primed = false)
+{
+    constexpr int T = MT * KS, D = T < AD ? T : AD;
+    constexpr int BR = BD + 1;                           // ring of X fragment sets
+    constexpr bool OVERLAP = KS >= 32;                   // 32 half-quads over a group's steps
     const int r = lane & 31, h = lane >> 5;
-    f16v acc[MT][4];
+    const h8* wl = wfrag + lane;
+    const _Float16* xl = X + r * kXStride + 8 * h;
+    const float* bl = bias + 4 * h;
+    h2 packed[MT][4][4][2];                              // [m][n][g] -> 4 halves
+    f16v acc[4], done[4];
+    f4v bq[4];                                           // bias of the group about to start
+    h8 a[D], b[BR][4];
+    if (primed) {
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+        for (int d = 0; d < D; ++d) a[d] = ring[d];
+    } else {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
+        for (int d = 0; d < D; ++d) a[d] = wl[d * 64];
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bq[g] = *reinterpret_cast<const f4v*>(bl + 8 * g);
+#pragma unroll
+    for (int d = 0; d < BD; ++d)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+            if (d < T) b[d][n] = *reinterpret_cast<const h8*>(xl + 32 * n * kXStride + 16 * (d % KS));
+    SDIRT_PIN();
+#pragma clang loop unroll(full)
+    for (int t = 0; t < T; ++t) {
+        const int m = t / KS, ks = t % KS;
+        const h8 at = a[t % D];
+        f16v c0[4];
+        if (ks == 0) {
             // accumulator register 4 g + i of a lane holds output row 8 g + 4 h + i of the tile
-            const f4v bv = *reinterpret_cast<const f4v*>(bias + 32 * m + 8 * g + 4 * h);
+            f16v bv;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bv[4 * g + i] = bq[g][i];
+#pragma unroll
+            for (int n = 0; n < 4; ++n) c0[n] = bv;
+        } else {
+#pragma unroll
+            for (int n = 0; n < 4; ++n) c0[n] = acc[n];
+        }
+        // ---- MFMA 0 | weights (and bias) ----
+        acc[0] = mfma(at, b[t % BR][0], c0[0]);
+        if (t + D < T) a[t % D] = wl[(t + D) * 64];
+        else if (wnext) a[t % D] = wnext[lane + (t + D - T) * 64];
+        if (m + 1 < MT && KS >= 4 && ks >= KS - 4) {
+            const int g = ks - (KS - 4);
+            bq[g] = *reinterpret_cast<const f4v*>(bl + 32 * (m + 1) + 8 * g);
+        } else if (m + 1 < MT && KS < 4 && ks == KS - 1) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bq[g] = *reinterpret_cast<const f4v*>(bl + 32 * (m + 1) + 8 * g);
+        }
+        SDIRT_PIN();
+        // ---- MFMA 1 | X fragments 0, 1 ----
+        acc[1] = mfma(at, b[t % BR][1], c0[1]);
+        if (t + BD < T) {
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+                b[(t + BD) % BR][n] =
+                    *reinterpret_cast<const h8*>(xl + 32 * n * kXStride + 16 * ((t + BD) % KS));
+        }
+        SDIRT_PIN();
+        // ---- MFMA 2 | X fragments 2, 3 ----
+        acc[2] = mfma(at, b[t % BR][2], c0[2]);
+        if (t + BD < T) {
+#pragma unroll
+            for (int n = 2; n < 4; ++n)
+                b[(t + BD) % BR][n] =
+                    *reinterpret_cast<const h8*>(xl + 32 * n * kXStride + 16 * ((t + BD) % KS));
+        }
+        SDIRT_PIN();
+        // ---- MFMA 3 | half a quad of the previous group ----
+        acc[3] = mfma(at, b[t % BR][3], c0[3]);
+        if (OVERLAP && m > 0) {
+            const int q = ks / 2, n = q / 4, g = q % 4, half = ks & 1;
+            packed[m - 1][n][g][half] = relu_pack(done[n][4 * g + 2 * half], done[n][4 * g + 2 * half + 1]);
+        }
+        SDIRT_PIN();
+        if (ks == KS - 1) {
+#pragma unroll
+            for (int n = 0; n < 4; ++n) done[n] = acc[n];
+            if (m == MT - 1 || !OVERLAP) {
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        packed[m][n][g][0] = relu_pack(done[n][4 * g + 0], done[n][4 * g + 1]);
+                        packed[m][n][g][1] = relu_pack(done[n][4 * g + 2], done[n][4 * g + 3]);
+                    }
+            }
+        }
+    }
+    if (ring) {
+        // step T + d of the stream sits in slot (T + d) % D; hand the ring over in step order
+#pragma unroll
+        for (int d = 0; d < D; ++d) ring[d] = a[(T + d) % D];
+    }
+    __syncthreads();                       // every wave has finished reading X
+    if (flat_of > 0) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int n = 0; n < 4; ++n)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[m][n][4 * g + i] = bv[i];
-        }
-    const h8* wl = wfrag + lane;
-    const _Float16* xl = X + r * kXStride + 8 * h;
-    const int mstride = ksn * 64;
-    h8 a0[MT], a1[MT], b0[4], b1[4];
+                for (int g = 0; g < 4; ++g) {
+                    const int f = out_col0 + 32 * m + 8 * g + 4 * h;
+                    _Float16* dst = X + (32 * n + r) * flat_of + f;
 #pragma unroll
-    for (int m = 0; m < MT; ++m) a0[m] = wl[m * mstride];
-#pragma unroll
-    for (int n = 0; n < 4; ++n) b0[n] = *reinterpret_cast<const h8*>(xl + 32 * n * kXStride);
-    // two k-steps per trip, the operands of one fetched while the other multiplies; straight-line
-    // bodies only (a branch around an MFMA group makes the compiler shuttle all 256
-    // accumulators between register files at every trip).  ksn is even (MT == 4) or 1 (MT == 1).
-#define SDIRT_LOAD(A, B, KSTEP)                                                                  \
-    do {                                                                                         \
-        _Pragma("unroll") for (int m = 0; m < MT; ++m) A[m] = wl[m * mstride + (KSTEP) * 64];    \
-        _Pragma("unroll") for (int n = 0; n < 4; ++n)                                            \
-            B[n] = *reinterpret_cast<const h8*>(xl + 32 * n * kXStride + 16 * (KSTEP));          \
-        /* keep the fetches of the NEXT step ahead of this step's MFMAs: left alone, the   */    \
-        /* scheduler sinks each load to just before its use and waits out the L2 latency */      \
-        __builtin_amdgcn_sched_barrier(0);                                                       \
-    } while (0)
-#define SDIRT_MFMA(A, B)                                                                         \
-    do {                                                                                         \
-        _Pragma("unroll") for (int m = 0; m < MT; ++m)                                           \
-            _Pragma("unroll") for (int n = 0; n < 4; ++n) acc[m][n] = mfma(A[m], B[n], acc[m][n]); \
-        __builtin_amdgcn_sched_barrier(0);                                                       \
-    } while (0)
-    if (MT == 1) {                         // the 3 -> h4 layer: a single k-step
-        SDIRT_MFMA(a0, b0);
+                    for (int i = 0; i < 4; ++i)
+                        if (f + i < flat_of) dst[i] = packed[m][n][g][i >> 1][i & 1];
+                }
     } else {
-        for (int ks = 0; ks < ksn - 2; ks += 2) {
-            SDIRT_LOAD(a1, b1, ks + 1);
-            SDIRT_MFMA(a0, b0);
-            SDIRT_LOAD(a0, b0, ks + 2);
-            SDIRT_MFMA(a1, b1);
-        }
-        SDIRT_LOAD(a1, b1, ksn - 1);
-        SDIRT_MFMA(a0, b0);
-        SDIRT_MFMA(a1, b1);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    struct alignas(8) Pair { h2 lo, hi; } pr{packed[m][n][g][0], packed[m][n][g][1]};
+                    *reinterpret_cast<Pair*>(X + (32 * n + r) * kXStride + out_col0 + 32 * m + 8 * g + 4 * h) = pr;
+                }
     }
-#undef SDIRT_LOAD
-#undef SDIRT_MFMA
-    __syncthreads();                       // every wave has finished reading X
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int n = 0; n < 4; ++n)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                h4 v;
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    v[i] = (_Float16)fmaxf(acc[m][n][4 * g + i], 0.0f);
-                *reinterpret_cast<h4*>(X + (32 * n + r) * kXStride + out_col0 + 32 * m + 8 * g + 4 * h) = v;
-            }
     __syncthreads();
 }
+#undef SDIRT_PIN
 
+template <int AD, int BD>
 __global__ void __launch_bounds__(kThreads, 1)
 k_psfnet_mlp(MlpShape shape, const h8* __restrict__ wpk, const float* __restrict__ bpk,
              const float* __restrict__ inp, int64_t n_points, int mirror, _Float16* __restrict__ out)
@@ -156,34 +253,41 @@ k_psfnet_mlp(MlpShape shape, const h8* __restrict__ wpk, const float* __restrict
         const h8* w = wpk;
         const float* b = bpk;
         // 3 -> h4: one 32-feature tile per wave while h4 allows
-        if (32 * wave < h4) layer<1>(w + wave * 64, b + 32 * wave, 1, X, lane, 32 * wave);
+        if (32 * wave < h4) layer<1, 1>(w + wave * 64, b + 32 * wave, X, lane, 32 * wave);
         else { __syncthreads(); __syncthreads(); }
         w += 128 / 32 * 64;                       // first layer: 128 rows x 16 columns
         b += 128;
         // h4 -> 512, (512 -> 512) x L, 512 -> out (rows zero-padded to 512)
         int ksn = h4 / 16;
+        h8 ring[AD];
+        bool primed = false;
         for (int l = 1; l < shape.n_layers; ++l) {
-            if (l + 1 < shape.n_layers || 128 * wave < of)
-                layer<4>(w + 4 * wave * ksn * 64, b + 128 * wave, ksn, X, lane, 128 * wave);
-            else { __syncthreads(); __syncthreads(); }
+            const h8* wt = w + 4 * wave * ksn * 64;
+            const float* bt = b + 128 * wave;
+            const bool last = l + 1 == shape.n_layers;
+            // the next layer's stream of this wave (a wave idle in the last layer skips it)
+            const h8* wn = (!last && !(l + 2 == shape.n_layers && 128 * wave >= of))
+                               ? w + 16 * ksn * 64 + 4 * wave * 32 * 64 : nullptr;
+            if (last && 128 * wave >= of) { __syncthreads(); __syncthreads(); }
+            else if (ksn == 32) {
+                layer<32, 4, AD, BD>(wt, bt, X, lane, 128 * wave, last ? of : 0, wn, ring, primed);
+                primed = wn != nullptr;
+            }
+            else if (ksn == 8) layer<8, 4>(wt, bt, X, lane, 128 * wave);
+            else if (ksn == 6) layer<6, 4>(wt, bt, X, lane, 128 * wave);
+            else if (ksn == 4) layer<4, 4>(wt, bt, X, lane, 128 * wave);
+            else layer<2, 4>(wt, bt, X, lane, 128 * wave);
             w += 16 * ksn * 64;                   // 512 output rows of this layer
             b += kHid;
             ksn = kHid / 16;
         }
-        // X[row][0 .. of) -> out[row0 + row][0 .. of): one contiguous run of rows * of halves
+        // X now holds the tile as it lies in global memory: rows * of contiguous halves, starting
+        // 16-byte aligned because row0 is a multiple of 128 and the host checks `out`
         const int64_t valid = std::min<int64_t>(kRows, n_rows - row0);
         const int total = (int)valid * of;
         _Float16* dst = out + row0 * of;
-        // 16-byte aligned because row0 is a multiple of 128 and the host checks `out`
-        for (int i8 = threadIdx.x; i8 * 8 < total; i8 += kThreads) {
-            const int i0 = i8 * 8;
-            h8 v;
-            int row = i0 / of, col = i0 - row * of;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                v[j] = (i0 + j < total) ? X[row * kXStride + col] : (_Float16)0;
-                if (++col == of) { col = 0; ++row; }
-            }
+        for (int i0 = threadIdx.x * 8; i0 < total; i0 += kThreads * 8) {
+            const h8 v = *reinterpret_cast<const h8*>(X + i0);
             if (i0 + 8 <= total) *reinterpret_cast<h8*>(dst + i0) = v;
             else
                 for (int j = 0; i0 + j < total; ++j) dst[i0 + j] = v[j];
@@ -294,15 +398,15 @@ int sdirt_psfnet_mlp(const void* packed, const int32_t* widths, int32_t n_layers
     const float* b = reinterpret_cast<const float*>(static_cast<const char*>(packed) +
                                                     weights_bytes(widths, n_layers));
     const size_t lds = sizeof(_Float16) * kRows * kXStride;           // 133,120 B
-    HIP_TRY(hipFuncSetAttribute((const void*)k_psfnet_mlp, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds));
+    auto kern = k_psfnet_mlp<6, 2>;      // 6 weight fragments, 2 sets of X fragments in flight
+    HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int dev = 0, cus = 256;
     HIP_TRY(hipGetDevice(&dev));
     HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     const int64_t rows = n_points * (mirror ? 2 : 1);
     const int64_t tiles = (rows + kRows - 1) / kRows;
     const int grid = (int)std::min<int64_t>(tiles, cus);
-    k_psfnet_mlp<<<grid, kThreads, lds, as_stream(stream)>>>(shape, w, b, inp, n_points, mirror ? 1 : 0,
+    kern<<<grid, kThreads, lds, as_stream(stream)>>>(shape, w, b, inp, n_points, mirror ? 1 : 0,
                                                             static_cast<_Float16*>(out));
     LAUNCH_CHECK();
     return SDIRT_OK;
