@@ -314,9 +314,13 @@ class PSFNet(Lensgroup):
         depth = depth + self.d_sensor
         N, C, H, W = img.shape
         z = self.depth2z(depth).squeeze(1)
-        x, y = torch.meshgrid(torch.linspace(-1, 1, W), torch.linspace(1, -1, H), indexing="xy")
-        x = x.unsqueeze(0).repeat(N, 1, 1).to(img.device)
-        y = y.unsqueeze(0).repeat(N, 1, 1).to(img.device)
+        key = (N, H, W, str(img.device))
+        if getattr(self, "_render_grid", (None,))[0] != key:
+            # the reference rebuilds this grid on the host at every call (psfnet.py:682-688)
+            x, y = torch.meshgrid(torch.linspace(-1, 1, W), torch.linspace(1, -1, H), indexing="xy")
+            self._render_grid = (key, x.unsqueeze(0).repeat(N, 1, 1).to(img.device),
+                                 y.unsqueeze(0).repeat(N, 1, 1).to(img.device))
+        _, x, y = self._render_grid
         o = torch.stack((x, y, z), -1).float()
         if img.is_cuda and self.fused_render:
             # one GEMM chain over [(x,y,z); (-x,y,z)], then flip + normalise + convolve in one
