@@ -134,11 +134,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--no-gather", action="store_true",
-                    help="skip the all-gather of the PSF shards (N > 1)")
+    ap.add_argument("--gather", action="store_true",
+                    help="N > 1: also all-gather the PSF shards to every rank (RCCL, on a side "
+                         "stream under the next step's kernels).  Off by default: point sources "
+                         "are independent, the path itself has no exchange step")
+    ap.add_argument("--no-gather", action="store_true", help="(default; kept for older scripts)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2")
     args = ap.parse_args()
+    args.no_gather = not args.gather
     global KS, SPP, GRID_Z
     wl = WORKLOADS[args.workload]
     KS, SPP = wl["ks"], wl["spp"]
@@ -265,6 +269,9 @@ def main():
                        "name": args.workload,
                        "points_per_gpu": n_local, "spp": SPP, "ks": KS,
                        "parallelism": f"points sharded over {world} GPU(s)"
+                                      + ("" if world == 1 else
+                                         ", shared pupil samples (48 KB broadcast) and batch-global "
+                                         "Newton trip check (mask all-reduce) per step")
                                       + ("" if world == 1 or args.no_gather
                                          else " + RCCL all-gather of the PSF volume"),
                        "newton_trip_policy": lens.trip_policy,
