@@ -193,12 +193,24 @@ def main():
 
     gather_done = [None, None]      # per buffer set: event of the last gather that read it
 
+    in_flight = [None]
+
+    def settle():
+        """Newton trip check of the step whose kernel was enqueued last (lens.psf_lr(defer=True))."""
+        if in_flight[0] is not None:
+            in_flight[0].wait()
+            in_flight[0] = None
+
     def step():
         idx = step_no[0] % 2
         out = out_bufs[idx]
         if world == 1:
+            # keep one step in flight: the GPU starts step i+1 while the host verifies step i
             step_no[0] += 1
-            return lens.psf_lr(points_local, ks=KS, spp=SPP, dp=DP, out=out)
+            pending = lens.psf_lr(points_local, ks=KS, spp=SPP, dp=DP, out=out, defer=True)
+            settle()
+            in_flight[0] = pending
+            return out
         if gather_done[idx] is not None:
             # the gather of two steps ago still reads these tensors on the comm stream
             torch.cuda.current_stream(device).wait_event(gather_done[idx])
@@ -219,6 +231,7 @@ def main():
         return L, R
 
     def fence():
+        settle()
         torch.cuda.synchronize(device)          # all streams of the device, the gather one too
         if world > 1:
             dist.barrier()

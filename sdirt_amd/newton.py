@@ -120,15 +120,17 @@ class TripPlanner:
             trips = new
         raise RuntimeError("Newton trip-table speculation did not converge")  # pragma: no cover
 
-    def run_many(self, keys, curved, order, launch, max_rounds=None):
+    def run_many(self, keys, curved, order, launch, max_rounds=None, first=None):
         """Several independent passes verified in ONE launch/readback round (the chief-ray pass
         and the primary pass of a psf call).  launch(list_of_trip_tables) -> list of mask
-        arrays, one per key.  All passes are re-launched together when any table was wrong."""
+        arrays, one per key.  All passes are re-launched together when any table was wrong.
+        first = (tables, masks): a round that was already launched with `tables` (speculated by
+        `initial`) and has reported `masks` -- deferred verification, see Lensgroup.psf_lr."""
         K = len(curved)
-        tables = [self.initial(k, curved) for k in keys]
+        tables = [self.initial(k, curved) for k in keys] if first is None else first[0]
         rounds = max_rounds if max_rounds is not None else 2 * K + 2
-        for _ in range(rounds):
-            masks = launch(tables)
+        for i in range(rounds):
+            masks = first[1] if (first is not None and i == 0) else launch(tables)
             self.launches += 1
             results = [verify(t, m, order, curved) for t, m in zip(tables, masks)]
             if all(ok for ok, _ in results):

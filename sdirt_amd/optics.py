@@ -72,6 +72,19 @@ class _EventBracket:
         return False
 
 
+class PendingPSF:
+    """A psf_lr call whose kernel is enqueued and whose Newton trip check is still due."""
+
+    def __init__(self, finish):
+        self._finish, self._result = finish, None
+
+    def wait(self):
+        if self._finish is not None:
+            self._result = self._finish()
+            self._finish = None
+        return self._result
+
+
 class Lensgroup:
     """optics.py:22-116.  `device` must be a CUDA (ROCm) device for anything that traces."""
 
@@ -448,7 +461,7 @@ class Lensgroup:
     @torch.no_grad()
     def psf_lr(self, points, ks=31, wvln=DEFAULT_WAVE, spp=GEO_SPP, center=True,
                dp=(0.78, 1.44, 0.3, 0.5), normalize=True, want_r=True, _default_r_zero=False,
-               pupil_xy=None, center_pupil_xy=None, out=None):
+               pupil_xy=None, center_pupil_xy=None, out=None, defer=False):
         """Left AND right dual-pixel PSFs of one ray-traced batch: (L, R), each
         [N,ks,ks] (or [ks,ks] for a single point), max-normalised separately as
         optics.py:983-987 would normalise each of them.  dp = (h, f, w, r) of
@@ -461,7 +474,13 @@ class Lensgroup:
 
         out: optional (L, R) float32 CUDA tensors [N,ks,ks] to write into -- a consumer
         that renders batch after batch (PSFNet fitting) re-uses its buffers instead of
-        asking the caching allocator for two 277 MB blocks per call."""
+        asking the caching allocator for two 277 MB blocks per call.
+
+        defer=True (center=True only): enqueue the kernel with the speculated Newton trip tables
+        and return a `PendingPSF` at once; its `.wait()` reads the convergence masks back,
+        verifies them (re-launching in the rare case the speculation was wrong) and returns
+        (L, R).  A caller that renders batch after batch keeps one call in flight -- the GPU
+        starts batch i+1 while the host checks batch i -- without giving up the check."""
         self._require_gpu()
         if not torch.is_tensor(points):
             points = torch.tensor(points)
@@ -516,8 +535,10 @@ class Lensgroup:
             # one C call -- one kernel launch when a workgroup owns a point -- and ONE
             # verification round for both trip tables
             handle_c = self.dev_lens(DEFAULT_WAVE)
-            anyv = torch.zeros(1, dtype=torch.int32, device=self.device)
-            masks = torch.zeros((2, _lib.MAX_SURFACES), dtype=torch.int32, device=self.device)
+            MS = _lib.MAX_SURFACES
+            # one control block: [primary masks | chief-ray masks | any-valid flag] -> one readback
+            ctl = torch.zeros(2 * MS + 1, dtype=torch.int32, device=self.device)
+            masks, anyv = ctl[:2 * MS].view(2, MS), ctl[2 * MS:]
             reference = self.trip_policy == "reference"
 
             def enqueue2(tp, tc):
@@ -530,23 +551,61 @@ class Lensgroup:
                         dptr(L), dptr(R), dptr(masks[0]) if reference else None,
                         dptr(masks[1]) if reference else None, stream_ptr(self.device)))
 
+            def squeeze(L_, R_):
+                if R_ is None and want_r:
+                    R_ = torch.zeros_like(L_)
+                if single_point:
+                    L_ = L_.squeeze(0)
+                    R_ = R_.squeeze(0) if R_ is not None else None
+                return L_, R_
+
             if reference:
-                def launch(tables):
-                    masks.zero_()
-                    anyv.zero_()
+                keys = [("psf", wkey, self.precision), ("center", self.precision)]
+                keep = (po, x2, y2, xc, yc, cen)              # alive until the kernel has run
+
+                def enqueue_round(tables):
+                    ctl.zero_()
                     enqueue2(tables[0], tables[1])
-                    m = masks[:, :K]
                     if self.mask_reduce is not None:
-                        m = self.mask_reduce(m.reshape(-1)).reshape(2, K)
-                    m = m.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+                        masks[:, :K] = self.mask_reduce(masks[:, :K].reshape(-1)).reshape(2, K)
+
+                def read_masks(host):
+                    m = host[:2 * MS].reshape(2, MS)[:, :K].astype(np.int64) & 0xFFFFFFFF
                     return [m[0], m[1]]
-                self.trips.run_many([("psf", wkey, self.precision), ("center", self.precision)],
-                                    self._curved(), list(range(K)), launch)
-                assert int(anyv.item()) == 1, "No sampled rays is valid."   # optics.py:902
+
+                def launch(tables):
+                    enqueue_round(tables)
+                    host = ctl.cpu().numpy()
+                    launch.any_valid = int(host[2 * MS])
+                    return read_masks(host)
+
+                if defer:
+                    tables = [self.trips.initial(k, self._curved()) for k in keys]
+                    enqueue_round(tables)
+                    host = torch.empty(ctl.shape, dtype=ctl.dtype, pin_memory=True)
+                    host.copy_(ctl, non_blocking=True)
+                    done = torch.cuda.Event()
+                    done.record(torch.cuda.current_stream(self.device))
+
+                    def finish():
+                        done.synchronize()
+                        h = host.numpy()
+                        launch.any_valid = int(h[2 * MS])
+                        self.trips.run_many(keys, self._curved(), list(range(K)), launch,
+                                            first=(tables, read_masks(h)))
+                        assert launch.any_valid == 1, "No sampled rays is valid."   # optics.py:902
+                        return squeeze(L, R) if keep else None
+                    return PendingPSF(finish)
+                self.trips.run_many(keys, self._curved(), list(range(K)), launch)
+                assert launch.any_valid == 1, "No sampled rays is valid."   # optics.py:902
             else:
                 full = np.where(self._curved(), NEWTON_MAXITER, 0)
                 enqueue2(full, full)
+            if defer:
+                return PendingPSF(lambda: squeeze(L, R))
         else:
+            if defer:
+                raise ValueError("defer=True needs center=True")
             def enqueue(trips, mask_ptr):
                 with self._timed("psf_lr"):
                     _lib.check(_lib.lib().sdirt_psf_lr(

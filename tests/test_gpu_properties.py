@@ -278,3 +278,34 @@ def test_lean_math_is_exact():
     assert run(0, 0x80000000, 1) == 0 and run(0, 0xBF800000, 1) == 0   # -0, -1 -> NaN
     assert run(1, 0, 1 << 36, 40) == 0
     assert run(2, 0x123456789AB, 1 << 36) == 0
+
+
+def test_deferred_trip_check_equals_the_immediate_one():
+    """psf_lr(defer=True): same PSFs, same verified trip tables, also when the speculated table
+    is wrong for the batch (forced here by poisoning the planner's memory)."""
+    lens = make_lens("rf50mm", DEV)
+    g = load_golden("f8_rf50_mini_c2")
+    pts = torch.tensor(g["points"])
+    kw = dict(ks=33, spp=512, pupil_xy=(g["pupil_x2"][:512], g["pupil_y2"][:512]),
+              center_pupil_xy=(g["pupil_xc"], g["pupil_yc"]))
+    L0, R0 = lens.psf_lr(pts, **kw)
+    tabs = {k: v.copy() for k, v in lens.trips.cache.items()}
+    p1 = lens.psf_lr(pts, defer=True, **kw)
+    p2 = lens.psf_lr(pts[:5], defer=True, **kw)             # two calls in flight
+    L1, R1 = p1.wait()
+    assert p1.wait()[0] is L1                                # idempotent
+    L2, _ = p2.wait()
+    assert torch.allclose(L0, L1, atol=2e-6) and torch.allclose(R0, R1, atol=2e-6)
+    assert torch.allclose(L0[:5], L2, atol=2e-6)
+    # wrong speculation: one trip short on a curved surface of both passes
+    for k in list(lens.trips.cache):
+        bad = lens.trips.cache[k].copy()
+        bad[1] = max(1, bad[1] - 1)
+        lens.trips.cache[k] = bad
+        lens.trips.votes[k] = {tuple(int(x) for x in bad): 99}
+    before = lens.trips.relaunches
+    L3, R3 = lens.psf_lr(pts, defer=True, **kw).wait()
+    assert lens.trips.relaunches > before
+    assert torch.allclose(L0, L3, atol=2e-6) and torch.allclose(R0, R3, atol=2e-6)
+    for k, v in tabs.items():
+        assert np.array_equal(lens.trips.cache[k], v), k
