@@ -264,11 +264,22 @@ def main():
         alg_bytes = n_local * (12 + 8) + (SPP + 2048) * 8 + 2 * n_local * KS * KS * 4
         dom = "psf_lr_centered" if "psf_lr_centered" in k_ms else "psf_lr"
         ach = alg_bytes / (k_ms[dom] * 1e-3) / 1e9
-        traffic = None
+        traffic = valu = None
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
         if os.path.exists(pmc) and args.workload == "c2":
             with open(pmc) as f:
-                traffic = json.load(f).get("k_psf_lr_hbm_bytes_per_launch")
+                counters = json.load(f)
+            traffic = counters.get("k_psf_lr_hbm_bytes_per_launch")
+            n_instr = counters.get("k_psf_lr_valu_wave_instructions_per_launch")
+            if n_instr:
+                # what actually bounds the kernel: vector-instruction issue.  Peak = one full-rate
+                # wave64 instruction per 2 cycles per SIMD (1024 SIMDs, 2.4 GHz); quarter-rate
+                # instructions (v_rcp / v_sqrt, ~6 % of the mix) make the reachable figure lower.
+                peak = 1024 * 2.4e9 / 2
+                valu = {"wave_instructions_per_launch": n_instr,
+                        "achieved_per_s": n_instr / (k_ms[dom] * 1e-3), "peak_per_s": peak,
+                        "frac": n_instr / (k_ms[dom] * 1e-3) / peak,
+                        "source": "SQ_INSTS_VALU, profiles/r01/summary_g_single_launch.json"}
         res = {
             "metric": f"rays/sec {wl['lens']} {KS}x{KS} DP-PSF @{SPP}spp", "value": rays / dt,
             "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -294,7 +305,7 @@ def main():
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "k_psf_lr<R,small-r,Lean,CENTER> (chief-ray pass + primary pass "
                                    "of a point in one workgroup)",
-                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "algorithmic_bytes_per_launch": alg_bytes, "valu_issue": valu,
                          "note": "scalar-per-ray fp32 math: the kernel is VALU-bound by "
                                  "construction (~6.4 k VALU instr/ray vs 8.25 B/ray), DESIGN.md §3"},
         }

@@ -230,10 +230,15 @@ class PSFNet(Lensgroup):
         sensor's mirror symmetry, for the right one as fliplr of the kernel at (-x, y, z);
         each (L, R) pair is normalised by its joint sum.  inp [..., 3] -> [..., 2, ks, ks].
         As in the reference, `inp[..., 0]` is negated in place."""
-        mirrored = inp.clone()
-        mirrored[..., 0] = mirrored[..., 0] * (-1)
-        both = self.psfnet(torch.stack((inp, mirrored)))          # one GEMM chain for L and R
-        inp[..., 0] = mirrored[..., 0]
+        if (inp.is_cuda and self.fused_mlp and not torch.is_grad_enabled()
+                and getattr(self.psfnet, "fused_supported", lambda: False)()):
+            both = self.psfnet.forward_fused(inp, mirror=True)    # one kernel for L and R
+            inp[..., 0] = inp[..., 0] * (-1)
+        else:
+            mirrored = inp.clone()
+            mirrored[..., 0] = mirrored[..., 0] * (-1)
+            both = self.psfnet(torch.stack((inp, mirrored)))      # one GEMM chain for L and R
+            inp[..., 0] = mirrored[..., 0]
         psf = torch.stack((both[0], torch.flip(both[1], dims=[-1])), dim=-3)
         psf = psf / (psf.sum(-1).sum(-1).unsqueeze(-1).unsqueeze(-1) + 1e-9)
         assert psf.shape[-1] == self.kernel_size

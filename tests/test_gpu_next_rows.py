@@ -267,3 +267,25 @@ def test_fused_mlp_kernel_equals_the_layer_by_layer_network(h4, layers, out, n):
     with torch.no_grad():
         net.net[-2].bias.add_(1.0)
     assert (net.forward_fused(x).reshape(n, out).float() - got).abs().max().item() > 0.5
+
+
+def test_pred_uses_the_fused_network_without_changing_results():
+    """PSFNet.pred under no_grad goes through sdirt_psfnet_mlp for the reference's architecture;
+    with gradients enabled it stays on the torch.nn layers; both agree to fp16 rounding."""
+    from sdirt_amd.psfnet import PSFNet
+    torch.manual_seed(3)
+    m = PSFNet(os.path.join(DATA, "rf50mm.json"), sensor_res=(512, 768), kernel_size=21, device=DEV,
+               post_computation=False)
+    with torch.no_grad():
+        m.psfnet.net[-2].bias.add_(0.05)
+    inp = torch.rand(1, 6, 9, 3, device=DEV)
+    inp[..., :2] = inp[..., :2] * 2 - 1
+    a = m.pred(inp.clone())                                   # grad mode: torch.nn layers
+    with torch.no_grad():
+        b = m.pred(inp.clone())                               # fused kernel
+        m.fused_mlp = False
+        c = m.pred(inp.clone())
+    assert a.shape == b.shape == (1, 6, 9, 2, 21, 21) and b.dtype == torch.float16
+    scale = c.float().abs().max().item()
+    assert (b.float() - c.float()).abs().max().item() < 1e-2 * scale
+    assert (a.float() - c.float()).abs().max().item() < 1e-2 * scale
