@@ -7,9 +7,10 @@ per point, 65x65 LEFT and RIGHT PSFs, lambda = 0.589 um.  One "step" = one
 Lensgroup.psf_lr call over the rank's 16384 points: draw the pupil uniforms
 (torch CPU generator, the reference's order), chief-ray centre pass (2048 rays
 per point) and the sample->trace->splat->normalise pass in ONE fused kernel launch,
-verification of the batch-global Newton trip counts, and -- for N > 1 -- the RCCL all-gather of the
-PSF shards.  Weak scaling: every rank renders its own 16384-point slab of a
-32x32x(16*N) volume.
+verification of the batch-global Newton trip counts (of step i while step i+1 runs).  For N > 1
+the ranks share the pupil sample set (48 KB broadcast) and the trip check (mask all-reduce);
+--gather adds the RCCL all-gather of the PSF shards.  Weak scaling: every rank renders its own
+16384-point slab of a 32x32x(16*N) volume.
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
@@ -29,6 +30,8 @@ import time
 # libgomp reads this when it initialises: idle OpenMP threads of the CPU-baseline
 # leg must sleep, not spin, inside a CPU-quota'd container
 os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+# the pool's host driver only supports dmabuf IPC (RCCL between processes needs it)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np
 import torch

@@ -446,17 +446,20 @@ class Lensgroup:
         return self.psf_diff(points=points, wvln=wvln, ks=ks, spp=spp, center=center)
 
     def psf_diff(self, points, wvln=DEFAULT_WAVE, ks=31, spp=GEO_SPP, center=True,
-                 param_list=None):
+                 param_list=None, _defer=False):
         """optics.py:934-996: normalised points [N,3] (or [3]) -> max-normalised
         PSF [N,ks,ks] (or [ks,ks]) of the left sub-pixel (right if param_list[4] != 'l')."""
         dp, direct = None, "l"
         if param_list is not None:
             h, f, w, r, direct = param_list
             dp = (h, f, w, r)
-        L, R = self.psf_lr(points, ks=ks, wvln=wvln, spp=spp, center=center, dp=dp,
-                           want_r=(param_list is not None and direct != "l"),
-                           _default_r_zero=(param_list is None))
-        return L if direct == "l" else R
+        res = self.psf_lr(points, ks=ks, wvln=wvln, spp=spp, center=center, dp=dp,
+                          want_r=(param_list is not None and direct != "l"),
+                          _default_r_zero=(param_list is None), defer=_defer)
+        pick = (lambda lr: lr[0]) if direct == "l" else (lambda lr: lr[1])
+        if _defer:
+            return PendingPSF(lambda: pick(res.wait()))
+        return pick(res)
 
     @torch.no_grad()
     def psf_lr(self, points, ks=31, wvln=DEFAULT_WAVE, spp=GEO_SPP, center=True,
@@ -622,8 +625,17 @@ class Lensgroup:
 
     def psf_rgb(self, points, ks=31, spp=GEO_SPP, center=True, param_list=None):
         """optics.py:999-1015: [N,3,ks,ks] (or [3,ks,ks])."""
-        psfs = [self.psf_diff(points=points, wvln=w, ks=ks, spp=spp, center=center,
-                              param_list=param_list) for w in WAVE_RGB]
+        n_points = points.shape[0] if torch.is_tensor(points) and points.dim() == 2 else 1
+        if center and n_points > 0:
+            # the three wavelengths are independent calls (fresh pupil draws each, in the
+            # reference's order): enqueue all three, then run the three trip checks -- one host
+            # wait instead of three, the kernels back to back on the GPU
+            pending = [self.psf_diff(points=points, wvln=w, ks=ks, spp=spp, center=center,
+                                     param_list=param_list, _defer=True) for w in WAVE_RGB]
+            psfs = [p.wait() for p in pending]
+        else:
+            psfs = [self.psf_diff(points=points, wvln=w, ks=ks, spp=spp, center=center,
+                                  param_list=param_list) for w in WAVE_RGB]
         return torch.stack(psfs, dim=-3)
 
     def psf_map(self, depth=DEPTH, grid=7, ks=51, spp=GEO_SPP, center=True):
