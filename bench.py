@@ -218,7 +218,12 @@ def main():
             # the gather of two steps ago still reads these tensors on the comm stream
             torch.cuda.current_stream(device).wait_event(gather_done[idx])
         pupil = sd.broadcast_pupil_points(lens, SPP)
-        L, R = sharded.render(points_local, pupil, out)
+        pending = sharded.render(points_local, pupil, out, defer=True)
+        settle()                      # trip check of the previous step, under this step's kernel
+        in_flight[0] = pending
+        if not args.no_gather:
+            settle()                  # shards must be final before they leave the GPU
+        L, R = out
         if not args.no_gather:
             ready = torch.cuda.Event()
             ready.record(torch.cuda.current_stream(device))

@@ -133,9 +133,11 @@ class ShardedPSF:
     def from_lens(cls, lens, ks, wvln=0.589, dp=(0.78, 1.44, 0.3, 0.5), group=None):
         lens.mask_reduce = lambda m: reduce_masks_or(m, group)
 
-        def render(points_local, pupil, out=None):
+        def render(points_local, pupil, out=None, defer=False):
+            # defer=True: every rank enqueues the same kernels and collectives in the same order
+            # and takes the same re-launch decision later (the masks are reduced over ranks)
             return lens.psf_lr(points_local, ks=ks, wvln=wvln, dp=dp, pupil_xy=(pupil[0], pupil[1]),
-                               center_pupil_xy=(pupil[2], pupil[3]), out=out)
+                               center_pupil_xy=(pupil[2], pupil[3]), out=out, defer=defer)
         self = cls(render, lens.device, group)
         self.lens = lens
         return self
