@@ -300,6 +300,17 @@ int sdirt_psfnet_mlp(const void* packed /*dev*/, const int32_t* widths /*host*/,
                      const float* inp /*dev*/, int64_t n_points, int32_t mirror,
                      void* out /*dev fp16*/, void* stream);
 
+/* ---- depth-from-dual-pixel network: cost volume ---------------------------- */
+
+/* YRStereonet_3D.forward's cost volume (dfdp/dddnet/dddnet.py:136-148): x, y [B,C,H,W] left / right
+ * feature maps -> cost [B,2C,D,H,W]; plane i holds, for gap = i - D/2, x in channels [0,C) and y
+ * displaced by gap columns in channels [C,2C), both zero in the |gap| columns the shift vacates
+ * (columns >= W+gap for gap < 0, columns < gap for gap > 0).  half_precision != 0: fp16 tensors
+ * (the network runs under autocast), else fp32.  Every output element is written once. */
+int sdirt_dp_cost_volume(const void* x /*dev*/, const void* y /*dev*/, int32_t batch,
+                         int32_t channels, int32_t d_max, int32_t height, int32_t width,
+                         int32_t half_precision, void* cost /*dev, out*/, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,158 @@
+"""Depth-from-dual-pixel network (consumer of the simulated DP pairs).
+
+`DfDPNet` is the reference's YRStereonet_3D (dfdp/dddnet/dddnet.py:103-152, 358-568) with the
+same parameter names, so its checkpoints load unchanged:
+
+  feature   2-D CNN to 1/4 resolution, 32 channels (3 stride-1/2 convs, 2 dilated convs, two
+            average-pool context branches, fusion)                        dddnet.py:358-407
+  cost      signed-shift DP cost volume [B, 64, 20, H/4, W/4]              dddnet.py:136-148
+            -> ONE HIP kernel (sdirt_dp_cost_volume) instead of zero-fill + 40 sliced copies
+  matching  3-D conv hourglass -> [B, 1, 10, H/4, W/4]                     dddnet.py:409-446
+  disp      trilinear x(2, 4, 4) upsample, softmin over the 20 shifts, expectation over
+            shifts -10..9                                                  dddnet.py:543-568
+
+The convolutions are stock torch.nn (MIOpen on ROCm) -- dense conv work the vendor library
+covers.  Unlike the reference (dddnet.py:564 hard-codes torch.cuda.current_device()), the
+module also runs on the CPU, where the cost volume falls back to the reference's slice copies
+(used by the CPU tests of the host logic only).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib
+from .basics import dptr, stream_ptr
+
+
+def dp_cost_volume(x, y, d_max=20):
+    """dddnet.py:155-178 / 136-148: x, y [B,C,H,W] -> [B,2C,d_max,H,W]."""
+    B, C, H, W = x.shape
+    if x.is_cuda and x.dtype in (torch.float16, torch.float32) and not (x.requires_grad or y.requires_grad):
+        x, y = x.contiguous(), y.to(x.dtype).contiguous()
+        cost = torch.empty((B, 2 * C, d_max, H, W), dtype=x.dtype, device=x.device)
+        _lib.check(_lib.lib().sdirt_dp_cost_volume(dptr(x), dptr(y), B, C, d_max, H, W,
+                                                   1 if x.dtype == torch.float16 else 0,
+                                                   dptr(cost), stream_ptr(x.device)))
+        return cost
+    # autograd / CPU path: the reference's formulation
+    cost = torch.zeros(B, C * 2, d_max, H, W).type_as(x)
+    for i in range(d_max):
+        gap = i - d_max // 2
+        keep = slice(None, gap) if gap < 0 else slice(gap, None)
+        cost[:, :C, i, :, keep] = x[:, :, :, keep]
+        cost[:, C:, i, :, keep] = y[:, :, :, -gap:] if gap < 0 else (y[:, :, :, :-gap] if gap > 0 else y)
+    return cost
+
+
+class BasicConv(nn.Module):
+    """conv (2-D / 3-D, optionally transposed, no bias) [+ batch norm] [+ ReLU]; dddnet.py:513-541."""
+
+    def __init__(self, cin, cout, deconv=False, is_3d=False, bn=True, relu=True, **kw):
+        super().__init__()
+        conv = {(False, False): nn.Conv2d, (False, True): nn.ConvTranspose2d,
+                (True, False): nn.Conv3d, (True, True): nn.ConvTranspose3d}[(is_3d, deconv)]
+        self.conv = conv(cin, cout, bias=False, **kw)
+        self.bn = (nn.BatchNorm3d if is_3d else nn.BatchNorm2d)(cout)
+        self.use_bn, self.relu = bn, relu
+
+    def forward(self, x):
+        x = self.conv(x)
+        if self.use_bn:
+            x = self.bn(x)
+        return F.relu(x, inplace=True) if self.relu else x
+
+
+def _convbn(cin, cout):
+    return nn.Sequential(nn.Conv2d(cin, cout, kernel_size=1, stride=1, padding=0, dilation=1, bias=False),
+                         nn.BatchNorm2d(cout))
+
+
+class Feature(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.start = nn.Sequential(BasicConv(3, 32, kernel_size=3, padding=1),
+                                   BasicConv(32, 64, kernel_size=3, stride=1, padding=1),
+                                   BasicConv(64, 64, kernel_size=3, stride=2, padding=1))
+        self.layer1 = nn.Sequential(BasicConv(64, 128, kernel_size=3, stride=1, padding=4, dilation=4),
+                                    BasicConv(128, 128, kernel_size=3, stride=1, padding=8, dilation=8),
+                                    BasicConv(128, 128, kernel_size=3, stride=2, padding=1))
+        self.branch1 = nn.Sequential(nn.AvgPool2d((32, 32), stride=(32, 32)), _convbn(128, 32),
+                                     nn.ReLU(inplace=True))
+        self.branch3 = nn.Sequential(nn.AvgPool2d((8, 8), stride=(8, 8)), _convbn(128, 32),
+                                     nn.ReLU(inplace=True))
+        self.end = nn.Sequential(BasicConv(192, 96, kernel_size=3, stride=1, padding=1),
+                                 BasicConv(96, 32, kernel_size=1, bn=False, relu=False, padding=0))
+
+    def forward(self, x):
+        x = self.layer1(self.start(x))
+        size = x.shape[2:]
+        ctx = [F.interpolate(b(x), size, mode="bilinear", align_corners=True)
+               for b in (self.branch1, self.branch3)]
+        return self.end(torch.cat(ctx + [x], 1))
+
+
+class Conv2x(nn.Module):
+    """Upsample x2 (trilinear), conv, concatenate the skip tensor, conv; dddnet.py:570-602."""
+
+    def __init__(self, cin, cout, is_3d=True):
+        super().__init__()
+        self.conv1 = BasicConv(cin, cout, False, is_3d, kernel_size=3, stride=1, padding=1)
+        self.conv2 = BasicConv(cout * 2, cout, False, is_3d, kernel_size=3, stride=1, padding=1)
+        self.up2 = nn.Upsample(scale_factor=2, mode="trilinear", align_corners=True)
+
+    def forward(self, x, rem):
+        x = self.conv1(self.up2(x))
+        assert x.size() == rem.size()
+        return self.conv2(torch.cat((x, rem), 1))
+
+
+class Matching(nn.Module):
+    def __init__(self):
+        super().__init__()
+        c3 = dict(is_3d=True, kernel_size=3, padding=1)
+        self.start = nn.Sequential(BasicConv(64, 32, **c3), BasicConv(32, 48, stride=2, **c3),
+                                   BasicConv(48, 64, **c3))
+        self.conv1a = nn.Sequential(BasicConv(64, 64, stride=2, **c3), BasicConv(64, 64, **c3))
+        self.deconv1a = Conv2x(64, 64, is_3d=True)
+        self.end = nn.Sequential(
+            BasicConv(64, 64, is_3d=True, kernel_size=4, padding=1, stride=2, deconv=True),
+            BasicConv(64, 1, is_3d=True, kernel_size=3, padding=1, stride=1, bn=False, relu=False))
+
+    def forward(self, x):
+        x = self.start(x)
+        return self.end(self.deconv1a(self.conv1a(x), x))
+
+
+class Disp(nn.Module):
+    def __init__(self, maxdisp=20):
+        super().__init__()
+        self.maxdisp = maxdisp
+
+    def forward(self, x):
+        x = F.interpolate(x, [self.maxdisp, x.shape[3] * 4, x.shape[4] * 4], mode="trilinear",
+                          align_corners=False)
+        p = F.softmin(torch.squeeze(x, 1), dim=1)
+        shifts = torch.arange(-self.maxdisp // 2, self.maxdisp // 2, device=x.device).view(1, -1, 1, 1)
+        return torch.sum(p * shifts, 1, keepdim=True)
+
+
+class DfDPNet(nn.Module):
+    """YRStereonet_3D: (left, right) DP views [B,3,H,W] (H, W multiples of 128) -> signed
+    disparity [B,1,H,W] in pixels of the quarter-resolution shift axis, range (-10, 9)."""
+
+    def __init__(self, maxdisp=20):
+        super().__init__()
+        self.maxdisp = maxdisp
+        self.feature = Feature()
+        self.matching = Matching()
+        self.disp = Disp(maxdisp)
+        for m in self.modules():                     # dddnet.py:115-120
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+
+    def forward(self, xl, yr):
+        cost = dp_cost_volume(self.feature(xl), self.feature(yr), self.maxdisp)
+        return self.disp(self.matching(cost))

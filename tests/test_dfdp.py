@@ -1,0 +1,66 @@
+"""Depth-from-DP network against the fixture generated from the reference's
+YRStereonet_3D by oracle/gen_golden_dfdp.py."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+
+def inputs(fx):
+    g = torch.Generator().manual_seed(int(fx["input_seed"]))
+    xl = torch.rand(1, 3, 128, 128, generator=g)
+    xr = torch.roll(xl, 3, dims=-1) * 0.9 + 0.05 * torch.rand(1, 3, 128, 128, generator=g)
+    assert xl.double().sum().item() == pytest.approx(float(fx["xl_sum"]), rel=1e-12)
+    assert xr.double().sum().item() == pytest.approx(float(fx["xr_sum"]), rel=1e-12)
+    cx, cy = torch.rand(2, 3, 4, 24, generator=g), torch.rand(2, 3, 4, 24, generator=g)
+    return xl, xr, cx, cy
+
+
+def build(fx):
+    from sdirt_amd.dfdp import DfDPNet
+    torch.manual_seed(int(fx["seed"]))
+    return DfDPNet().eval()
+
+
+def test_dfdp_net_draws_the_reference_weights_and_matches_it_on_cpu():
+    fx = load_golden("f10_dfdp_net")
+    net = build(fx)
+    sd = net.state_dict()
+    keys = [k[4:] for k in fx.files if k.startswith("sum/")]
+    assert sorted(keys) == sorted(k for k, v in sd.items() if v.dtype.is_floating_point)
+    for k in keys:                                     # same names, same seeded values
+        assert sd[k].double().sum().item() == pytest.approx(float(fx["sum/" + k]), rel=1e-10, abs=1e-10), k
+        assert sd[k].double().abs().sum().item() == pytest.approx(float(fx["abs/" + k]), rel=1e-10), k
+    xl, xr, cx, cy = inputs(fx)
+    from sdirt_amd.dfdp import dp_cost_volume
+    np.testing.assert_array_equal(dp_cost_volume(cx, cy, 20).numpy(), fx["cv"])
+    with torch.no_grad():
+        fl = net.feature(xl)
+        disp = net(xl, xr)
+    np.testing.assert_allclose(fl[0, :, ::8, ::8].numpy(), fx["feature_l_head"], rtol=1e-4, atol=1e-5)
+    assert disp.shape == fx["disp"].shape == (1, 1, 128, 128)
+    np.testing.assert_allclose(disp.numpy(), fx["disp"], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.gpu
+def test_dfdp_net_and_cost_volume_kernel_on_the_gpu():
+    fx = load_golden("f10_dfdp_net")
+    dev = "cuda:0"
+    net = build(fx).to(dev)
+    xl, xr, cx, cy = inputs(fx)
+    from sdirt_amd.dfdp import dp_cost_volume
+    cv = dp_cost_volume(cx.to(dev), cy.to(dev), 20)                    # HIP kernel, fp32
+    np.testing.assert_array_equal(cv.cpu().numpy(), fx["cv"])
+    cvh = dp_cost_volume(cx.to(dev).half(), cy.to(dev).half(), 20)     # HIP kernel, fp16
+    np.testing.assert_array_equal(cvh.float().cpu().numpy(), torch.from_numpy(fx["cv"]).half().float().numpy())
+    g = torch.Generator().manual_seed(5)
+    for shape, d in (((1, 5, 7, 33), 20), ((2, 2, 3, 9), 6), ((1, 1, 2, 130), 12)):   # ragged widths
+        a, b = torch.rand(*shape, generator=g), torch.rand(*shape, generator=g)
+        assert torch.equal(dp_cost_volume(a.to(dev), b.to(dev), d).cpu(), dp_cost_volume(a, b, d))
+    with torch.no_grad():
+        disp = net(xl.to(dev), xr.to(dev))
+    assert np.abs(disp.cpu().numpy() - fx["disp"]).max() < 2e-3        # MIOpen fp32 convs vs CPU
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):   # as Basenet.forward runs it
+        disp16 = net(xl.to(dev), xr.to(dev))
+    assert np.abs(disp16.float().cpu().numpy() - fx["disp"]).max() < 5e-2

@@ -57,3 +57,30 @@ print(f"psf dtype {psf.dtype}; one network pass {t_net:.2f} ms ({fl / t_net / 1e
       f"pred (L+R, normalise) {t_pred:.2f} ms; convolution {t_conv:.2f} ms; fused MLP both passes {t_fmlp:.2f} ms ({2 * fl / t_fmlp / 1e9:.0f} TFLOP/s); "
       f"render total {t_all:.2f} ms (torch.nn layers + fused conv {t_gemm:.2f} ms, op-by-op chain {t_chain:.2f} ms) "
       f"-> {1e3 / t_all:.1f} frames/s")
+
+# ---- second half of config 5: depth-from-DP network forward on the simulated pair ----------
+from sdirt_amd.dfdp import DfDPNet, dp_cost_volume
+torch.manual_seed(1)
+net = DfDPNet().to(dev).eval()
+with torch.no_grad():
+    pair = m.render(img, depth, foc)
+    left, right = pair[:, :3].contiguous(), pair[:, 3:].contiguous()
+    t32 = timed(lambda: net(left, right), n=5, warm=2)
+    with torch.autocast("cuda", dtype=torch.float16):
+        t16 = timed(lambda: net(left, right), n=5, warm=2)
+        f = net.feature(left)
+    t_cv = timed(lambda: dp_cost_volume(f, f, 20))
+
+    def ref_cv(x, y, d_max=20):
+        B, C, H_, W_ = x.shape
+        cost = torch.zeros(B, C * 2, d_max, H_, W_).type_as(x)
+        for i in range(d_max):
+            gap = i - d_max // 2
+            keep = slice(None, gap) if gap < 0 else slice(gap, None)
+            cost[:, :C, i, :, keep] = x[:, :, :, keep]
+            cost[:, C:, i, :, keep] = y[:, :, :, -gap:] if gap < 0 else (y[:, :, :, :-gap] if gap > 0 else y)
+        return cost
+    t_cv_ref = timed(lambda: ref_cv(f, f))
+print(f"DfDP net forward 512x768: fp32 {t32:.1f} ms, fp16 autocast {t16:.1f} ms; cost volume "
+      f"[1,64,20,128,192] {f.dtype}: HIP kernel {t_cv * 1e3:.0f} us vs zero-fill + 40 slice copies {t_cv_ref * 1e3:.0f} us; "
+      f"config 5 end to end (render + depth net, fp16) {t_all + t16:.1f} ms")
