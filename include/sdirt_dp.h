@@ -311,6 +311,11 @@ int sdirt_dp_cost_volume(const void* x /*dev*/, const void* y /*dev*/, int32_t b
                          int32_t channels, int32_t d_max, int32_t height, int32_t width,
                          int32_t half_precision, void* cost /*dev, out*/, void* stream);
 
+/* PSFNet tone curves (deeplens/psfnet.py:589-620), elementwise over n floats, in place allowed:
+ * mode 0 = degamma(img) (code value in [0,1] -> linear luminance, psfnet.py:600-603),
+ * mode 1 = clip(gamma(l), 0, 1) (psfnet.py:617-620 followed by the clip of render, :712). */
+int sdirt_tone_curve(const float* in /*dev*/, int64_t n, int32_t mode, float* out /*dev*/, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -65,3 +65,57 @@ extern "C" int sdirt_dp_cost_volume(const void* x, const void* y, int32_t batch,
     LAUNCH_CHECK();
     return SDIRT_OK;
 }
+
+// ---------------------------------------------------------------------------
+// PSFNet tone curves (deeplens/psfnet.py:589-620), one pass each instead of ~25 elementwise launches.
+// The arithmetic follows torch's fp32 op sequence on the GPU term by term (scalar / tensor is
+// reciprocal * scalar, tensor / scalar is tensor * (1 / scalar), no contraction), so the results
+// are interchangeable with the op-by-op chain.
+// ---------------------------------------------------------------------------
+namespace {
+
+constexpr float kA1 = 0.89129432f, kB1 = 0.27217316f, kC1 = -0.00246187f;           // psfnet.py:591
+constexpr float kA2 = 5.94018909e-01f, kB2 = 1.20060450e+01f, kC2 = -5.24983855e-03f;  // psfnet.py:592
+
+__device__ __forceinline__ float recip(float v) { return 1.0f / v; }
+
+// degamma(img) = fit_degamma(img * 255): 8-bit code value -> luminance
+__device__ __forceinline__ float tone_degamma(float img)
+{
+    const float x = img * 255.0f;
+    const float lo = recip(recip(kA1 * x + kB1) + kC1);
+    const float hi = recip(recip(kA2 * x + kB2) + kC2);
+    const float t = fminf(x * (1.0f / 100.0f), 1.0f);
+    return hi * t + lo * (1.0f - t);
+}
+
+// clip(gamma(l), 0, 1) with gamma(l) = fit_gamma(l) / 255
+__device__ __forceinline__ float tone_gamma_clip(float l)
+{
+    const float r = recip(l + 1e-9f);
+    const float x1 = (recip(r - kC1) - kB1) * (1.0f / kA1);
+    const float x2 = (recip(r - kC2) - kB2) * (1.0f / kA2);
+    const float t = fminf(((x1 + x2) * 0.5f) * (1.0f / 100.0f), 1.0f);
+    const float g = (x2 * t + x1 * (1.0f - t)) * (1.0f / 255.0f);
+    return fminf(fmaxf(g, 0.0f), 1.0f);
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(256) k_tone(const float* __restrict__ in, int64_t n, float* __restrict__ out)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = MODE == 0 ? tone_degamma(in[i]) : tone_gamma_clip(in[i]);
+}
+
+}  // namespace
+
+extern "C" int sdirt_tone_curve(const float* in, int64_t n, int32_t mode, float* out, void* stream)
+{
+    if (!in || !out || n < 0 || mode < 0 || mode > 1) return fail(SDIRT_ERR_INVALID_ARGUMENT, "bad argument");
+    if (n == 0) return SDIRT_OK;
+    const int grid = (int)std::min<int64_t>((n + 255) / 256, 256 * 16);
+    if (mode == 0) k_tone<0><<<grid, 256, 0, as_stream(stream)>>>(in, n, out);
+    else k_tone<1><<<grid, 256, 0, as_stream(stream)>>>(in, n, out);
+    LAUNCH_CHECK();
+    return SDIRT_OK;
+}

@@ -284,7 +284,19 @@ class PSFNet(Lensgroup):
         return hi * t + lo * (1 - t)
 
     def degamma(self, img_gamma):
+        if img_gamma.is_cuda and img_gamma.dtype == torch.float32 and not img_gamma.requires_grad:
+            return self._tone(img_gamma, 0)
         return self.fit_degamma(img_gamma * 255.)
+
+    @staticmethod
+    def _tone(t, mode):
+        """degamma (mode 0) / clip(gamma(.), 0, 1) (mode 1) in one kernel, same fp32 arithmetic."""
+        from . import _lib
+        from .basics import dptr, stream_ptr
+        t = t.contiguous()
+        out = torch.empty_like(t)
+        _lib.check(_lib.lib().sdirt_tone_curve(dptr(t), t.numel(), mode, dptr(out), stream_ptr(t.device)))
+        return out
 
     def fit_gamma(self, l):
         """psfnet.py:605-615: inverse of fit_degamma."""
@@ -341,7 +353,10 @@ class PSFNet(Lensgroup):
         else:
             psf = self.pred(o)
             render_lr = local_psf_render_fast(self.degamma(img), psf, self.kernel_size)
-        render = self.gamma(torch.cat(render_lr, dim=1))
+        render = torch.cat(render_lr, dim=1)
+        if not train and render.is_cuda and render.dtype == torch.float32:
+            return self._tone(render, 1)                      # gamma + clip in one pass
+        render = self.gamma(render)
         if train:
             render = self.noise(render, img.shape)
         return torch.clip(render, 0.0, 1.0)

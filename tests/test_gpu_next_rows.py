@@ -289,3 +289,22 @@ def test_pred_uses_the_fused_network_without_changing_results():
     scale = c.float().abs().max().item()
     assert (b.float() - c.float()).abs().max().item() < 1e-2 * scale
     assert (a.float() - c.float()).abs().max().item() < 1e-2 * scale
+
+
+def test_tone_curve_kernels_equal_the_torch_chain():
+    """sdirt_tone_curve against fit_degamma / fit_gamma evaluated op by op in torch on the GPU."""
+    from sdirt_amd.psfnet import PSFNet
+    m = PSFNet(os.path.join(DATA, "rf50mm.json"), sensor_res=(512, 768), kernel_size=7, device=DEV,
+               post_computation=False)
+    g = torch.Generator(device=DEV).manual_seed(0)
+    x = torch.rand(100000, device=DEV, generator=g)
+    x[:4] = torch.tensor([0.0, 1.0, 100 / 255, 0.5], device=DEV)
+    lin_ref = m.fit_degamma(x * 255.)
+    lin = m.degamma(x)
+    assert (lin - lin_ref).abs().max().item() <= 2e-6 * lin_ref.abs().max().item()
+    assert (lin == lin_ref).float().mean().item() > 0.99
+    back_ref = torch.clip(m.gamma(lin_ref), 0.0, 1.0)
+    back = m._tone(lin_ref, 1)
+    assert (back - back_ref).abs().max().item() <= 1e-6
+    assert (back == back_ref).float().mean().item() > 0.99
+    assert (back - x).abs().max().item() < 1e-2               # gamma ~ inverse of degamma (two blended fits)
