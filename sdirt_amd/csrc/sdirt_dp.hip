@@ -425,8 +425,10 @@ struct CenterArgs {
 
 // __launch_bounds__(512, 8): four workgroups per CU = 8 waves per SIMD; without the hint the
 // CENTER instantiations use 101 SGPRs, which the hardware admits only 7 waves per SIMD for.
+// The big-radius microlens branch (corner-clipped areas, monte_carlo.py:242-372) needs ~90 VGPRs:
+// capped at 64 it would spill 60 of them to scratch, so it runs at 4 waves per SIMD instead.
 template <bool HAVE_R, bool BIG, class HotMath, bool CENTER>
-__global__ void __launch_bounds__(kFused, 8)
+__global__ void __launch_bounds__(kFused, BIG ? 4 : 8)
 k_psf_lr(const DevSurface* __restrict__ lens, int K, TripTable trips,
          const float* __restrict__ po, const float* __restrict__ x2, const float* __restrict__ y2,
          int S, int nsplit, int chunk, float pz, float zs, SplatGeom gm, DevDpParams dp,
