@@ -66,6 +66,26 @@ def case():
         d["cv_x"], d["cv_y"] = fx.numpy(), fy.numpy()
         d["cv"] = ref.YRStereonet_3D.get_dp_cost_volume(fx, fy, 20).numpy()
         d["disp"] = net(xl, xr).numpy()
+    # Basenet.dfdp (dfdp/basenet.py:23-49) in depth-estimation mode, same seed: its first member is
+    # the same YRStereonet_3D, so the weights above are drawn again
+    bspec = importlib.util.spec_from_file_location("dfdp_ref.basenet", "/root/reference/dfdp/basenet.py",
+                                                   submodule_search_locations=None)
+    pkg = types.ModuleType("dfdp_ref"); pkg.__path__ = ["/root/reference/dfdp"]; sys.modules["dfdp_ref"] = pkg
+    dd = types.ModuleType("dfdp_ref.dddnet"); dd.__path__ = []; sys.modules["dfdp_ref.dddnet"] = dd
+    sys.modules["dfdp_ref.dddnet.dddnet"] = ref
+    bn = importlib.util.module_from_spec(bspec); bn.__package__ = "dfdp_ref"
+    bspec.loader.exec_module(bn)
+    torch.manual_seed(21)
+    base = bn.Basenet(train_mode="dfdp").eval()
+    gt = 0.5 + 4.5 * torch.rand(1, 1, 128, 128, generator=g)
+    gt[0, 0, :4, :4] = 0.0                                  # invalid ground truth -> masked out
+    d["gt_depth_sum"] = np.float64(gt.double().sum().item())
+    with torch.no_grad():
+        losses, outputs = base.dfdp({"stack_rgb_img": torch.cat((xl, xr), 1), "AiF_img": xl,
+                                     "gt_depth": gt.clone()}, train=True)
+    d["loss_total"] = np.float64(losses["total"].item())
+    d["pred_depth_est"] = outputs["pred_depth_est"].numpy()
+    d["gt_depth_roundtrip_err"] = np.float64((outputs["gt_depth"] - gt).abs().max().item())
     return d
 
 

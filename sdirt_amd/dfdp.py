@@ -156,3 +156,60 @@ class DfDPNet(nn.Module):
     def forward(self, xl, yr):
         cost = dp_cost_volume(self.feature(xl), self.feature(yr), self.maxdisp)
         return self.disp(self.matching(cost))
+
+
+class Basenet(nn.Module):
+    """dfdp/basenet.py:9-105, depth-estimation mode: the DP pair rendered by PSFNet.render
+    ([B,6,H,W], left views then right views) -> log-depth estimate, SmoothL1 loss on the pixels
+    with valid ground truth.  The optional deblurring branch (train_mode='deblur', Mydeblur) is
+    not built."""
+
+    def __init__(self, train_mode="dfdp"):
+        super().__init__()
+        if train_mode != "dfdp":
+            raise NotImplementedError("only train_mode='dfdp' (depth estimation) is built")
+        self.train_mode = train_mode
+        self.dfdp_net = DfDPNet()
+
+    def forward(self, input_dict):
+        with torch.autocast("cuda", dtype=torch.float16, enabled=input_dict["stack_rgb_img"].is_cuda):
+            return self.dfdp(input_dict, train=True)
+
+    def linear(self, depth):
+        """basenet.py:88-92: metres -> log-metres IN PLACE where depth is valid; remembers the mask."""
+        self.mask = (depth > 1e-9).detach()
+        depth[self.mask] = torch.log(depth[self.mask])
+        return depth
+
+    def inverse_linear(self, depth, mask=None):
+        if mask is None:
+            depth[self.mask] = torch.exp(depth[self.mask])
+            return depth
+        return torch.exp(depth)
+
+    def compute_loss(self, results, gts):
+        l1 = nn.SmoothL1Loss(reduction="mean")
+        est = l1(results["pred_depth_est"][self.mask], gts["gt_depth"][self.mask])
+        return {"depth_est": est, "total": est}
+
+    def dfdp(self, input_dict, train=False):
+        stack, gt_aif = input_dict["stack_rgb_img"], input_dict["AiF_img"]
+        left, right = stack[:, 0:3], stack[:, 3:]
+        gt_depth = self.linear(input_dict["gt_depth"])
+        depth_est = self.dfdp_net(left, right)
+        losses = None
+        if train:
+            losses = self.compute_loss({"pred_depth_est": depth_est}, {"gt_depth": gt_depth})
+        outputs = {"gt_depth": self.inverse_linear(gt_depth), "gt_aif": gt_aif, "gt_l": None, "gt_r": None,
+                   "rt_render_l": left, "rt_render_r": right,
+                   "pred_depth_est": self.inverse_linear(depth_est.to(torch.float32))}
+        return losses, outputs
+
+    def inference(self, input_dict):
+        gt_depth, gt_aif = self.linear(input_dict["depth"]), input_dict["AiF_img"]
+        stack = input_dict["stack_rgb_img"]
+        left, right = stack[:, 0:3], stack[:, 3:]
+        depth_est = self.dfdp_net(left, right)
+        return {"gt_depth": self.inverse_linear(gt_depth), "gt_aif": gt_aif, "gt_l": left, "gt_r": right,
+                "rt_render_l": None, "rt_render_r": None,
+                "pred_depth_est": self.inverse_linear(depth_est.to(torch.float32), mask=False)}

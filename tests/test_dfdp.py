@@ -14,6 +14,10 @@ def inputs(fx):
     assert xl.double().sum().item() == pytest.approx(float(fx["xl_sum"]), rel=1e-12)
     assert xr.double().sum().item() == pytest.approx(float(fx["xr_sum"]), rel=1e-12)
     cx, cy = torch.rand(2, 3, 4, 24, generator=g), torch.rand(2, 3, 4, 24, generator=g)
+    gt = 0.5 + 4.5 * torch.rand(1, 1, 128, 128, generator=g)
+    gt[0, 0, :4, :4] = 0.0
+    assert gt.double().sum().item() == pytest.approx(float(fx["gt_depth_sum"]), rel=1e-12)
+    inputs.gt = gt
     return xl, xr, cx, cy
 
 
@@ -41,6 +45,25 @@ def test_dfdp_net_draws_the_reference_weights_and_matches_it_on_cpu():
     np.testing.assert_allclose(fl[0, :, ::8, ::8].numpy(), fx["feature_l_head"], rtol=1e-4, atol=1e-5)
     assert disp.shape == fx["disp"].shape == (1, 1, 128, 128)
     np.testing.assert_allclose(disp.numpy(), fx["disp"], rtol=1e-4, atol=1e-4)
+
+
+def test_basenet_depth_mode_matches_the_reference():
+    """dfdp/basenet.py:23-49: log-depth transform in place, masked SmoothL1, outputs back in metres."""
+    from sdirt_amd.dfdp import Basenet
+    fx = load_golden("f10_dfdp_net")
+    xl, xr, _, _ = inputs(fx)
+    torch.manual_seed(int(fx["seed"]))
+    base = Basenet(train_mode="dfdp").eval()
+    gt = inputs.gt.clone()
+    with torch.no_grad():
+        losses, outputs = base.dfdp({"stack_rgb_img": torch.cat((xl, xr), 1), "AiF_img": xl, "gt_depth": gt},
+                                    train=True)
+    assert losses["total"].item() == pytest.approx(float(fx["loss_total"]), rel=1e-4)
+    np.testing.assert_allclose(outputs["pred_depth_est"].numpy(), fx["pred_depth_est"], rtol=2e-4, atol=1e-5)
+    assert (outputs["gt_depth"] - inputs.gt).abs().max().item() <= float(fx["gt_depth_roundtrip_err"]) + 1e-6
+    assert outputs["gt_depth"] is gt                                   # transformed in place, as the reference
+    with pytest.raises(NotImplementedError):
+        Basenet(train_mode="deblur")
 
 
 @pytest.mark.gpu
