@@ -311,6 +311,13 @@ int sdirt_dp_cost_volume(const void* x /*dev*/, const void* y /*dev*/, int32_t b
                          int32_t channels, int32_t d_max, int32_t height, int32_t width,
                          int32_t half_precision, void* cost /*dev, out*/, void* stream);
 
+/* Adjoint of sdirt_dp_cost_volume for training the depth network: grad_cost [B,2C,D,H,W] ->
+ * grad_x, grad_y [B,C,H,W] (each input element sums the gradients of the volume elements it was
+ * copied to, fp32 accumulation). */
+int sdirt_dp_cost_volume_backward(const void* grad_cost /*dev*/, int32_t batch, int32_t channels,
+                                  int32_t d_max, int32_t height, int32_t width, int32_t half_precision,
+                                  void* grad_x /*dev, out*/, void* grad_y /*dev, out*/, void* stream);
+
 /* PSFNet tone curves (deeplens/psfnet.py:589-620), elementwise over n floats, in place allowed:
  * mode 0 = degamma(img) (code value in [0,1] -> linear luminance, psfnet.py:600-603),
  * mode 1 = clip(gamma(l), 0, 1) (psfnet.py:617-620 followed by the clip of render, :712). */

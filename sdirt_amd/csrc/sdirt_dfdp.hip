@@ -42,7 +42,58 @@ k_dp_cost_volume(const T* __restrict__ x, const T* __restrict__ y, int B, int C,
     }
 }
 
+// Adjoint of the cost volume: every input element collects the gradient of the (up to D) volume
+// elements it was copied to.  One thread per input element, reads coalesced along w.
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_dp_cost_volume_bwd(const T* __restrict__ gcost, int B, int C, int D, int H, int W, T* __restrict__ gx,
+                     T* __restrict__ gy)
+{
+    const int64_t total = (int64_t)B * 2 * C * H * W;
+    const int64_t plane = (int64_t)H * W;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (int64_t)gridDim.x * blockDim.x) {
+        const int w = (int)(t % W);
+        int64_t rest = t / W;
+        const int h = (int)(rest % H); rest /= H;
+        const int c2 = (int)(rest % (2 * C));
+        const int b = (int)(rest / (2 * C));
+        const bool right = c2 >= C;
+        const T* src = gcost + (((int64_t)b * 2 * C + c2) * D) * plane + (int64_t)h * W;
+        float acc = 0.0f;
+        for (int i = 0; i < D; ++i) {
+            const int gap = i - D / 2;
+            const int wv = right ? w + gap : w;                        // column of the volume it went to
+            const int lo = gap > 0 ? gap : 0, hi = gap < 0 ? W + gap : W;
+            if (wv >= lo && wv < hi) acc += (float)src[i * plane + wv];
+        }
+        T* dst = right ? gy : gx;
+        dst[(((int64_t)b * C + (right ? c2 - C : c2)) * H + h) * W + w] = (T)acc;
+    }
+}
+
 }  // namespace
+
+extern "C" int sdirt_dp_cost_volume_backward(const void* grad_cost, int32_t batch, int32_t channels,
+                                             int32_t d_max, int32_t height, int32_t width,
+                                             int32_t half_precision, void* grad_x, void* grad_y, void* stream)
+{
+    if (!grad_cost || !grad_x || !grad_y || batch < 0 || channels < 1 || d_max < 1 || height < 1 || width < 1)
+        return fail(SDIRT_ERR_INVALID_ARGUMENT, "bad argument");
+    if (batch == 0) return SDIRT_OK;
+    const int64_t total = (int64_t)batch * 2 * channels * height * width;
+    const int grid = (int)std::min<int64_t>((total + 255) / 256, 256 * 64);
+    if (half_precision)
+        k_dp_cost_volume_bwd<_Float16><<<grid, 256, 0, as_stream(stream)>>>(
+            static_cast<const _Float16*>(grad_cost), batch, channels, d_max, height, width,
+            static_cast<_Float16*>(grad_x), static_cast<_Float16*>(grad_y));
+    else
+        k_dp_cost_volume_bwd<float><<<grid, 256, 0, as_stream(stream)>>>(
+            static_cast<const float*>(grad_cost), batch, channels, d_max, height, width,
+            static_cast<float*>(grad_x), static_cast<float*>(grad_y));
+    LAUNCH_CHECK();
+    return SDIRT_OK;
+}
 
 extern "C" int sdirt_dp_cost_volume(const void* x, const void* y, int32_t batch, int32_t channels,
                                     int32_t d_max, int32_t height, int32_t width, int32_t half_precision,

@@ -24,17 +24,9 @@ from . import _lib
 from .basics import dptr, stream_ptr
 
 
-def dp_cost_volume(x, y, d_max=20):
-    """dddnet.py:155-178 / 136-148: x, y [B,C,H,W] -> [B,2C,d_max,H,W]."""
+def _cost_volume_reference(x, y, d_max):
+    """The reference's formulation (dddnet.py:136-148): zero-fill, then 2 * d_max slice copies."""
     B, C, H, W = x.shape
-    if x.is_cuda and x.dtype in (torch.float16, torch.float32) and not (x.requires_grad or y.requires_grad):
-        x, y = x.contiguous(), y.to(x.dtype).contiguous()
-        cost = torch.empty((B, 2 * C, d_max, H, W), dtype=x.dtype, device=x.device)
-        _lib.check(_lib.lib().sdirt_dp_cost_volume(dptr(x), dptr(y), B, C, d_max, H, W,
-                                                   1 if x.dtype == torch.float16 else 0,
-                                                   dptr(cost), stream_ptr(x.device)))
-        return cost
-    # autograd / CPU path: the reference's formulation
     cost = torch.zeros(B, C * 2, d_max, H, W).type_as(x)
     for i in range(d_max):
         gap = i - d_max // 2
@@ -42,6 +34,39 @@ def dp_cost_volume(x, y, d_max=20):
         cost[:, :C, i, :, keep] = x[:, :, :, keep]
         cost[:, C:, i, :, keep] = y[:, :, :, -gap:] if gap < 0 else (y[:, :, :, :-gap] if gap > 0 else y)
     return cost
+
+
+class _CostVolume(torch.autograd.Function):
+    """sdirt_dp_cost_volume / sdirt_dp_cost_volume_backward (one kernel each way)."""
+
+    @staticmethod
+    def forward(ctx, x, y, d_max):
+        B, C, H, W = x.shape
+        x, y = x.contiguous(), y.to(x.dtype).contiguous()
+        cost = torch.empty((B, 2 * C, d_max, H, W), dtype=x.dtype, device=x.device)
+        _lib.check(_lib.lib().sdirt_dp_cost_volume(dptr(x), dptr(y), B, C, d_max, H, W,
+                                                   1 if x.dtype == torch.float16 else 0,
+                                                   dptr(cost), stream_ptr(x.device)))
+        ctx.shape, ctx.d_max = (B, C, H, W), d_max
+        return cost
+
+    @staticmethod
+    def backward(ctx, grad_cost):
+        B, C, H, W = ctx.shape
+        g = grad_cost.contiguous()
+        gx = torch.empty((B, C, H, W), dtype=g.dtype, device=g.device)
+        gy = torch.empty_like(gx)
+        _lib.check(_lib.lib().sdirt_dp_cost_volume_backward(dptr(g), B, C, ctx.d_max, H, W,
+                                                            1 if g.dtype == torch.float16 else 0,
+                                                            dptr(gx), dptr(gy), stream_ptr(g.device)))
+        return gx, gy, None
+
+
+def dp_cost_volume(x, y, d_max=20):
+    """dddnet.py:155-178 / 136-148: x, y [B,C,H,W] -> [B,2C,d_max,H,W] (differentiable)."""
+    if x.is_cuda and x.dtype in (torch.float16, torch.float32):
+        return _CostVolume.apply(x, y, d_max)
+    return _cost_volume_reference(x, y, d_max)          # CPU (host-logic tests only)
 
 
 class BasicConv(nn.Module):

@@ -310,12 +310,14 @@ class PSFNet(Lensgroup):
         return self.fit_gamma(img_degamma) / 255.
 
     def noise(self, render, shape):
-        """psfnet.py:627-640: Gaussian noise with a left/right ramp (training augmentation)."""
+        """psfnet.py:627-640: Gaussian noise with a left/right ramp (training augmentation).  Same
+        draws from numpy's and torch's generators, in the same order; the ramp is built on the
+        device instead of being expanded to [N,C,H,W] on the host and copied over."""
         N, C, H, W = shape
         noise_map = torch.randn_like(render) * (0.05 * np.random.rand())
         lo, hi = np.random.rand() / 2, np.random.rand() / 2 + 0.5
-        ramp = torch.linspace(lo, hi, W).repeat(N, C, H, 1)
-        weight = torch.cat([ramp, torch.flip(ramp, [-1])], dim=1).to(render.device)
+        ramp = torch.linspace(lo, hi, W, device=render.device)
+        weight = torch.cat([ramp.expand(N, C, H, W), torch.flip(ramp, [-1]).expand(N, C, H, W)], dim=1)
         render += noise_map * weight
         return render
 
