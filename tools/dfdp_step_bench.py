@@ -15,6 +15,7 @@ from sdirt_amd.dfdp import Basenet
 from sdirt_amd.psfnet import PSFNet
 
 dev = "cuda:0"
+torch.backends.cudnn.benchmark = os.environ.get("SDIRT_MIOPEN_FIND", "0") == "1"
 bs, H, W, ks = 4, 512, 768, 21
 torch.manual_seed(0); np.random.seed(0)
 lens = PSFNet(os.path.join(os.path.dirname(__file__), "..", "sdirt_amd", "data", "rf50mm.json"),
