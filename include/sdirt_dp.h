@@ -163,7 +163,11 @@ int sdirt_rays_to_aos(sdirt_rays rays, int64_t n_rays, float* o /*dev [M,3] or N
  * bit j (1..trips) = "some ray still had |f(t)| > 50e-6 in trip j".  A trip
  * table T reproduces the reference's batch exactly iff for every surface bits
  * 1..T-1 are set and bit T is clear (or T == 10); sdirt_amd/newton.py runs that
- * check and re-launches with the corrected table when speculation fails. */
+ * check and re-launches with the corrected table when speculation fails.
+ * A NEGATIVE entry -T selects the speed mode for that surface: at most T trips, and every 64-ray
+ * wave leaves the loop as soon as none of ITS rays is open -- the reference's loop condition per
+ * wave instead of per batch; no host check is needed, results differ from the batch-exact ones
+ * in the low-order bits of t (PSFs to ~1e-5 of their peak). */
 int sdirt_trace(const sdirt_lens* lens, int32_t first, int32_t last, int32_t backward,
                 const int32_t* trips /*host [K]*/, uint32_t flags /*SDIRT_PSF_STRICT_IEEE or 0*/,
                 sdirt_rays rays, int64_t n_rays, uint32_t* conv_mask /*dev [K] or NULL*/,

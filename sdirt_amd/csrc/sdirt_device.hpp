@@ -308,7 +308,12 @@ __device__ __forceinline__ typename Lane<T>::Mask newton_k(const DevSurface& s, 
     const Mk alive = L::gt(r.ra, L::splat(0.0f));
     T t = t0;
     uint32_t mask = 0;
-    for (int it = 1; it <= trips; ++it) {
+    // trips >= 0: exactly that many trips (the reference's batch-wide count, supplied by the host).
+    // trips < 0: at most -trips, and this WAVE stops as soon as none of its 64 rays is open -- the
+    // reference's loop condition evaluated per wave instead of per batch (speed mode, no host check).
+    const bool adaptive = trips < 0;
+    const int cap = adaptive ? -trips : trips;
+    for (int it = 1; it <= cap; ++it) {
         const T nx = r.ox + r.dx * t, ny = r.oy + r.dy * t, nz = r.oz + r.dz * t;
         const T rr = nx * nx + ny * ny;
         const Mk inside = KGT ? L::lt(rr, L::splat(s.lim_loose)) : L::gt(rr, L::splat(0.0f));
@@ -321,8 +326,10 @@ __device__ __forceinline__ typename Lane<T>::Mask newton_k(const DevSurface& s, 
         const T dr2dt = 2.0f * (dd * t + dox);
         const T dfdt = dgd * dr2dt - r.dz;
         const bool open = L::any(L::gt(L::fabs(ft), L::splat(tol_loose)));
-        mask |= (__ballot(open) != 0ull) ? (1u << it) : 0u;
+        const bool wave_open = __ballot(open) != 0ull;
+        mask |= wave_open ? (1u << it) : 0u;
         t = t - clampv(M::div(ft, dfdt + eps), -kNewtonStepBound, kNewtonStepBound);
+        if (adaptive && !wave_open) break;
     }
     mask_out = mask;
     const T t1 = t - t0;   // :563

@@ -102,9 +102,9 @@ static int make_trips(const sdirt_lens* lens, const int32_t* trips, TripTable& t
     for (int k = 0; k < SDIRT_MAX_SURFACES; ++k) tt.t[k] = 0;
     for (int k = 0; k < lens->n_surfaces; ++k) {
         int v = trips ? trips[k] : SDIRT_NEWTON_MAXITER;
-        if (v < 0 || v > SDIRT_NEWTON_MAXITER)
-            return fail(SDIRT_ERR_INVALID_ARGUMENT, "trips[%d]=%d outside [0,%d]", k, v,
-                        SDIRT_NEWTON_MAXITER);
+        if (v < -SDIRT_NEWTON_MAXITER || v > SDIRT_NEWTON_MAXITER)
+            return fail(SDIRT_ERR_INVALID_ARGUMENT, "trips[%d]=%d outside [-%d,%d]", k, v,
+                        SDIRT_NEWTON_MAXITER, SDIRT_NEWTON_MAXITER);
         tt.t[k] = (int8_t)v;
     }
     return SDIRT_OK;

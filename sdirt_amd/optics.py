@@ -99,7 +99,9 @@ class Lensgroup:
         self._pupil_cache = {}         # entrance(bool) -> (z, r)
         self.trips = TripPlanner()
         #: 'reference' = reproduce the reference's batch-global Newton trip counts
-        #: (speculate + verify, newton.py); 'max' = always 10 trips, no host sync.
+        #: (speculate + verify, newton.py); 'max' = always 10 trips, no host sync;
+        #: 'adaptive' = speed mode: every 64-ray wave stops iterating when none of its rays is
+        #: open (<= 10 trips), no host sync -- not batch-exact (PSFs differ by ~1e-5 of peak).
         self.trip_policy = "reference"
         #: optional hook reducing convergence masks over ranks (set by sdirt_amd.dist)
         self.mask_reduce = None
@@ -271,13 +273,21 @@ class Lensgroup:
             m = self.mask_reduce(m)
         return m.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
 
+    def _fixed_trips(self):
+        """Trip table of the policies that need no host check: 10 everywhere ('max') or -10 =
+        "up to 10, each wave stops when its own rays are done" ('adaptive')."""
+        if self.trip_policy not in ("max", "adaptive"):
+            raise ValueError(f"unknown trip_policy {self.trip_policy!r}")
+        n = NEWTON_MAXITER if self.trip_policy == "max" else -NEWTON_MAXITER
+        return np.where(self._curved(), n, 0).astype(np.int32)
+
     def _run_with_trips(self, key, order, enqueue):
         """enqueue(trips_ctypes, mask_ptr) launches the kernels.  Returns the trip
         table that was finally used."""
         K = len(self.surfaces)
         curved = self._curved()
         if self.trip_policy != "reference":
-            trips = np.where(curved, NEWTON_MAXITER, 0).astype(np.int32)
+            trips = self._fixed_trips()
             enqueue((C.c_int32 * K)(*trips.tolist()), None)
             return trips
         mask = self._mask_buffer()
@@ -602,7 +612,7 @@ class Lensgroup:
                 self.trips.run_many(keys, self._curved(), list(range(K)), launch)
                 assert launch.any_valid == 1, "No sampled rays is valid."   # optics.py:902
             else:
-                full = np.where(self._curved(), NEWTON_MAXITER, 0)
+                full = self._fixed_trips()
                 enqueue2(full, full)
             if defer:
                 return PendingPSF(lambda: squeeze(L, R))

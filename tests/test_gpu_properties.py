@@ -309,3 +309,25 @@ def test_deferred_trip_check_equals_the_immediate_one():
     assert torch.allclose(L0, L3, atol=2e-6) and torch.allclose(R0, R3, atol=2e-6)
     for k, v in tabs.items():
         assert np.array_equal(lens.trips.cache[k], v), k
+
+
+def test_adaptive_speed_mode_stays_within_its_stated_distance():
+    """trip_policy='adaptive' (per-wave Newton exit, no host check): PSFs within 3e-4 of peak of
+    the batch-exact ones (SURVEY.md hard part 2's acceptance for adaptive Newton; measured ~1e-5),
+    chief-ray centres within 1e-5 mm, same validity."""
+    lens = make_lens("rf50mm", DEV)
+    g = load_golden("f8_rf50_mini_c2")
+    pts = torch.tensor(g["points"])
+    kw = dict(ks=65, spp=4096, pupil_xy=(g["pupil_x2"], g["pupil_y2"]),
+              center_pupil_xy=(g["pupil_xc"], g["pupil_yc"]))
+    L0, R0 = lens.psf_lr(pts, **kw)
+    lens.trip_policy = "adaptive"
+    launches = lens.trips.launches
+    L1, R1 = lens.psf_lr(pts, **kw)
+    assert lens.trips.launches == launches                   # no speculation / verification rounds
+    dl, dr = (L0 - L1).abs().max().item(), (R0 - R1).abs().max().item()
+    assert dl < 3e-4 and dr < 3e-4, (dl, dr)
+    assert (L1.amax((-1, -2)) - 1).abs().max().item() < 1e-5
+    lens.trip_policy = "bogus"
+    with pytest.raises(ValueError):
+        lens.psf_lr(pts[:1], **kw)
