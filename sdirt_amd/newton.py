@@ -33,7 +33,7 @@ def first_clear_bit(mask, upto):
     return None
 
 
-def verify(trips, masks, order, curved):
+def verify(trips, masks, order, curved, aggressive=False):
     """Check a speculated trip table against the convergence masks it produced.
 
     trips[k]  : trips run on surface k
@@ -43,7 +43,10 @@ def verify(trips, masks, order, curved):
 
     Returns (ok, new_trips).  When not ok, new_trips holds the corrected count
     for the first wrong surface and best guesses (from the same masks) for the
-    surfaces after it.
+    surfaces after it.  aggressive: a surface whose every trip was still open is
+    re-run with the full 10 trips (which always reveals the exact count) instead
+    of one more trip -- used from the second failed round on, so that a table far
+    below the truth is reached in a bounded number of rounds.
     """
     trips = np.asarray(trips, np.int32).copy()
     masks = [int(m) for m in masks]
@@ -64,7 +67,7 @@ def verify(trips, masks, order, curved):
         # that ran still had an open ray, one more trip is by far the likeliest answer (a
         # batch flips between neighbouring counts when its slowest ray changes).  Downstream
         # surfaces: their masks came from slightly different rays, use them as the next guess.
-        new[k] = j if j is not None else min(max(T, 0) + 1, NEWTON_MAXITER)
+        new[k] = j if j is not None else (NEWTON_MAXITER if aggressive else min(max(T, 0) + 1, NEWTON_MAXITER))
     return (not failed), new
 
 
@@ -108,11 +111,11 @@ class TripPlanner:
     def run(self, key, curved, order, launch, max_rounds=None):
         K = len(curved)
         trips = self.initial(key, curved)
-        rounds = max_rounds if max_rounds is not None else 2 * K + 2
-        for _ in range(rounds):
+        rounds = max_rounds if max_rounds is not None else 3 * K + 3
+        for i in range(rounds):
             masks = launch(trips)
             self.launches += 1
-            ok, new = verify(trips, masks, order, curved)
+            ok, new = verify(trips, masks, order, curved, aggressive=i > 0)
             if ok:
                 self.learn(key, trips)
                 return trips
@@ -128,11 +131,11 @@ class TripPlanner:
         `initial`) and has reported `masks` -- deferred verification, see Lensgroup.psf_lr."""
         K = len(curved)
         tables = [self.initial(k, curved) for k in keys] if first is None else first[0]
-        rounds = max_rounds if max_rounds is not None else 2 * K + 2
+        rounds = max_rounds if max_rounds is not None else 3 * K + 3
         for i in range(rounds):
             masks = first[1] if (first is not None and i == 0) else launch(tables)
             self.launches += 1
-            results = [verify(t, m, order, curved) for t, m in zip(tables, masks)]
+            results = [verify(t, m, order, curved, aggressive=i > 0) for t, m in zip(tables, masks)]
             if all(ok for ok, _ in results):
                 for k, t in zip(keys, tables):
                     self.learn(k, t)

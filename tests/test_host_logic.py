@@ -133,10 +133,11 @@ def test_trip_planner_converges_and_caches():
     need[2] = 5
     got = pl.run("k", curved, range(12), launch)
     assert list(got) == need and len(calls) == 5                  # wrong + corrected
-    # two trips short costs two corrections, never a wrong answer
+    # two trips short: one more, then the full 10 to read the exact count off the mask
     need[2] = 7
+    n = len(calls)
     got = pl.run("k", curved, range(12), launch)
-    assert list(got) == need
+    assert list(got) == need and len(calls) - n == 4
 
 
 def test_trip_planner_bets_on_the_most_frequent_table():
@@ -272,3 +273,55 @@ def test_host_pupil_mapping_expressions_match_the_reference():
     r = torch.sqrt(u_r2 * st["pupil_r"] ** 2)
     x2, y2 = (r * torch.cos(theta)).numpy(), (r * torch.sin(theta)).numpy()
     assert ulp_diff(x2, g["pupil_x2"]).max() <= 2 and ulp_diff(y2, g["pupil_y2"]).max() <= 2
+
+
+# ------------------------------------------------------------------ property tests (hypothesis)
+def _needs():
+    from hypothesis import strategies as st
+    return st.lists(st.integers(min_value=0, max_value=11), min_size=1, max_size=24)
+
+
+def test_trip_planner_always_lands_on_the_reference_table():
+    """Whatever table is speculated first, launch/verify rounds end on exactly the per-surface
+    counts the reference's batch-wide loop would run (need 11 = never converges -> cap 10)."""
+    from hypothesis import given, settings, strategies as st
+    from sdirt_amd.newton import TripPlanner
+
+    @settings(max_examples=200, deadline=None)
+    @given(_needs(), st.data())
+    def check(need, data):
+        curved = [n > 0 for n in need]
+        want = [min(n, 10) if c else 0 for n, c in zip(need, curved)]
+        order = list(range(len(need)))
+        if data.draw(st.booleans()):
+            order.reverse()                                   # backward tracing
+        pl = TripPlanner()
+        guess = data.draw(st.lists(st.integers(1, 10), min_size=len(need), max_size=len(need)))
+        pl.cache["k"] = np.asarray([g if c else 0 for g, c in zip(guess, curved)], np.int32)
+        rounds = []
+
+        def launch(trips):
+            rounds.append(list(trips))
+            return masks_for(trips, need)
+        got = pl.run("k", curved, order, launch)
+        assert list(got) == want
+        assert rounds[-1] == want and len(rounds) <= 3 * len(need) + 3
+        # and a second call with the same batch is a single launch
+        n = len(rounds)
+        assert list(pl.run("k", curved, order, launch)) == want and len(rounds) == n + 1
+    check()
+
+
+def test_shard_bounds_partition_properties():
+    from hypothesis import given, settings, strategies as st
+    from sdirt_amd.dist import shard_bounds
+
+    @settings(max_examples=200, deadline=None)
+    @given(st.integers(0, 100000), st.integers(1, 64))
+    def check(n, world):
+        b = shard_bounds(n, world)
+        assert len(b) == world and b[0][0] == 0 and b[-1][1] == n
+        assert all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+        sizes = [hi - lo for lo, hi in b]
+        assert max(sizes) - min(sizes) <= 1
+    check()
