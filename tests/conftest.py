@@ -57,8 +57,10 @@ def make_lens(name, device, state=None):
     scalars pinned to the reference fixture (lens_state_*.json)."""
     from sdirt_amd import Lensgroup
     st = state or load_state(name)
-    lens = Lensgroup(os.path.join(DATA, f"{name}.json"), sensor_res=(512, 768),
-                     post_computation=False, device=device)
+    path = os.path.join(DATA, f"{name}.json")
+    if not os.path.exists(path):                # test-only prescriptions live with the fixtures
+        path = os.path.join(GOLDEN, f"lens_{name}.json")
+    lens = Lensgroup(path, sensor_res=(512, 768), post_computation=False, device=device)
     lens.set_state(d_sensor=st["d_sensor"], hfov=st["hfov"],
                    pupil=(st["pupil_z"], st["pupil_r"]),
                    exit_pupil=(st["exit_pupil_z"], st["exit_pupil_r"]))

@@ -36,7 +36,8 @@ def rays_from_fixture(o, d, wvln=0.589):
 
 @pytest.mark.parametrize("precision", ["lean", "ieee"])
 @pytest.mark.parametrize("lens_name,fx", [("rf50mm", "f1_rf50_c1"), ("rf50mm", "f2_rf50_pts4"),
-                                          ("rf35mm", "f3_rf35_pts4")])
+                                          ("rf35mm", "f3_rf35_pts4"),
+                                          ("rf50mm_variant", "f11_rf50_variant_pts4")])
 def test_staged_trace_bit_exact_vs_oracle_and_close_to_reference(oracle, lens_name, fx, precision):
     """Both math policies -- the default lean division/sqrt and the compiler's IEEE
     sequences -- must reproduce the IEEE CPU oracle bit for bit."""
@@ -92,7 +93,8 @@ def test_sampling_matches_reference(oracle):
     assert np.array_equal(ray.d.cpu().numpy(), d_or)
 
 
-@pytest.mark.parametrize("lens_name,fx", [("rf50mm", "f2_rf50_pts4"), ("rf35mm", "f3_rf35_pts4")])
+@pytest.mark.parametrize("lens_name,fx", [("rf50mm", "f2_rf50_pts4"), ("rf35mm", "f3_rf35_pts4"),
+                                          ("rf50mm_variant", "f11_rf50_variant_pts4")])
 def test_chief_center(oracle, lens_name, fx):
     st, g = load_state(lens_name), load_golden(fx)
     lens = make_lens(lens_name, DEV, st)
@@ -161,7 +163,8 @@ def test_splat_synthetic_and_edges(oracle):
 
 @pytest.mark.parametrize("lens_name,fx,seed", [("rf50mm", "f1_rf50_c1", 0),
                                                ("rf50mm", "f2_rf50_pts4", 1),
-                                               ("rf35mm", "f3_rf35_pts4", 2)])
+                                               ("rf35mm", "f3_rf35_pts4", 2),
+                                               ("rf50mm_variant", "f11_rf50_variant_pts4", 11)])
 def test_psf_end_to_end_same_seed(oracle, lens_name, fx, seed):
     """Lensgroup.psf with the reference's seed: same RNG draws, own pupil mapping,
     own centre, fused kernel.  Few rays per pixel (spp 64..256), so one ray that
@@ -240,7 +243,8 @@ def test_rgb(oracle):
 
 
 @pytest.mark.parametrize("lens_name,n,spp,ks", [("rf50mm", 192, 4096, 65), ("rf35mm", 96, 2048, 33),
-                                                ("rf50mm", 1100, 1024, 21)])
+                                                ("rf50mm", 1100, 1024, 21),
+                                                ("rf50mm_variant", 64, 2048, 33)])
 def test_random_points_fused_vs_oracle(oracle, lens_name, n, spp, ks):
     """Random points over the whole field and depth range, BASELINE config-2 sampling density:
     the fused HIP kernels (own disc mapping, own centres, speculate+verify trips) against the

@@ -17,7 +17,10 @@ import pytest
 from conftest import load_golden, load_state, ulp_diff
 
 DP = [0.78, 1.44, 0.3, 0.5]
-CASES = [("rf50mm", "f1_rf50_c1"), ("rf50mm", "f2_rf50_pts4"), ("rf35mm", "f3_rf35_pts4")]
+# the variant prescription (oracle/gen_golden_variant.py) reaches a conic <= -1, an r^2 asphere term
+# and a flat refracting surface
+CASES = [("rf50mm", "f1_rf50_c1"), ("rf50mm", "f2_rf50_pts4"), ("rf35mm", "f3_rf35_pts4"),
+         ("rf50mm_variant", "f11_rf50_variant_pts4")]
 
 
 @pytest.mark.parametrize("lens_name,fx", CASES)
