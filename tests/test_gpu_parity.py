@@ -270,3 +270,30 @@ def test_random_points_fused_vs_oracle(oracle, lens_name, n, spp, ks):
     # identical rays, identical trip tables; what differs is summation order (LDS atomics vs
     # serial), acos/sqrt in the sub-pixel WEIGHTS (ocml vs libm) and the fp64 centroid order
     assert dl.max() <= 5e-6 and dr.max() <= 5e-6
+
+
+@pytest.mark.parametrize("lens_name", ["rf50mm", "rf35mm"])
+@pytest.mark.parametrize("tag", ["ent", "ext"])
+def test_partial_traces_in_both_directions(oracle, lens_name, tag):
+    """Lensgroup.trace(lens_range=...) backward through the front group and forward through the
+    rear group (the traces behind the paraxial pupils, fixture F12): bit-exact against the oracle,
+    equal trips / validity and close positions against the reference."""
+    st, g = load_state(lens_name), load_golden(f"f12_pupil_traces_{lens_name}")
+    lens = make_lens(lens_name, DEV, st)
+    a = int(g["aper_idx"])
+    K = len(lens.surfaces)
+    rng = range(0, a) if tag == "ent" else range(a + 1, K)
+    ray = rays_from_fixture(g[tag + "_o_in"], g[tag + "_d_in"])
+    ray, valid, _ = lens.trace(ray, lens_range=rng)
+    surf = oracle.surfaces_from_state(st, 0.589)
+    ref = oracle.trace(surf, g[tag + "_o_in"], g[tag + "_d_in"], np.ones(16, np.float32),
+                       first=rng[0], last=rng[-1] + 1)
+    o, d = ray.o.cpu().numpy(), ray.d.cpu().numpy()
+    assert np.array_equal(o, ref["o"]) and np.array_equal(d, ref["d"])
+    assert np.array_equal(ray.ra.cpu().numpy(), ref["ra"])
+    assert np.array_equal(ray.ra.cpu().numpy(), g[tag + "_ra"][-1])
+    assert np.abs(o - g[tag + "_o"][-1]).max() < 2e-6 and np.abs(d - g[tag + "_d"][-1]).max() < 2e-7
+    key = ("trace", 0.589, rng[0], rng[-1] + 1, tag == "ext", "lean")
+    used = lens.trips.cache[key]
+    order = list(rng) if tag == "ext" else list(rng)[::-1]
+    assert np.array_equal(used[order], g[tag + "_trips"])

@@ -147,3 +147,23 @@ def test_rgb_wavelength_tables(oracle):
         assert ok and np.abs(co - g["centers"][i]).max() < 4e-6
         assert np.abs(lo - g["psf"][:, i]).max() <= 3e-4       # 64 rays: single-ray sensitivity
     assert np.array_equal(g["trips"].shape, (6, 12))
+
+
+@pytest.mark.parametrize("lens_name", ["rf50mm", "rf35mm"])
+@pytest.mark.parametrize("tag", ["ent", "ext"])
+def test_partial_traces_in_both_directions(oracle, lens_name, tag):
+    """The 16-ray traces behind the paraxial pupils (optics.py:1335-1361): backward from the stop
+    through the front group, forward through the rear group -- per-surface states and trips."""
+    st, g = load_state(lens_name), load_golden(f"f12_pupil_traces_{lens_name}")
+    surf = oracle.surfaces_from_state(st, 0.589)
+    a = int(g["aper_idx"])
+    first, last = (0, a) if tag == "ent" else (a + 1, len(surf))
+    o, d = g[tag + "_o_in"], g[tag + "_d_in"]
+    assert (d[0, 2] < 0) == (tag == "ent")                     # entrance pupil: backward tracing
+    out = oracle.trace(surf, o, d, np.ones(len(o), np.float32), first=first, last=last, record=True)
+    order = range(first, last) if tag == "ext" else range(last - 1, first - 1, -1)
+    assert np.array_equal(out["trips"][list(order)], g[tag + "_trips"])
+    for step in range(last - first):
+        assert np.array_equal(out["rec_ra"][step], g[tag + "_ra"][step])
+        assert np.abs(out["rec_o"][step] - g[tag + "_o"][step]).max() < 2e-6, step
+        assert np.abs(out["rec_d"][step] - g[tag + "_d"][step]).max() < 2e-7, step
