@@ -186,6 +186,10 @@ def main():
         # the all-gather of step i runs on its own stream underneath the kernels of step i+1
         # (double-buffered: xGMI copy engines / RCCL channels vs. VALU-bound compute)
         comm_stream = torch.cuda.Stream(device)
+        # its own communicator: PyTorch runs all collectives of one process group on one internal
+        # stream, so a gather issued on the default group would hold back the next step's small
+        # pupil broadcast (and with it the next kernel) until 4 GB have moved
+        gather_group = dist.new_group() if args.gather else None
         gather_buf = [tuple(torch.empty((n_total, KS, KS), dtype=torch.float32, device=device)
                             for _ in range(2)) for _ in range(2)]          # (L_all, R_all) x 2
     step_no = [0]
@@ -230,8 +234,8 @@ def main():
             buf = gather_buf[idx]
             with torch.cuda.stream(comm_stream):
                 comm_stream.wait_event(ready)
-                sd.all_gather_shards(L, n_total, world, out=buf[0])     # no staging copy:
-                sd.all_gather_shards(R, n_total, world, out=buf[1])     # shards go straight out
+                sd.all_gather_shards(L, n_total, world, group=gather_group, out=buf[0])
+                sd.all_gather_shards(R, n_total, world, group=gather_group, out=buf[1])
                 done = torch.cuda.Event()
                 done.record(comm_stream)
             gather_done[idx] = done
