@@ -195,38 +195,35 @@ def main():
     step_no = [0]
     # output buffers are owned by the caller and re-used (two sets: the previous step's PSFs
     # may still be feeding the all-gather / the consumer while the next step renders)
+    DEPTH = 3        # calls kept in flight (kernel enqueued, Newton trip check pending)
     out_bufs = [tuple(torch.empty((n_local, KS, KS), dtype=torch.float32, device=device)
-                      for _ in range(2)) for _ in range(2)]
+                      for _ in range(2)) for _ in range(DEPTH + 1)]
 
     gather_done = [None, None]      # per buffer set: event of the last gather that read it
 
-    in_flight = [None]
+    in_flight = []
 
-    def settle():
-        """Newton trip check of the step whose kernel was enqueued last (lens.psf_lr(defer=True))."""
-        if in_flight[0] is not None:
-            in_flight[0].wait()
-            in_flight[0] = None
+    def settle(keep=0):
+        """Newton trip checks (lens.psf_lr(defer=True)) of all but the `keep` newest steps.  The
+        host stays a few kernels ahead of the GPU, so a descheduled host thread (the boxes are
+        shared) does not leave the GPU idle."""
+        while len(in_flight) > keep:
+            in_flight.pop(0).wait()
 
     def step():
         idx = step_no[0] % 2
-        out = out_bufs[idx]
+        out = out_bufs[step_no[0] % (DEPTH + 1)]
         if world == 1:
-            # keep one step in flight: the GPU starts step i+1 while the host verifies step i
             step_no[0] += 1
-            pending = lens.psf_lr(points_local, ks=KS, spp=SPP, dp=DP, out=out, defer=True)
-            settle()
-            in_flight[0] = pending
+            in_flight.append(lens.psf_lr(points_local, ks=KS, spp=SPP, dp=DP, out=out, defer=True))
+            settle(keep=DEPTH)
             return out
         if gather_done[idx] is not None:
             # the gather of two steps ago still reads these tensors on the comm stream
             torch.cuda.current_stream(device).wait_event(gather_done[idx])
         pupil = sd.broadcast_pupil_points(lens, SPP)
-        pending = sharded.render(points_local, pupil, out, defer=True)
-        settle()                      # trip check of the previous step, under this step's kernel
-        in_flight[0] = pending
-        if not args.no_gather:
-            settle()                  # shards must be final before they leave the GPU
+        in_flight.append(sharded.render(points_local, pupil, out, defer=True))
+        settle(keep=0 if not args.no_gather else DEPTH)   # gathered shards must be final
         L, R = out
         if not args.no_gather:
             ready = torch.cuda.Event()

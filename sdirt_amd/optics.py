@@ -316,6 +316,19 @@ class Lensgroup:
                                                 stream_ptr(self.device)))
         return ray
 
+    def _staging(self, spp, depth=8):
+        """A page-locked [2, spp] buffer from a ring of `depth` per size, and the event that
+        marks its upload as done; a slot is reused only after its previous upload has finished."""
+        ring = self.__dict__.setdefault("_stage_ring", {}).setdefault(spp, {"slots": [], "next": 0})
+        if len(ring["slots"]) < depth:
+            ring["slots"].append((torch.empty((2, spp), dtype=torch.float32, pin_memory=True),
+                                  torch.cuda.Event()))
+            return ring["slots"][-1]
+        slot = ring["slots"][ring["next"]]
+        ring["next"] = (ring["next"] + 1) % depth
+        slot[1].synchronize()
+        return slot
+
     def _pupil_samples(self, spp, pupil_r):
         """optics.py:483-488: spp points on the pupil disc -> device arrays (x2, y2).
 
@@ -328,13 +341,20 @@ class Lensgroup:
         (the Xeon that produced tests/golden and the EPYC of the GPU box disagree on ~5 % of
         the samples) -- at the price of threaded MKL calls (measured 24 ms per call on a
         256-thread host under a 16-CPU quota)."""
-        u_theta, u_r2 = torch.rand(spp), torch.rand(spp)
         if self.pupil_mapping == "host":
+            u_theta, u_r2 = torch.rand(spp), torch.rand(spp)
             theta = u_theta * 2 * np.pi
             r = torch.sqrt(u_r2 * pupil_r ** 2)
             xy = torch.stack((r * torch.cos(theta), r * torch.sin(theta))).to(self.device)
             return xy[0], xy[1]
-        u = torch.stack((u_theta, u_r2)).to(self.device)
+        # draw straight into page-locked memory (same generator, same values as torch.rand(spp))
+        # so that the upload is a true asynchronous copy: from pageable memory it would block
+        # the host until the stream has drained, i.e. until the previous call's kernel is done
+        stage, done = self._staging(spp)
+        torch.rand(spp, out=stage[0])
+        torch.rand(spp, out=stage[1])
+        u = stage.to(self.device, non_blocking=True)
+        done.record(torch.cuda.current_stream(self.device))
         xy = torch.empty((2, spp), dtype=torch.float32, device=self.device)
         _lib.check(_lib.lib().sdirt_pupil_samples(dptr(u[0]), dptr(u[1]), spp, float(pupil_r),
                                                   dptr(xy[0]), dptr(xy[1]),
