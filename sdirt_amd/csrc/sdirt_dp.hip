@@ -562,6 +562,20 @@ k_psf_lr(const DevSurface* __restrict__ lens, int K, TripTable trips,
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ float round_half(float v) { return (float)(_Float16)v; }
 
+// The fp16 arithmetic of the reference's _fast renderer (x.half() * psf.half(), summed in fp32)
+// on packed registers: (wl, wr) rounded to fp16 as a pair, one v_pk_mul_f16 per image value --
+// the fp16 product of two fp16 numbers IS round_half(float(v) * float(w)): their exact product
+// has 22 significant bits and fits fp32 -- and the two widening accumulations.
+typedef _Float16 hpair __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ hpair half_pair(float lo, float hi) { return hpair{(_Float16)lo, (_Float16)hi}; }
+__device__ __forceinline__ void mul_acc_half(float v, hpair w, float& accl, float& accr)
+{
+    const _Float16 vh = (_Float16)v;
+    const hpair p = hpair{vh, vh} * w;
+    accl = __builtin_fmaf((float)p[0], 1.0f, accl);
+    accr = __builtin_fmaf((float)p[1], 1.0f, accr);
+}
+
 // One WAVE per output pixel: the 64 lanes stride over the 2*ks*ks kernel taps of that
 // pixel, so the per-pixel PSFs -- the only large operand, 2*ks*ks*4 B per pixel, read exactly
 // once -- stream in as fully coalesced 256-B segments.  The image (a few MB) is gathered
@@ -601,16 +615,14 @@ k_local_psf_render(const float* __restrict__ img, const float* __restrict__ psf,
                     // stored tap f multiplies the neighbour at the FLIPPED offset (render_psf.py:138)
                     const int yy = min(max(y + (ks - 1 - fi) - pad, 0), H - 1);
                     const int xx = min(max(x + (ks - 1 - fj) - pad, 0), W - 1);
-                    float wl = kl[f], wr = kr[f];
-                    if (HALF) { wl = round_half(wl); wr = round_half(wr); }
+                    const float wl = kl[f], wr = kr[f];
+                    const hpair wpair = half_pair(wl, wr);
                     const float* px = img + ((int64_t)b * C * H + yy) * W + xx;
 #pragma unroll
                     for (int c = 0; c < C; ++c) {
                         float v = px[(int64_t)c * HW];
                         if (HALF) {
-                            v = round_half(v);
-                            accl[c] += round_half(v * wl);
-                            accr[c] += round_half(v * wr);
+                            mul_acc_half(v, wpair, accl[c], accr[c]);
                         } else {
                             accl[c] += v * wl;
                             accr[c] += v * wr;
@@ -713,16 +725,14 @@ k_local_psf_render_tiled(const float* __restrict__ img, const float* __restrict_
                         const int f = fi * ks + fj;
                         const int yy = min(max(y + (ks - 1 - fi) - pad, 0), H - 1);
                         const int xx = min(max(x + (ks - 1 - fj) - pad, 0), W - 1);
-                        float wl = kl[f], wr = kr[f];
-                        if (HALF) { wl = round_half(wl); wr = round_half(wr); }
+                        const float wl = kl[f], wr = kr[f];
+                        const hpair wpair = half_pair(wl, wr);
                         const float* px = img + ((int64_t)b * C * H + yy) * W + xx;
 #pragma unroll
                         for (int c = 0; c < C; ++c) {
                             float v = px[(int64_t)c * HW];
                             if (HALF) {
-                                v = round_half(v);
-                                accl[c] += round_half(v * wl);
-                                accr[c] += round_half(v * wr);
+                                mul_acc_half(v, wpair, accl[c], accr[c]);
                             } else {
                                 accl[c] += v * wl;
                                 accr[c] += v * wr;
@@ -818,15 +828,11 @@ k_psfnet_render(const float* __restrict__ img, const _Float16* __restrict__ raw_
                     if (lane_row < rows_per_iter && fi < ks && fj < ks) {
                         const int yy = min(max(y + (ks - 1 - fi) - pad, 0), H - 1);
                         const int xx = min(max(x + (ks - 1 - fj) - pad, 0), W - 1);
-                        const float wl = round_half((float)kl[fi * ks + fj] * inv_l);
-                        const float wr = round_half((float)kr[fi * ks + (ks - 1 - fj)] * inv_r);
+                        const hpair wpair = half_pair((float)kl[fi * ks + fj] * inv_l,
+                                                      (float)kr[fi * ks + (ks - 1 - fj)] * inv_r);
                         const float* px = img + ((int64_t)b * C * H + yy) * W + xx;
 #pragma unroll
-                        for (int c = 0; c < C; ++c) {
-                            const float v = round_half(px[(int64_t)c * HW]);
-                            accl[c] += round_half(v * wl);
-                            accr[c] += round_half(v * wr);
-                        }
+                        for (int c = 0; c < C; ++c) mul_acc_half(px[(int64_t)c * HW], wpair, accl[c], accr[c]);
                     }
                 }
             }
