@@ -432,7 +432,11 @@ class Lensgroup:
         return ps
 
     def _points_to_object(self, points):
-        pts = points.to(self.device, torch.float32).contiguous()
+        if not points.is_cuda:
+            # page-locked staging: an upload from pageable memory blocks the host until the
+            # stream has drained (i.e. until the previous call's kernel has finished)
+            points = points.to(torch.float32).contiguous().pin_memory()
+        pts = points.to(self.device, torch.float32, non_blocking=True).contiguous()
         out = torch.empty_like(pts)
         _lib.check(_lib.lib().sdirt_points_to_object(
             dptr(pts), pts.shape[0], float(np.tan(self.hfov)), float(self.r_last),

@@ -72,14 +72,17 @@ class PSFNet(Lensgroup):
         z[z_gauss < 0] = foc_z * z_gauss[z_gauss < 0] / 3 + foc_z
         return z
 
-    def get_training_data(self, bs=256, spp=4096):
-        """psfnet.py:170-202: (inp [bs,3] in [-1,1]^2 x [0,1], psf [bs,ks,ks] on the GPU)."""
+    def get_training_data(self, bs=256, spp=4096, _defer=False):
+        """psfnet.py:170-202: (inp [bs,3] in [-1,1]^2 x [0,1], psf [bs,ks,ks] on the GPU).
+        _defer: the second item is a PendingPSF (kernel enqueued, Newton trip check in .wait())."""
         foc_z = np.random.choice(self.foc_z_arr)
         x = (torch.rand(bs) - 0.5) * 2
         y = (torch.rand(bs) - 0.5) * 2
         z = self._warp_z(torch.clamp(torch.randn(bs), min=-3, max=3), foc_z)
         inp = torch.stack((x, y, z), dim=-1)
         points = torch.stack((x, y, self.z2depth(z)), dim=-1)
+        if _defer:
+            return inp, self.psf_diff(points=points, ks=self.kernel_size, spp=spp, _defer=True)
         return inp, self.psf(points=points, ks=self.kernel_size, spp=spp)
 
     def get_test_data(self, bs=1024, spp=65536):
@@ -174,18 +177,27 @@ class PSFNet(Lensgroup):
             main = torch.cuda.current_stream(self.device)
             side = torch.cuda.Stream(self.device)
 
+            produced = [0]
+
             def produce():
-                # the ray tracer's only host wait (the Newton trip check, newton.py) then blocks
-                # on `side`, while `main` keeps running the captured step
+                # enqueue only: the Newton trip check of this batch (newton.py) runs when the batch
+                # is consumed, two iterations later, by which time its kernel has long finished
+                produced[0] += 1
                 with torch.cuda.stream(side):
-                    inp, psf = self.get_training_data(bs=bs, spp=spp)
-                    inp = inp.to(self.device, non_blocking=True)
+                    inp, pend = self.get_training_data(bs=bs, spp=spp, _defer=True)
+                    inp = inp.pin_memory().to(self.device, non_blocking=True)
+                return inp, pend
+
+            def consume(item):
+                inp, pend = item
+                with torch.cuda.stream(side):
+                    psf = pend.wait()                          # re-launches (rare) go to `side` too
                     ready = torch.cuda.Event()
                     ready.record(side)
                 return inp, psf, ready
 
             side.wait_stream(main)
-            first = produce()
+            first = consume(produce())
             static_inp = torch.empty_like(first[0])
             static_psf = torch.empty_like(first[1])
             main.wait_event(first[2])
@@ -207,15 +219,18 @@ class PSFNet(Lensgroup):
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 static_loss = fwd_bwd()
-            nxt = first
+            queue = [first]
+            while produced[0] < min(iters + 1, 3):
+                queue.append(produce())
             for i in range(iters + 1):
-                inp, psf, ready = nxt
+                item = queue.pop(0)
+                inp, psf, ready = item if len(item) == 3 else consume(item)
                 main.wait_event(ready)
                 static_inp.copy_(inp); static_psf.copy_(psf)
                 inp.record_stream(main); psf.record_stream(main)
                 graph.replay()                                 # grads are rewritten, not accumulated
-                if i < iters:
-                    nxt = produce()
+                if produced[0] < iters + 1:
+                    queue.append(produce())
                 scaler.step(optim)
                 scaler.update()
                 sche.step()
