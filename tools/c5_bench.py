@@ -13,6 +13,7 @@ from sdirt_amd.psfnet import PSFNet
 from sdirt_amd.render_psf import local_psf_render_fast
 
 dev = "cuda:0"
+torch.backends.cudnn.benchmark = os.environ.get("SDIRT_MIOPEN_FIND", "0") == "1"
 H, W, ks = 512, 768, 21
 torch.manual_seed(0)
 m = PSFNet(os.path.join(os.path.dirname(__file__), "..", "sdirt_amd", "data", "rf50mm.json"),
