@@ -414,3 +414,33 @@ def test_random_prescriptions_trace_bit_exact_against_the_oracle(oracle, seed, t
             assert np.array_equal(ray.o.cpu().numpy(), ref["o"]), (seed, backward, precision)
             assert np.array_equal(ray.d.cpu().numpy(), ref["d"])
             assert np.array_equal(ray.obliq.cpu().numpy(), ref["obliq"])
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_dual_pixel_parameters_splat_against_the_oracle(oracle, seed):
+    """Fuzz of the DP model (monte_carlo.py:135-372): random microlens / stack geometry (h, f, w, r)
+    on both sides of r = 0.5, random sensor-plane rays incl. dead and out-of-window ones: L and R
+    grids of the HIP splat against the CPU oracle."""
+    from sdirt_amd import forward_integral_lr
+    rng = np.random.default_rng(100 + seed)
+    S, N, ks, ps = 512, 5, int(rng.choice([9, 21, 33])), 0.046875
+    h = float(rng.uniform(0.4, 1.1)); f = h + float(rng.uniform(0.3, 1.2))
+    w = float(rng.uniform(0.1, 0.45)); r = float(rng.uniform(0.15, 0.95))
+    half = (ks / 2 - 0.5) * ps
+    o = np.zeros((S, N, 3), np.float32)
+    o[..., :2] = rng.uniform(-1.25 * half, 1.25 * half, (S, N, 2))
+    o[..., 2] = 62.25
+    d = rng.normal(0, 0.2, (S, N, 3)).astype(np.float32)
+    d[..., 2] = 1.0
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    ra = (rng.random((S, N)) > 0.15).astype(np.float32)
+    cen = ((rng.random((N, 2)) - 0.5) * ps).astype(np.float32)
+    lg0, rg0 = oracle.forward_integral(o, d.astype(np.float32), ra, ps, ks, cen, dp=[h, f, w, r])
+    from test_gpu_parity import rays_from_fixture, t
+    ray = rays_from_fixture(o, d.astype(np.float32))
+    ray.ra = t(ra)
+    lg, rg = forward_integral_lr(ray, ps, ks, t(cen), [h, f, w, r, "l"])
+    scale = max(lg0.max(), rg0.max())
+    assert scale > 0
+    assert np.abs(lg.cpu().numpy() - lg0).max() <= 3e-6 * scale, (h, f, w, r)
+    assert np.abs(rg.cpu().numpy() - rg0).max() <= 3e-6 * scale, (h, f, w, r)
