@@ -297,3 +297,18 @@ def test_partial_traces_in_both_directions(oracle, lens_name, tag):
     used = lens.trips.cache[key]
     order = list(rng) if tag == "ext" else list(rng)[::-1]
     assert np.array_equal(used[order], g[tag + "_trips"])
+
+
+def test_splat_on_random_dual_pixel_geometries():
+    """HIP splat against the reference on six random (h, f, w, r) sets, both branches (F13)."""
+    from sdirt_amd import assign_points_to_pixels_big_r, assign_points_to_pixels_small_r
+    g = load_golden("f13_splat_fuzz")
+    ks, ps = int(g["ks"]), float(g["ps"])
+    xr = [(-ks / 2 + 0.5) * ps, (ks / 2 - 0.5) * ps]
+    for i, dp in enumerate(g["params"]):
+        fn = assign_points_to_pixels_small_r if dp[3] <= 0.5 else assign_points_to_pixels_big_r
+        l, r = fn(points=t(g[f"points{i}"]), ks=ks, x_range=xr, y_range=xr, ra=t(g[f"ra{i}"]),
+                  x_tan=t(g[f"x_tan{i}"]), param_list=list(dp) + ["l"])
+        scale = max(g[f"l{i}"].max(), g[f"r{i}"].max())
+        assert np.abs(l.cpu().numpy() - g[f"l{i}"]).max() <= 2e-6 * scale, (i, dp)
+        assert np.abs(r.cpu().numpy() - g[f"r{i}"]).max() <= 2e-6 * scale, (i, dp)

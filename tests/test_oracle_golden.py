@@ -167,3 +167,15 @@ def test_partial_traces_in_both_directions(oracle, lens_name, tag):
         assert np.array_equal(out["rec_ra"][step], g[tag + "_ra"][step])
         assert np.abs(out["rec_o"][step] - g[tag + "_o"][step]).max() < 2e-6, step
         assert np.abs(out["rec_d"][step] - g[tag + "_d"][step]).max() < 2e-7, step
+
+
+def test_splat_on_random_dual_pixel_geometries(oracle):
+    """Both splat branches on six random (h, f, w, r) sets (fixture F13, from the reference)."""
+    g = load_golden("f13_splat_fuzz")
+    ks, ps = int(g["ks"]), float(g["ps"])
+    xr = [(-ks / 2 + 0.5) * ps, (ks / 2 - 0.5) * ps]
+    for i, dp in enumerate(g["params"]):
+        l, r = oracle.assign_points_to_pixels(g[f"points{i}"], g[f"ra{i}"], g[f"x_tan{i}"], ks, xr, dp=list(dp))
+        scale = max(g[f"l{i}"].max(), g[f"r{i}"].max())
+        assert np.abs(l - g[f"l{i}"]).max() <= 5e-7 * scale, (i, dp)
+        assert np.abs(r - g[f"r{i}"]).max() <= 5e-7 * scale, (i, dp)
