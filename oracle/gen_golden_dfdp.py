@@ -86,6 +86,21 @@ def case():
     d["loss_total"] = np.float64(losses["total"].item())
     d["pred_depth_est"] = outputs["pred_depth_est"].numpy()
     d["gt_depth_roundtrip_err"] = np.float64((outputs["gt_depth"] - gt).abs().max().item())
+    # train_mode='deblur' (basenet.py:29-31, 65-69): the Mydeblur branch on top
+    torch.manual_seed(21)
+    base = bn.Basenet(train_mode="deblur").eval()
+    for k, v in base.deblur_net.state_dict().items():
+        d["dsum/" + k] = np.float64(v.double().sum().item())
+        d["dabs/" + k] = np.float64(v.double().abs().sum().item())
+    with torch.no_grad():
+        base.deblur_net.cam_attention.gamma.fill_(0.3)        # exercise the attention branch
+        losses, outputs = base.dfdp({"stack_rgb_img": torch.cat((xl, xr), 1), "AiF_img": xl,
+                                     "gt_depth": gt.clone()}, train=True)
+    d["deblur_loss_total"] = np.float64(losses["total"].item())
+    d["deblur_losses"] = np.asarray([losses["depth_est"].item(), losses["depth_fix"].item(),
+                                     losses["aif"].item()], np.float64)
+    d["pred_aif_head"] = outputs["pred_aif"][0, :, ::16, ::16].numpy()
+    d["pred_depth_fix_head"] = outputs["pred_depth_fix"][0, :, ::16, ::16].numpy()
     return d
 
 

@@ -186,15 +186,16 @@ class DfDPNet(nn.Module):
 class Basenet(nn.Module):
     """dfdp/basenet.py:9-105, depth-estimation mode: the DP pair rendered by PSFNet.render
     ([B,6,H,W], left views then right views) -> log-depth estimate, SmoothL1 loss on the pixels
-    with valid ground truth.  The optional deblurring branch (train_mode='deblur', Mydeblur) is
-    not built."""
+    with valid ground truth; train_mode='deblur' adds the Mydeblur branch (refined depth + deblurred
+    image, basenet.py:29-31, 65-69)."""
 
     def __init__(self, train_mode="dfdp"):
         super().__init__()
-        if train_mode != "dfdp":
-            raise NotImplementedError("only train_mode='dfdp' (depth estimation) is built")
+        if train_mode not in ("dfdp", "deblur"):
+            raise ValueError("train_mode must be 'dfdp' or 'deblur'")
         self.train_mode = train_mode
         self.dfdp_net = DfDPNet()
+        self.deblur_net = Mydeblur()        # always constructed, as in the reference (checkpoint keys)
 
     def forward(self, input_dict):
         with torch.autocast("cuda", dtype=torch.float16, enabled=input_dict["stack_rgb_img"].is_cuda):
@@ -215,19 +216,30 @@ class Basenet(nn.Module):
     def compute_loss(self, results, gts):
         l1 = nn.SmoothL1Loss(reduction="mean")
         est = l1(results["pred_depth_est"][self.mask], gts["gt_depth"][self.mask])
-        return {"depth_est": est, "total": est}
+        losses = {"depth_est": est, "total": est}
+        if self.train_mode == "deblur":                                      # basenet.py:65-69
+            losses["depth_fix"] = l1(results["pred_depth_fix"][self.mask], gts["gt_depth"][self.mask])
+            losses["aif"] = l1(results["pred_aif"], gts["gt_aif"])
+            losses["total"] = est * 2 + losses["depth_fix"] + losses["aif"]
+        return losses
 
     def dfdp(self, input_dict, train=False):
         stack, gt_aif = input_dict["stack_rgb_img"], input_dict["AiF_img"]
         left, right = stack[:, 0:3], stack[:, 3:]
         gt_depth = self.linear(input_dict["gt_depth"])
         depth_est = self.dfdp_net(left, right)
+        results = {"pred_depth_est": depth_est}
+        if self.train_mode == "deblur":
+            results["pred_depth_fix"], results["pred_aif"] = self.deblur_net(left, right, depth_est)
         losses = None
         if train:
-            losses = self.compute_loss({"pred_depth_est": depth_est}, {"gt_depth": gt_depth})
+            losses = self.compute_loss(results, {"gt_depth": gt_depth, "gt_aif": gt_aif})
         outputs = {"gt_depth": self.inverse_linear(gt_depth), "gt_aif": gt_aif, "gt_l": None, "gt_r": None,
                    "rt_render_l": left, "rt_render_r": right,
                    "pred_depth_est": self.inverse_linear(depth_est.to(torch.float32))}
+        if self.train_mode == "deblur":
+            outputs["pred_depth_fix"] = self.inverse_linear(results["pred_depth_fix"].to(torch.float32))
+            outputs["pred_aif"] = results["pred_aif"]
         return losses, outputs
 
     def inference(self, input_dict):
@@ -235,6 +247,155 @@ class Basenet(nn.Module):
         stack = input_dict["stack_rgb_img"]
         left, right = stack[:, 0:3], stack[:, 3:]
         depth_est = self.dfdp_net(left, right)
-        return {"gt_depth": self.inverse_linear(gt_depth), "gt_aif": gt_aif, "gt_l": left, "gt_r": right,
-                "rt_render_l": None, "rt_render_r": None,
-                "pred_depth_est": self.inverse_linear(depth_est.to(torch.float32), mask=False)}
+        out = {"gt_depth": self.inverse_linear(gt_depth), "gt_aif": gt_aif, "gt_l": left, "gt_r": right,
+               "rt_render_l": None, "rt_render_r": None,
+               "pred_depth_est": self.inverse_linear(depth_est.to(torch.float32), mask=False)}
+        if self.train_mode == "deblur":
+            fix, aif = self.deblur_net(left, right, depth_est)
+            out["pred_depth_fix"], out["pred_aif"] = self.inverse_linear(fix.to(torch.float32), mask=False), aif
+        return out
+
+
+# ---- optional deblurring branch (dddnet.py:15-100, 180-305) --------------------------------------
+def _init_deblur(m):
+    """dddnet.py:15-29 (`weight_init`)."""
+    name = m.__class__.__name__
+    if name.find("Conv") != -1 and hasattr(m, "kernel_size"):
+        n = m.kernel_size[0] * m.kernel_size[1] * m.out_channels
+        m.weight.data.normal_(0, 0.5 * (2.0 / n) ** 0.5)
+        if m.bias is not None:
+            m.bias.data.zero_()
+    elif name.find("BatchNorm") != -1:
+        m.weight.data.fill_(1)
+        m.bias.data.zero_()
+    elif name.find("Linear") != -1:
+        m.weight.data.normal_(0, 0.01)
+        m.bias.data = torch.ones(m.bias.data.size())
+
+
+def _res_pair(c):
+    return nn.Sequential(nn.Conv2d(c, c, kernel_size=3, padding=1), nn.ReLU(),
+                         nn.Conv2d(c, c, kernel_size=3, padding=1))
+
+
+class Encoder(nn.Module):
+    """Three resolution levels (32, 64, 128 channels), two residual conv pairs each."""
+
+    def __init__(self, in_channel=3, out_channel=128):
+        super().__init__()
+        self.layer1 = nn.Conv2d(in_channel, 32, kernel_size=3, padding=1)
+        self.layer2, self.layer3 = _res_pair(32), _res_pair(32)
+        self.layer5 = nn.Conv2d(32, 64, kernel_size=3, stride=2, padding=1)
+        self.layer6, self.layer7 = _res_pair(64), _res_pair(64)
+        self.layer9 = nn.Conv2d(64, 128, kernel_size=3, stride=2, padding=1)
+        self.layer10 = _res_pair(128)
+        self.layer11 = nn.Sequential(nn.Conv2d(128, 128, kernel_size=3, padding=1), nn.ReLU(),
+                                     nn.Conv2d(128, out_channel, kernel_size=3, padding=1))
+
+    def forward(self, x):
+        x = self.layer1(x)
+        for blk in (self.layer2, self.layer3):
+            x = blk(x) + x
+        x = self.layer5(x)
+        for blk in (self.layer6, self.layer7):
+            x = blk(x) + x
+        x = self.layer9(x)
+        for blk in (self.layer10, self.layer11):
+            x = blk(x) + x
+        return x
+
+
+class Decoder(nn.Module):
+    def __init__(self, in_channel=128, out_channel=3):
+        super().__init__()
+        self.layer13 = nn.Sequential(nn.Conv2d(in_channel, 128, kernel_size=3, padding=1), nn.ReLU(),
+                                     nn.Conv2d(128, 128, kernel_size=3, padding=1))
+        self.layer14 = _res_pair(128)
+        self.layer16 = nn.ConvTranspose2d(128, 64, kernel_size=4, stride=2, padding=1)
+        self.layer17, self.layer18 = _res_pair(64), _res_pair(64)
+        self.layer20 = nn.ConvTranspose2d(64, 32, kernel_size=4, stride=2, padding=1)
+        self.layer21, self.layer22 = _res_pair(32), _res_pair(32)
+        self.layer24 = nn.Conv2d(32, out_channel, kernel_size=3, padding=1)
+
+    def forward(self, x):
+        for blk in (self.layer13, self.layer14):
+            x = blk(x) + x
+        x = self.layer16(x)
+        for blk in (self.layer17, self.layer18):
+            x = blk(x) + x
+        x = self.layer20(x)
+        for blk in (self.layer21, self.layer22):
+            x = blk(x) + x
+        return self.layer24(x)
+
+
+class CAM_Module(nn.Module):
+    """Channel attention: softmax(max(E) - E) V with E = X X^T over flattened pixels, gated by gamma."""
+
+    def __init__(self, in_dim):
+        super().__init__()
+        self.chanel_in = in_dim
+        self.gamma = nn.Parameter(torch.zeros(1))
+
+    def forward(self, x):
+        B, C, H, W = x.shape
+        q = x.view(B, C, -1)
+        energy = torch.bmm(q, q.permute(0, 2, 1))
+        att = torch.softmax(torch.max(energy, -1, keepdim=True)[0].expand_as(energy) - energy, dim=-1)
+        return self.gamma * torch.bmm(att, q).view(B, C, H, W) + x
+
+
+class ConvBlock(nn.Module):
+    def __init__(self, cin, cout, kernel_size=3, stride=1, padding=1, bias=True, activation="prelu", norm=None):
+        super().__init__()
+        self.conv = nn.Conv2d(cin, cout, kernel_size, stride, padding, bias=bias)
+        self.norm = norm
+        if norm == "batch":
+            self.bn = nn.BatchNorm2d(cout)
+        elif norm == "instance":
+            self.bn = nn.InstanceNorm2d(cout)
+        self.activation = activation
+        acts = {"relu": lambda: nn.ReLU(True), "prelu": nn.PReLU, "lrelu": lambda: nn.LeakyReLU(0.2, True),
+                "tanh": nn.Tanh, "sigmoid": nn.Sigmoid}
+        if activation is not None:
+            self.act = acts[activation]()
+
+    def forward(self, x):
+        x = self.conv(x)
+        if self.norm is not None:
+            x = self.bn(x)
+        return self.act(x) if self.activation is not None else x
+
+
+class Mydeblur(nn.Module):
+    """dddnet.py:32-100: three-level patch hierarchy (quarters -> halves -> full frame) of
+    encoder/decoder pairs on cat(left, right, disparity), a channel-attention branch on the view
+    difference; returns (refined disparity [B,1,H,W], deblurred image [B,3,H,W])."""
+
+    def __init__(self):
+        super().__init__()
+        self.feat = 128
+        self.encoder1 = Encoder(7, self.feat).apply(_init_deblur)
+        self.encoder2 = Encoder(7, self.feat).apply(_init_deblur)
+        self.encoder3 = Encoder(7, self.feat).apply(_init_deblur)
+        self.decoder3 = Decoder(self.feat, 7).apply(_init_deblur)
+        self.decoder2 = Decoder(self.feat, 7).apply(_init_deblur)
+        self.decoder1 = Decoder(self.feat, 3).apply(_init_deblur)
+        self.decoderd = Decoder(self.feat, 1).apply(_init_deblur)
+        self.cam_attention = CAM_Module(self.feat)
+        self.down = ConvBlock(4, self.feat, 8, 4, 2, activation="sigmoid", norm=None)
+        self.conv = ConvBlock(self.feat, 1, 3, 1, 1, activation="sigmoid", norm=None)
+
+    def forward(self, image_left, image_right, est_blurdisp):
+        H, W = image_left.shape[2:]
+        lv1 = torch.cat((image_left, image_right, est_blurdisp), 1)
+        top, bot = lv1[:, :, :H // 2], lv1[:, :, H // 2:]
+        quads = [top[..., :W // 2], top[..., W // 2:], bot[..., :W // 2], bot[..., W // 2:]]
+        f3 = [self.encoder3(q) for q in quads]
+        f3_top, f3_bot = torch.cat(f3[:2], 3), torch.cat(f3[2:], 3)
+        f3_all = torch.cat((f3_top, f3_bot), 2)
+        r3_top, r3_bot = self.decoder3(f3_top), self.decoder3(f3_bot)
+        f2_all = torch.cat((self.encoder2(top + r3_top), self.encoder2(bot + r3_bot)), 2) + f3_all
+        f1 = self.encoder1(lv1 + self.decoder2(f2_all)) + f2_all
+        att = self.cam_attention(self.down(torch.cat((image_left - image_right, est_blurdisp), 1)))
+        return self.decoderd(f1 + att), self.decoder1(f1 + att)

@@ -62,8 +62,34 @@ def test_basenet_depth_mode_matches_the_reference():
     np.testing.assert_allclose(outputs["pred_depth_est"].numpy(), fx["pred_depth_est"], rtol=2e-4, atol=1e-5)
     assert (outputs["gt_depth"] - inputs.gt).abs().max().item() <= float(fx["gt_depth_roundtrip_err"]) + 1e-6
     assert outputs["gt_depth"] is gt                                   # transformed in place, as the reference
-    with pytest.raises(NotImplementedError):
-        Basenet(train_mode="deblur")
+    with pytest.raises(ValueError):
+        Basenet(train_mode="other")
+
+
+def test_basenet_deblur_mode_matches_the_reference():
+    """Mydeblur (dddnet.py:32-100, 180-305) under Basenet(train_mode='deblur'): same seeded weights
+    (per-tensor checksums), same three losses, same refined depth and deblurred image."""
+    from sdirt_amd.dfdp import Basenet
+    fx = load_golden("f10_dfdp_net")
+    xl, xr, _, _ = inputs(fx)
+    torch.manual_seed(int(fx["seed"]))
+    base = Basenet(train_mode="deblur").eval()
+    sd = base.deblur_net.state_dict()
+    keys = [k[5:] for k in fx.files if k.startswith("dsum/")]
+    assert sorted(keys) == sorted(sd)
+    for k in keys:
+        assert sd[k].double().sum().item() == pytest.approx(float(fx["dsum/" + k]), rel=1e-10, abs=1e-10), k
+        assert sd[k].double().abs().sum().item() == pytest.approx(float(fx["dabs/" + k]), rel=1e-10, abs=1e-12), k
+    with torch.no_grad():
+        base.deblur_net.cam_attention.gamma.fill_(0.3)
+        losses, outputs = base.dfdp({"stack_rgb_img": torch.cat((xl, xr), 1), "AiF_img": xl,
+                                     "gt_depth": inputs.gt.clone()}, train=True)
+    got = [losses["depth_est"].item(), losses["depth_fix"].item(), losses["aif"].item()]
+    np.testing.assert_allclose(got, fx["deblur_losses"], rtol=2e-4)
+    assert losses["total"].item() == pytest.approx(float(fx["deblur_loss_total"]), rel=2e-4)
+    np.testing.assert_allclose(outputs["pred_aif"][0, :, ::16, ::16].numpy(), fx["pred_aif_head"], rtol=1e-3, atol=2e-5)
+    np.testing.assert_allclose(outputs["pred_depth_fix"][0, :, ::16, ::16].numpy(), fx["pred_depth_fix_head"],
+                               rtol=1e-3, atol=2e-5)
 
 
 @pytest.mark.gpu
@@ -96,3 +122,13 @@ def test_dfdp_net_and_cost_volume_kernel_on_the_gpu():
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):   # as Basenet.forward runs it
         disp16 = net(xl.to(dev), xr.to(dev))
     assert np.abs(disp16.float().cpu().numpy() - fx["disp"]).max() < 5e-2
+    # the deblurring branch on the GPU (fp32 MIOpen convolutions vs the reference's CPU result)
+    from sdirt_amd.dfdp import Basenet
+    torch.manual_seed(int(fx["seed"]))
+    base = Basenet(train_mode="deblur").eval().to(dev)
+    with torch.no_grad():
+        base.deblur_net.cam_attention.gamma.fill_(0.3)
+        losses, outputs = base.dfdp({"stack_rgb_img": torch.cat((xl, xr), 1).to(dev), "AiF_img": xl.to(dev),
+                                     "gt_depth": inputs.gt.clone().to(dev)}, train=True)
+    assert losses["total"].item() == pytest.approx(float(fx["deblur_loss_total"]), rel=2e-3)
+    assert np.abs(outputs["pred_aif"][0, :, ::16, ::16].cpu().numpy() - fx["pred_aif_head"]).max() < 2e-3
