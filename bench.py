@@ -8,16 +8,19 @@ Lensgroup.psf_lr call over the rank's 16384 points: draw the pupil uniforms
 (torch CPU generator, the reference's order), chief-ray centre pass (2048 rays
 per point) and the sample->trace->splat->normalise pass in ONE fused kernel launch,
 verification of the batch-global Newton trip counts (of step i while step i+1 runs).  For N > 1
-the ranks share the pupil sample set (48 KB broadcast) and the trip check (mask all-reduce);
---gather adds the RCCL all-gather of the PSF shards.  Weak scaling: every rank renders its own
-16384-point slab of a 32x32x(16*N) volume.
+the ranks share the pupil sample set (48 KB broadcast) and the trip check (mask all-reduce), and
+the PSF shards are all-gathered to every rank over RCCL (north_star's reassembly step; on a side
+stream under the next step's kernels) -- `value` includes it, `value_no_gather` is the rate of the
+same loop without it.  Weak scaling: every rank renders its own 16384-point slab of a
+32x32x(16*N) volume.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1: starts its own N ranks)
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
 Rank 0 prints ONE JSON line (see the driver contract); `roofline` describes the
 dominant kernel (k_psf_lr), `cpu_baseline` times oracle/ (a C port of the
-reference's CPU path, OpenMP over the host cores) on a bounded sample of the
+reference's CPU path, OpenMP over the host cores, and a PyTorch-CPU restatement of
+the reference's whole-tensor execution model) on a bounded sample of the
 same workload.  oracle/ is only loaded for that baseline leg.
 """
 import argparse
@@ -94,10 +97,18 @@ def available_cores():
     return n
 
 
-def cpu_baseline(lens, points, budget_s=15.0):
-    """Times the CPU oracle (C port of the reference path, OpenMP) on every k-th
-    point of the same volume with the same 4096-spp sample set."""
-    from oracle import oracle as orc
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def lens_state(lens):
+    """The scalars and the surface table of `lens` in the form the oracle takes."""
     st = dict(hfov=lens.hfov, r_last=float(lens.r_last), sensor_size=list(lens.sensor_size),
               pupil_z=lens.entrance_pupil()[0], pupil_r=lens.entrance_pupil()[1],
               d_sensor=lens.d_sensor, pixel_size=lens.pixel_size, surfaces=[])
@@ -107,6 +118,19 @@ def cpu_baseline(lens, points, budget_s=15.0):
                                    ai=[float(a) for a in (s.ai if s.ai is not None else [])],
                                    n1={repr(0.589): s.mat1.ior(0.589)},
                                    n2={repr(0.589): s.mat2.ior(0.589)}))
+    return st
+
+
+def cpu_baseline(lens, points, budget_s=12.0):
+    """Times the two CPU restatements of the reference path on every k-th point of the same
+    volume with the same 4096-spp sample set, on the cores this process may use:
+      * `value` (kind "port"): oracle/sdirt_oracle.c, a per-ray C port with OpenMP -- the
+        strongest CPU implementation of the path we have;
+      * `torch`: oracle/torch_port.py, the reference's own execution model (whole-tensor fp32
+        PyTorch ops, 256 points per pass, torch.set_num_threads(cores))."""
+    from oracle import oracle as orc
+    from oracle import torch_port as tp
+    st = lens_state(lens)
     cores = available_cores()
     orc.set_num_threads(cores)
     rng = np.random.default_rng(0)
@@ -116,8 +140,11 @@ def cpu_baseline(lens, points, budget_s=15.0):
                                rng.random(2048, dtype=np.float32), st["pupil_r"] * 0.25)
     pts = points.numpy()
 
+    def subset(n):
+        return pts[:: max(1, len(pts) // n)][:n]
+
     def run(n):
-        sel = pts[:: max(1, len(pts) // n)][:n]
+        sel = subset(n)
         t0 = time.perf_counter()
         orc.psf(st, sel, x2, y2, xc, yc, KS, dp=list(DP))
         return len(sel), time.perf_counter() - t0
@@ -125,11 +152,68 @@ def cpu_baseline(lens, points, budget_s=15.0):
     n = int(min(len(pts), max(64, n0 * budget_s / max(t0, 1e-3))))
     n = min(n, 16384)                                   # bound memory: [S, n, 3] fp32 x 2 = 2.1 GB
     n1, t1 = run(n)
-    return {"value": n1 * SPP / t1, "unit": "rays/s", "cores": cores, "kind": "port",
-            "psfs_per_s": n1 / t1,
-            "sample": f"{n1} of the {len(pts)} point sources (every {max(1, len(pts) // n)}-th), "
-                      f"4096 spp + 2048 chief-ray rays each, ks 65, L+R, {t1:.1f} s; "
-                      "oracle/sdirt_oracle.c with OpenMP"}
+    res = {"value": n1 * SPP / t1, "unit": "rays/s", "cores": cores, "kind": "port",
+           "cpu_model": cpu_model(), "psfs_per_s": n1 / t1,
+           "sample": f"{n1} of the {len(pts)} point sources (every {max(1, len(pts) // n)}-th), "
+                     f"{SPP} spp + 2048 chief-ray rays each, ks {KS}, L+R, {t1:.1f} s; "
+                     "oracle/sdirt_oracle.c with OpenMP"}
+
+    old_threads = torch.get_num_threads()
+    torch.set_num_threads(cores)
+    try:
+        def run_t(n):
+            sel = subset(n)
+            t0 = time.perf_counter()
+            tp.psf(st, sel, x2, y2, xc, yc, KS, dp=list(DP), chunk=256)
+            return len(sel), time.perf_counter() - t0
+        run_t(64)                                       # thread pool / allocator warm-up
+        m0, u0 = run_t(256)
+        m = int(min(len(pts), max(256, (m0 * budget_s / max(u0, 1e-3)) // 256 * 256)))
+        m1, u1 = run_t(m) if m > m0 else (m0, u0)
+        res["torch"] = {"value": m1 * SPP / u1, "unit": "rays/s", "threads": cores,
+                        "psfs_per_s": m1 / u1, "torch": torch.__version__,
+                        "sample": f"{m1} point sources in passes of 256, {u1:.1f} s; "
+                                  "oracle/torch_port.py (builder's PyTorch-CPU restatement of the "
+                                  "reference's whole-tensor op sequence)"}
+    finally:
+        torch.set_num_threads(old_threads)
+    return res
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) without a launcher: start N fresh rank processes with
+    torch.distributed.run and relay their output and exit code.  Runs BEFORE anything here has
+    touched the GPU (this process never does: it only counts devices)."""
+    import socket
+    import subprocess
+    backend = os.environ.get("SDIRT_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()            # does not initialise the GPU
+    if backend == "nccl" and ndev < args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but {ndev} GPU(s) visible.  (Dry run of the "
+                         "multi-rank control flow on fewer GPUs: SDIRT_BENCH_BACKEND=gloo; its "
+                         "numbers mean nothing.)\n")
+        return 2
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=dict(os.environ))
+
+
+def pmc_counters(workload):
+    """PMC counters of k_psf_lr carried over from a rocprofv3 --pmc run of this same command
+    (counters cannot be read from inside the process): newest profiles/rNN/pmc_<workload>.json."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"pmc_{workload}.json")))
+    if files:
+        with open(files[-1]) as f:
+            c = json.load(f)
+        c["file"] = os.path.relpath(files[-1], ROOT)
+        return c
+    return None
 
 
 def main():
@@ -137,15 +221,19 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--gather", action="store_true",
-                    help="N > 1: also all-gather the PSF shards to every rank (RCCL, on a side "
-                         "stream under the next step's kernels).  Off by default: point sources "
-                         "are independent, the path itself has no exchange step")
-    ap.add_argument("--no-gather", action="store_true", help="(default; kept for older scripts)")
+    ap.add_argument("--no-gather", action="store_true",
+                    help="N > 1: skip the RCCL all-gather of the PSF shards (by default every rank "
+                         "ends each step with the whole PSF volume; `value_no_gather` is reported "
+                         "beside `value` either way)")
+    ap.add_argument("--gather", action="store_true", help="(default; kept for older scripts)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sustain-seconds", type=float, default=2.0,
+                    help="after the K timed steps, keep stepping for this long and report "
+                         "ms_per_step_sustained (0 = skip)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2")
     args = ap.parse_args()
-    args.no_gather = not args.gather
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     global KS, SPP, GRID_Z
     wl = WORKLOADS[args.workload]
     KS, SPP = wl["ks"], wl["spp"]
@@ -180,6 +268,7 @@ def main():
     a, b = sd.shard_bounds(n_total, world)[rank]
     points_local = points_all[a:b].to(device)
     n_local = b - a
+    gather_default = world > 1 and not args.no_gather
 
     if world > 1:
         sharded = sd.ShardedPSF.from_lens(lens, KS, dp=DP)
@@ -189,55 +278,67 @@ def main():
         # its own communicator: PyTorch runs all collectives of one process group on one internal
         # stream, so a gather issued on the default group would hold back the next step's small
         # pupil broadcast (and with it the next kernel) until 4 GB have moved
-        gather_group = dist.new_group() if args.gather else None
+        gather_group = dist.new_group() if gather_default else None
         gather_buf = [tuple(torch.empty((n_total, KS, KS), dtype=torch.float32, device=device)
-                            for _ in range(2)) for _ in range(2)]          # (L_all, R_all) x 2
+                            for _ in range(2)) for _ in range(2)] if gather_default else None
     step_no = [0]
-    # output buffers are owned by the caller and re-used (two sets: the previous step's PSFs
-    # may still be feeding the all-gather / the consumer while the next step renders)
+    # output buffers are owned by the caller and re-used (the previous steps' PSFs may still be
+    # feeding the all-gather / the consumer while the next step renders)
     DEPTH = 3        # calls kept in flight (kernel enqueued, Newton trip check pending)
     out_bufs = [tuple(torch.empty((n_local, KS, KS), dtype=torch.float32, device=device)
                       for _ in range(2)) for _ in range(DEPTH + 1)]
 
-    gather_done = [None, None]      # per buffer set: event of the last gather that read it
-
-    in_flight = []
+    gather_done = [None] * (DEPTH + 1)   # per output buffer set: event of the last gather reading it
+    gathers = [0]
+    in_flight = []                       # (PendingPSF, out, slot, ready event | None)
 
     def settle(keep=0):
-        """Newton trip checks (lens.psf_lr(defer=True)) of all but the `keep` newest steps.  The
-        host stays a few kernels ahead of the GPU, so a descheduled host thread (the boxes are
-        shared) does not leave the GPU idle."""
+        """Newton trip checks (lens.psf_lr(defer=True)) of all but the `keep` newest steps, each
+        followed -- when the step asked for it -- by the all-gather of its now final shards on
+        the comm stream.  The host stays `keep` kernels ahead of the GPU: the GPU renders step
+        i+1 while the host verifies step i and RCCL moves step i's PSFs, and a descheduled host
+        thread (the boxes are shared) does not leave the GPU idle."""
         while len(in_flight) > keep:
-            in_flight.pop(0).wait()
-
-    def step():
-        idx = step_no[0] % 2
-        out = out_bufs[step_no[0] % (DEPTH + 1)]
-        if world == 1:
-            step_no[0] += 1
-            in_flight.append(lens.psf_lr(points_local, ks=KS, spp=SPP, dp=DP, out=out, defer=True))
-            settle(keep=DEPTH)
-            return out
-        if gather_done[idx] is not None:
-            # the gather of two steps ago still reads these tensors on the comm stream
-            torch.cuda.current_stream(device).wait_event(gather_done[idx])
-        pupil = sd.broadcast_pupil_points(lens, SPP)
-        in_flight.append(sharded.render(points_local, pupil, out, defer=True))
-        settle(keep=0 if not args.no_gather else DEPTH)   # gathered shards must be final
-        L, R = out
-        if not args.no_gather:
-            ready = torch.cuda.Event()
-            ready.record(torch.cuda.current_stream(device))
-            buf = gather_buf[idx]
+            pend, out, slot, ready = in_flight.pop(0)
+            r0 = lens.trips.relaunches
+            pend.wait()
+            if ready is None:
+                continue
+            if lens.trips.relaunches != r0:          # re-rendered: the shards are ready later
+                ready = torch.cuda.Event()
+                ready.record(torch.cuda.current_stream(device))
+            buf = gather_buf[gathers[0] % 2]
+            gathers[0] += 1
             with torch.cuda.stream(comm_stream):
                 comm_stream.wait_event(ready)
-                sd.all_gather_shards(L, n_total, world, group=gather_group, out=buf[0])
-                sd.all_gather_shards(R, n_total, world, group=gather_group, out=buf[1])
+                sd.all_gather_shards(out[0], n_total, world, group=gather_group, out=buf[0])
+                sd.all_gather_shards(out[1], n_total, world, group=gather_group, out=buf[1])
                 done = torch.cuda.Event()
                 done.record(comm_stream)
-            gather_done[idx] = done
+            gather_done[slot] = done
+
+    def step(gather):
+        slot = step_no[0] % (DEPTH + 1)
+        out = out_bufs[slot]
         step_no[0] += 1
-        return L, R
+        if world == 1:
+            in_flight.append((lens.psf_lr(points_local, ks=KS, spp=SPP, dp=DP, out=out, defer=True),
+                              out, slot, None))
+            settle(keep=DEPTH)
+            return out
+        if gather_done[slot] is not None:
+            # an earlier gather may still read these tensors on the comm stream
+            torch.cuda.current_stream(device).wait_event(gather_done[slot])
+            gather_done[slot] = None
+        pupil = sd.broadcast_pupil_points(lens, SPP)
+        pend = sharded.render(points_local, pupil, out, defer=True)
+        ready = None
+        if gather:
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(device))
+        in_flight.append((pend, out, slot, ready))
+        settle(keep=1 if gather else DEPTH)
+        return out
 
     def fence():
         settle()
@@ -246,31 +347,45 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(device)
 
+    def timed(k, gather):
+        """k steps between two fences; wall time = MAX over ranks."""
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            step(gather)
+        fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        return dt
+
     # one-off initialisation, like loading the library: the first call on a lens discovers the
     # Newton trip tables (a launch with 10 trips everywhere, then the verified table); they are
     # lens state from then on.  Done before the W warm-up steps so that W = 0 still times K
     # steady-state steps.
-    step()
+    step(gather_default)
     settle()
     for _ in range(args.warmup):
-        step()
+        step(gather_default)
     lens.kernel_events = {}
     relaunch0 = lens.trips.relaunches
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    dt = timed(args.steps, gather_default)
+    relaunches = lens.trips.relaunches - relaunch0
 
     ev = lens.kernel_events
     lens.kernel_events = None
     k_ms = {k: float(np.mean([e0.elapsed_time(e1) for e0, e1 in v])) for k, v in ev.items()}
     n_launch = {k: len(v) for k, v in ev.items()}
+
+    # the same K steps without the all-gather (N > 1), and a loop long enough for the clocks to
+    # settle (the K-step region lasts a fraction of a second)
+    dt_ng = timed(args.steps, False) if gather_default else None
+    k_sus = dt_sus = None
+    if args.sustain_seconds > 0:
+        k_sus = max(args.steps, int(math.ceil(args.sustain_seconds / (dt / args.steps))))
+        dt_sus = timed(k_sus, gather_default)
 
     if rank == 0:
         rays = n_total * SPP * args.steps
@@ -280,10 +395,8 @@ def main():
         dom = "psf_lr_centered" if "psf_lr_centered" in k_ms else "psf_lr"
         ach = alg_bytes / (k_ms[dom] * 1e-3) / 1e9
         traffic = valu = None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(pmc) and args.workload == "c2":
-            with open(pmc) as f:
-                counters = json.load(f)
+        counters = pmc_counters(args.workload)
+        if counters:
             traffic = counters.get("k_psf_lr_hbm_bytes_per_launch")
             n_instr = counters.get("k_psf_lr_valu_wave_instructions_per_launch")
             if n_instr:
@@ -294,7 +407,10 @@ def main():
                 valu = {"wave_instructions_per_launch": n_instr,
                         "achieved_per_s": n_instr / (k_ms[dom] * 1e-3), "peak_per_s": peak,
                         "frac": n_instr / (k_ms[dom] * 1e-3) / peak,
-                        "source": "SQ_INSTS_VALU, profiles/r01/summary_g_single_launch.json"}
+                        "source": {"kind": "carried: SQ_INSTS_VALU of a separate rocprofv3 --pmc run "
+                                           "of this command, divided by THIS run's kernel time",
+                                   "file": counters["file"], "collected": counters.get("collected"),
+                                   "commit": counters.get("commit")}}
         res = {
             "metric": f"rays/sec {wl['lens']} {KS}x{KS} DP-PSF @{SPP}spp", "value": rays / dt,
             "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -311,10 +427,11 @@ def main():
                                       + ("" if world == 1 else
                                          ", shared pupil samples (48 KB broadcast) and batch-global "
                                          "Newton trip check (mask all-reduce) per step")
-                                      + ("" if world == 1 or args.no_gather
-                                         else " + RCCL all-gather of the PSF volume"),
+                                      + (" + RCCL all-gather of the PSF volume to every rank"
+                                         if gather_default else ""),
+                       "gather": bool(gather_default),
                        "newton_trip_policy": lens.trip_policy,
-                       "relaunches_in_timed_region": lens.trips.relaunches - relaunch0},
+                       "relaunches_in_timed_region": relaunches},
             "kernels_ms": k_ms, "kernel_launches": n_launch,
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
@@ -324,10 +441,21 @@ def main():
                          "note": "scalar-per-ray fp32 math: the kernel is VALU-bound by "
                                  "construction (~6.4 k VALU instr/ray vs 8.25 B/ray), DESIGN.md §3"},
         }
+        if dt_ng is not None:
+            res["value_no_gather"] = rays / dt_ng
+            res["ms_per_step_no_gather"] = dt_ng / args.steps * 1e3
+            gb = 2 * (world - 1) * n_local * KS * KS * 4 / 1e9      # received per rank and step
+            res["gather"] = {"algo": os.environ.get("SDIRT_GATHER_ALGO", "allgather"),
+                             "gb_received_per_rank_per_step": gb}
+        if dt_sus is not None:
+            res["ms_per_step_sustained"] = dt_sus / k_sus * 1e3
+            res["value_sustained"] = n_total * SPP * k_sus / dt_sus
+            res["sustained_steps"] = k_sus
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(lens, points_all)
-        print(json.dumps(res))
+        print(json.dumps(res), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

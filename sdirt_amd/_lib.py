@@ -81,6 +81,44 @@ SIGNATURES = {
     "sdirt_dp_cost_volume_backward": (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P, _P]),
 }
 
+class StreamArg:
+    """A hipStream_t together with the GPU it belongs to.  ctypes passes `_as_parameter_`;
+    the wrappers installed by lib() read `.index` to make that GPU the current HIP device for
+    the duration of the call (a kernel launch goes to the CURRENT device: torch's default stream
+    handle is 0 on every GPU, so the handle alone does not say where to run)."""
+    __slots__ = ("_as_parameter_", "index")
+
+    def __init__(self, handle, index):
+        self._as_parameter_ = C.c_void_p(handle)
+        self.index = index
+
+
+class _Library:
+    """Entry points of libsdirt_dp.so; every call whose stream argument is a StreamArg runs
+    with that stream's GPU current (lens on cuda:1 while the caller's current device is cuda:0)."""
+
+    def __init__(self, handle):
+        self._handle = handle
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+            setattr(self, name, self._guard(fn) if args and args[-1] is _P else fn)
+
+    @staticmethod
+    def _guard(fn):
+        def call(*args):
+            st = args[-1]
+            if isinstance(st, StreamArg):
+                import torch
+                if st.index != torch.cuda.current_device():
+                    with torch.cuda.device(st.index):
+                        return fn(*args)
+            return fn(*args)
+        call.__name__ = fn.__name__
+        return call
+
+
 _lib = None
 
 
@@ -106,13 +144,10 @@ def lib():
             h = C.CDLL(LIB_PATH)
         except OSError as e:      # pragma: no cover
             raise SdirtError(f"cannot load {LIB_PATH}: {e}") from e
-        for name, (res, args) in SIGNATURES.items():
-            fn = getattr(h, name)
-            fn.restype = res
-            fn.argtypes = args
-        if h.sdirt_abi_version() != 1:
+        wrapped = _Library(h)
+        if wrapped.sdirt_abi_version() != 1:
             raise SdirtError("libsdirt_dp.so ABI version mismatch; rebuild")
-        _lib = h
+        _lib = wrapped
     return _lib
 
 

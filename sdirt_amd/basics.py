@@ -35,10 +35,12 @@ def require_gpu(device):
 
 
 def stream_ptr(device=None):
-    """hipStream_t of torch's current stream as an integer for ctypes."""
+    """torch's current stream on `device` as a ctypes argument that also names its GPU
+    (_lib.StreamArg): the call it is passed to runs with that GPU as the current HIP device."""
     if device is not None:
         require_gpu(device)
-    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    st = torch.cuda.current_stream(device)
+    return _lib.StreamArg(st.cuda_stream, st.device.index)
 
 
 def dptr(t):

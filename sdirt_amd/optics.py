@@ -525,10 +525,15 @@ class Lensgroup:
         if single_point:
             points = points.unsqueeze(0)
         N = points.shape[0]
-        if N == 0:                       # empty batch: nothing to trace, no random numbers drawn
+        if N == 0 and not (self.mask_reduce is not None and center
+                           and self.trip_policy == "reference"):
+            # empty batch: nothing to trace, no random numbers drawn
             e = torch.empty((0, ks, ks), dtype=torch.float32, device=self.device)
-            return e, (e.clone() if want_r else None)
-        po = self._points_to_object(points)
+            res = (e, (e.clone() if want_r else None))
+            return PendingPSF(lambda: res) if defer else res
+        # (an empty SHARD of a multi-rank call goes on: its rank must enter the same mask
+        # reductions and take the same re-launch decisions as its peers, with nothing to launch)
+        po = self._points_to_object(points) if N else torch.empty((0, 3), device=self.device)
         # RNG order of the reference: primary pupil samples first (optics.py:963),
         # then the chief-ray samples inside psf_center (optics.py:969).
         pupilz, pupilr = self.entrance_pupil()
@@ -579,6 +584,8 @@ class Lensgroup:
             reference = self.trip_policy == "reference"
 
             def enqueue2(tp, tc):
+                if N == 0:
+                    return
                 with self._timed("psf_lr_centered"):
                     _lib.check(_lib.lib().sdirt_psf_lr_centered(
                         handle, handle_c, dptr(po), N, dptr(x2), dptr(y2), spp, dptr(xc), dptr(yc),
@@ -604,7 +611,9 @@ class Lensgroup:
                     ctl.zero_()
                     enqueue2(tables[0], tables[1])
                     if self.mask_reduce is not None:
-                        masks[:, :K] = self.mask_reduce(masks[:, :K].reshape(-1)).reshape(2, K)
+                        # masks AND the any-valid flag, OR-ed over ranks: every rank verifies the
+                        # same block, so all of them re-launch -- or raise -- together
+                        ctl.copy_(self.mask_reduce(ctl))
 
                 def read_masks(host):
                     m = host[:2 * MS].reshape(2, MS)[:, :K].astype(np.int64) & 0xFFFFFFFF

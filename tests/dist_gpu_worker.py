@@ -1,0 +1,81 @@
+"""One rank of tests/test_gpu_dist.py: the REAL renderer under a 2-rank process group.
+
+Both ranks share cuda:0 (the GPU boxes of the pool have one GPU); collectives go through gloo,
+exactly the control flow `bench.py` runs with SDIRT_BENCH_BACKEND=gloo and -- with RCCL in place
+of gloo -- on an 8-GPU node.  Rank 0 then renders the whole grid alone from the same seed and
+compares.  Prints one JSON line per rank; exit code 0 = all assertions held.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from conftest import make_lens
+    from sdirt_amd import dist as sd
+
+    ks, spp, dp = 33, 1024, (0.78, 1.44, 0.3, 0.5)
+    # 15 points: the first shard (7) is far and on axis, the second (8) near and off axis --
+    # the ranks' OWN slowest rays differ, the batch-global trip table must still be common
+    far = torch.tensor([[0.0, 0.0, -20000.0]]).repeat(7, 1) + torch.linspace(0, 0.05, 7)[:, None] * torch.tensor([[1.0, 1.0, 0.0]])
+    g = torch.linspace(-0.95, 0.95, 8)
+    near = torch.stack([g, -g, torch.linspace(-200.0, -400.0, 8)], dim=-1)
+    points = torch.cat([far, near])
+
+    lens = make_lens("rf50mm", "cuda:0")
+    sharded = sd.ShardedPSF.from_lens(lens, ks, dp=dp)
+    torch.manual_seed(1234 + rank)        # only rank 0's generator may matter
+    if rank == 0:
+        torch.manual_seed(7)
+    L, R = sharded.psf_volume(points, spp, gather=True)
+    tables = {str(k): v.tolist() for k, v in lens.trips.cache.items()}
+    out = {"rank": rank, "shape": list(L.shape), "tables": tables,
+           "relaunches": lens.trips.relaunches}
+
+    # an EMPTY shard: 1 point over 2 ranks -> rank 0 renders nothing but must still enter the
+    # mask reductions (and take the same decisions) or rank 1 would hang
+    L1, R1 = sharded.psf_volume(points[8:9], spp, gather=True)
+    assert L1.shape == (1, ks, ks) and float(L1.max()) > 0.99
+    out["empty_shard_ok"] = True
+
+    gathered = [None] * world
+    dist.all_gather_object(gathered, tables)
+    assert all(t == gathered[0] for t in gathered), f"ranks verified different trip tables: {gathered}"
+
+    if rank == 0:
+        solo = make_lens("rf50mm", "cuda:0")
+        torch.manual_seed(7)
+        Ls, Rs = solo.psf_lr(points, ks=ks, spp=spp, dp=dp)
+        solo_tables = {str(k): v.tolist() for k, v in solo.trips.cache.items()}
+        dl = float((L - Ls).abs().max())
+        dr = float((R - Rs).abs().max())
+        out.update(max_abs_diff_L=dl, max_abs_diff_R=dr, solo_tables=solo_tables)
+        assert L.shape == (15, ks, ks)
+        assert solo_tables == tables, (solo_tables, tables)
+        assert dl <= 3e-6 and dr <= 3e-6, (dl, dr)
+        # the table a rank would have verified from ITS OWN rays only (what makes the OR-reduce
+        # matter): rendered with fresh lenses, no reduction
+        own = []
+        for a, b in sd.shard_bounds(15, 2):
+            l2 = make_lens("rf50mm", "cuda:0")
+            torch.manual_seed(7)
+            l2.psf_lr(points[a:b], ks=ks, spp=spp, dp=dp)
+            own.append({str(k): v.tolist() for k, v in l2.trips.cache.items()})
+        out["own_tables_differ"] = own[0] != own[1]
+    print(json.dumps(out), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -179,3 +179,25 @@ def test_splat_on_random_dual_pixel_geometries(oracle):
         scale = max(g[f"l{i}"].max(), g[f"r{i}"].max())
         assert np.abs(l - g[f"l{i}"]).max() <= 5e-7 * scale, (i, dp)
         assert np.abs(r - g[f"r{i}"]).max() <= 5e-7 * scale, (i, dp)
+
+
+@pytest.mark.parametrize("lens_name,fx", CASES)
+def test_torch_port_follows_the_reference(oracle, lens_name, fx):
+    """oracle/torch_port.py (the PyTorch-CPU leg of bench.py's cpu_baseline) runs the reference's
+    batch-global Newton trip counts and lands on the reference's PSFs (64-spp fixtures: a ray that
+    moves across a pixel boundary shows at the 1e-3 level; it is a timing baseline, not the
+    bit-level oracle)."""
+    from oracle import torch_port as tp
+    st, g = load_state(lens_name), load_golden(fx)
+    ks = int(g["ks"])
+    L, R, cen, trips = tp.psf(st, g["points"], g["pupil_x2"], g["pupil_y2"], g["pupil_xc"],
+                              g["pupil_yc"], ks)
+    assert trips == g["trips"].tolist()
+    assert np.abs(cen.numpy() - g["center"]).max() < 1e-5
+    assert np.abs(L.numpy() - g["psf"]).max() < 3e-3
+    assert float(R.abs().max()) == 0.0                     # param_list=None leaves R empty
+    lo, ro, _, _ = oracle.psf(st, g["points"], g["pupil_x2"], g["pupil_y2"], g["pupil_xc"],
+                              g["pupil_yc"], ks, dp=DP)
+    L2, R2, _, _ = tp.psf(st, g["points"], g["pupil_x2"], g["pupil_y2"], g["pupil_xc"],
+                          g["pupil_yc"], ks, dp=DP)
+    assert np.abs(L2.numpy() - lo).max() < 3e-3 and np.abs(R2.numpy() - ro).max() < 3e-3
