@@ -16,31 +16,132 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace sdirt {
 
 constexpr int kMaxAi = 8;
 constexpr float kNewtonStepBound = 5.0f;   // deeplens/surfaces.py:29
 
-// Flat per-surface constant block.  Every field that the reference obtains by
-// rounding a Python/numpy float64 to fp32 at the point of use is rounded on the
-// host, once, in sdirt_lens_create (see sdirt_dp.hip: make_dev_surface).
-struct DevSurface {
-    int32_t kind;        // 0 plane, 1 sphere, 2 asphere
-    int32_t ai_degree;
-    int32_t do_refract;  // plane: eta != 1 (surfaces.py:450); curved: always 1
-    int32_t k_gt_m1;     // k > -1 (surfaces.py:727,738)
-    float d, c, k;
-    float r_lim;         // fp32(r)                         surfaces.py:421
-    float r2_lim;        // fp32(r*r in double)             surfaces.py:464,728
+// ---------------------------------------------------------------------------
+// Per-surface constants in device memory: two 64-byte blocks per surface, laid out for the
+// scalar unit.  A wave reads block `h` with ONE s_load_dwordx16 per surface (into 16 SGPRs:
+// no VGPRs, no LDS bandwidth) and block `p` with one more on aspheres only.  Every field the
+// reference obtains by rounding a Python/numpy float64 to fp32 at the point of use is rounded on
+// the host, once, in sdirt_lens_create (sdirt_dp.hip: make_dev_surface).
+// ---------------------------------------------------------------------------
+struct alignas(64) SurfHot {
+    uint32_t flags;      // bits 0-1 kind (0 plane, 1 sphere, 2 asphere) | 2 do_refract (plane: eta != 1,
+                         // surfaces.py:450) | 3 k > -1 (:727,738) | 4 c > 0 | 8-11 ai_degree
+    float d, c;
     float c2;            // c*c (fp32)
     float onepk;         // 1 + k
-    float lim_loose;     // ((1/c2) * fp32(1-1e-9)) / (1+k) surfaces.py:728,739
-    float d_plus_R;      // d + 1/c                         surfaces.py:607-615
+    float lim_loose;     // ((1/c2) * fp32(1-1e-9)) / (1+k)   surfaces.py:728,739
+    float r2_lim;        // fp32(r*r in double)               surfaces.py:464,728
+    float lim_tight;     // curved: min(r2_lim, lim_loose) when k > -1, else r2_lim -- the two domain
+                         // tests of _valid (surfaces.py:727-733) as one; planes: fp32(r) (surfaces.py:421)
+    // dwords 8-11: what refraction needs when tracing forward; 12-15: the same for backward
+    float d_plus_R;      // d + 1/c                           surfaces.py:607-615
     float eta_f, eta2_f; // forward: fp32(n1/n2), fp32((n1/n2)^2)   surfaces.py:401,663-669
+    float k;
+    float d_plus_R_b;    // = d_plus_R
     float eta_b, eta2_b; // backward: fp32(n2/n1), fp32((n2/n1)^2)  surfaces.py:404
+    uint32_t pad;
+};
+struct alignas(64) SurfPoly {
     float ai[kMaxAi];    // ai2, ai4, ...
     float kai[kMaxAi];   // (i+1) * ai[i]  (python int * fp32 tensor)  surfaces.py:823
 };
+struct DevSurface {
+    SurfHot h;
+    SurfPoly p;
+};
+static_assert(sizeof(SurfHot) == 64 && sizeof(SurfPoly) == 64 && sizeof(DevSurface) == 128, "layout");
+
+constexpr uint32_t kFlagRefract = 4u, kFlagKgtM1 = 8u, kFlagCpos = 16u;
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+
+// One 64-byte block through the scalar cache into 16 consecutive SGPRs, waited for on the spot.
+// The address is wave-uniform by construction.
+__device__ __forceinline__ u32x16 sload_block(const void* p)
+{
+    u32x16 r;
+    asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(r) : "s"(p) : "memory");
+    return r;
+}
+
+// The constants of one surface in registers: 12 SGPRs, fetched with ONE scalar-memory round trip
+// per surface (two loads, one wait).  Left to the compiler, the fields of a `const DevSurface&`
+// are fetched where they are first used: seven dependent s_load / s_waitcnt round trips (and one
+// vector load for the trip count) per surface in round 1's ISA, a quarter of every wave's time.
+struct Surf {
+    u32x8 a;      // flags d c c2 onepk lim_loose r2_lim lim_tight
+    u32x4 b;      // d_plus_R eta eta2 (direction-specific)
+    __device__ __forceinline__ int kind() const { return (int)(a[0] & 3u); }
+    __device__ __forceinline__ int ai_degree() const { return (int)((a[0] >> 8) & 15u); }
+    __device__ __forceinline__ bool do_refract() const { return (a[0] & kFlagRefract) != 0u; }
+    __device__ __forceinline__ bool k_gt_m1() const { return (a[0] & kFlagKgtM1) != 0u; }
+    __device__ __forceinline__ bool c_pos() const { return (a[0] & kFlagCpos) != 0u; }
+    __device__ __forceinline__ float d() const { return __uint_as_float(a[1]); }
+    __device__ __forceinline__ float c() const { return __uint_as_float(a[2]); }
+    __device__ __forceinline__ float c2() const { return __uint_as_float(a[3]); }
+    __device__ __forceinline__ float onepk() const { return __uint_as_float(a[4]); }
+    __device__ __forceinline__ float lim_loose() const { return __uint_as_float(a[5]); }
+    __device__ __forceinline__ float r2_lim() const { return __uint_as_float(a[6]); }
+    __device__ __forceinline__ float lim_tight() const { return __uint_as_float(a[7]); }
+    __device__ __forceinline__ float r_lim() const { return __uint_as_float(a[7]); }     // planes
+    __device__ __forceinline__ float d_plus_R() const { return __uint_as_float(b[0]); }
+    __device__ __forceinline__ float eta() const { return __uint_as_float(b[1]); }
+    __device__ __forceinline__ float eta2() const { return __uint_as_float(b[2]); }
+};
+
+// One surface's constants in flight: the two loads of its block plus the dword of the launch's
+// Newton trip table that holds its count (trip_words: the table in the kernel-argument segment,
+// one signed byte per surface).  surf_issue() starts the three scalar loads, surf_wait() is the
+// s_waitcnt that makes the registers readable -- the trace loop issues surface k+1's loads in the
+// middle of surface k (after its Newton solve, before its refraction) and waits at the end of
+// surface k, so the scalar-cache latency (which the wave otherwise sits out once per surface:
+// measured as a 3.5 % loss on the 21-surface rf35mm) is covered by ~100 vector instructions.
+// Between issue and wait the registers must not be touched: they are outputs of one asm statement
+// and in/outs of the next, with no other use in between.
+struct SurfRaw {
+    u32x8 a;
+    u32x4 b;
+    uint32_t tw;
+};
+
+template <bool FWD>
+__device__ __forceinline__ void surf_issue(SurfRaw& n, const DevSurface* blk, const void* trip_words, int k)
+{
+    const uint32_t off = (uint32_t)(k >> 2) << 2;
+    if (FWD)
+        asm volatile("s_load_dwordx8 %0, %3, 0x0\n\ts_load_dwordx4 %1, %3, 0x20\n\ts_load_dword %2, %4, %5"
+                     : "=&s"(n.a), "=&s"(n.b), "=&s"(n.tw) : "s"(blk), "s"(trip_words), "s"(off) : "memory");
+    else
+        asm volatile("s_load_dwordx8 %0, %3, 0x0\n\ts_load_dwordx4 %1, %3, 0x30\n\ts_load_dword %2, %4, %5"
+                     : "=&s"(n.a), "=&s"(n.b), "=&s"(n.tw) : "s"(blk), "s"(trip_words), "s"(off) : "memory");
+}
+
+__device__ __forceinline__ void surf_wait(SurfRaw& n)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(n.a), "+s"(n.b), "+s"(n.tw) : : "memory");
+}
+
+__device__ __forceinline__ int surf_trips(const SurfRaw& n, int k)
+{
+    return (int)(int8_t)(n.tw >> ((k & 3) * 8));
+}
+
+// The polynomial block in registers (aspheres only): ai(i) = w[i], kai(i) = w[8 + i].
+struct Poly {
+    u32x16 w;
+    __device__ __forceinline__ float ai(int i) const { return __uint_as_float(w[i]); }
+    __device__ __forceinline__ float kai(int i) const { return __uint_as_float(w[8 + i]); }
+};
+struct NoPoly {};
 
 struct DevDpParams {
     float h, f, w, r;    // fp32 of the python floats        monte_carlo.py:157-164
@@ -53,104 +154,9 @@ struct DevDpParams {
     float inv_r;
 };
 
-// ---------------------------------------------------------------------------
-// Lane types.  The trace core is written once, generic in the per-lane value type:
-//   float : one ray per lane -- what every kernel instantiates;
-//   f2    : two rays per lane.  Kept as a tested experiment: on gfx950 the compiler
-//           turns the adds/multiplies into v_pk_mul_f32 / v_pk_add_f32, results are
-//           bit-identical, but a packed fp32 op occupies the SIMD-32 for twice the
-//           passes of a scalar one (the 157 TFLOP/s vector-fp32 peak is already the
-//           un-packed FMA rate), so it buys nothing: measured 5.35 / 12.09 ms
-//           (f2) against 5.08 / 11.76 ms (float) for k_chief_center / k_psf_lr.
-// ---------------------------------------------------------------------------
-typedef float f2 __attribute__((ext_vector_type(2)));
-typedef int i2 __attribute__((ext_vector_type(2)));
-
-template <class T> struct Lane;
-
-template <> struct Lane<float> {
-    using Mask = bool;
-    static constexpr int width = 1;
-    static __device__ __forceinline__ float splat(float v) { return v; }
-    static __device__ __forceinline__ Mask lt(float a, float b) { return a < b; }
-    static __device__ __forceinline__ Mask le(float a, float b) { return a <= b; }
-    static __device__ __forceinline__ Mask gt(float a, float b) { return a > b; }
-    static __device__ __forceinline__ Mask ge(float a, float b) { return a >= b; }
-    static __device__ __forceinline__ Mask isnan(float a) { return a != a; }
-    static __device__ __forceinline__ Mask mand(Mask a, Mask b) { return a && b; }
-    static __device__ __forceinline__ Mask mnot(Mask a) { return !a; }
-    static __device__ __forceinline__ Mask all(bool u) { return u; }
-    static __device__ __forceinline__ bool any(Mask m) { return m; }
-    static __device__ __forceinline__ float sel(Mask m, float a, float b) { return m ? a : b; }
-    static __device__ __forceinline__ float to01(Mask m) { return m ? 1.0f : 0.0f; }
-    static __device__ __forceinline__ float fabs(float a) { return __builtin_fabsf(a); }
-    static __device__ __forceinline__ float fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
-    static __device__ __forceinline__ float sqrt_ieee(float a) { return __builtin_sqrtf(a); }
-    static __device__ __forceinline__ float sqrt_fast(float a) { return __builtin_amdgcn_sqrtf(a); }
-    static __device__ __forceinline__ float rcp_fast(float a) { return __builtin_amdgcn_rcpf(a); }
-    static __device__ __forceinline__ float rsq_fast(float a) { return __builtin_amdgcn_rsqf(a); }
-    static __device__ __forceinline__ float next_up(float a) { return __uint_as_float(__float_as_uint(a) + 1u); }
-    static __device__ __forceinline__ float next_down(float a) { return __uint_as_float(__float_as_uint(a) - 1u); }
-    static __device__ __forceinline__ Mask is_zero_or_pinf(float a)
-    {
-        return __builtin_amdgcn_classf(a, 0x260);   // -0 | +0 | +inf
-    }
-    template <class F> static __device__ __forceinline__ float map(float a, F f) { return f(a); }
+struct Ray {
+    float ox, oy, oz, dx, dy, dz, ra, ob;
 };
-
-template <> struct Lane<f2> {
-    using Mask = i2;
-    static constexpr int width = 2;
-    static __device__ __forceinline__ f2 splat(float v) { return f2{v, v}; }
-    static __device__ __forceinline__ Mask lt(f2 a, f2 b) { return a < b; }
-    static __device__ __forceinline__ Mask le(f2 a, f2 b) { return a <= b; }
-    static __device__ __forceinline__ Mask gt(f2 a, f2 b) { return a > b; }
-    static __device__ __forceinline__ Mask ge(f2 a, f2 b) { return a >= b; }
-    static __device__ __forceinline__ Mask isnan(f2 a) { return a != a; }
-    static __device__ __forceinline__ Mask mand(Mask a, Mask b) { return a & b; }
-    static __device__ __forceinline__ Mask mnot(Mask a) { return ~a; }
-    static __device__ __forceinline__ Mask all(bool u) { return u ? i2{-1, -1} : i2{0, 0}; }
-    static __device__ __forceinline__ bool any(Mask m) { return (m.x | m.y) != 0; }
-    static __device__ __forceinline__ f2 sel(Mask m, f2 a, f2 b)
-    {
-        return f2{m.x ? a.x : b.x, m.y ? a.y : b.y};
-    }
-    static __device__ __forceinline__ f2 to01(Mask m) { return f2{m.x ? 1.0f : 0.0f, m.y ? 1.0f : 0.0f}; }
-    static __device__ __forceinline__ f2 fabs(f2 a) { return f2{__builtin_fabsf(a.x), __builtin_fabsf(a.y)}; }
-    static __device__ __forceinline__ f2 fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
-    static __device__ __forceinline__ f2 sqrt_ieee(f2 a) { return f2{__builtin_sqrtf(a.x), __builtin_sqrtf(a.y)}; }
-    static __device__ __forceinline__ f2 sqrt_fast(f2 a)
-    {
-        return f2{__builtin_amdgcn_sqrtf(a.x), __builtin_amdgcn_sqrtf(a.y)};
-    }
-    static __device__ __forceinline__ f2 rcp_fast(f2 a)
-    {
-        return f2{__builtin_amdgcn_rcpf(a.x), __builtin_amdgcn_rcpf(a.y)};
-    }
-    static __device__ __forceinline__ Mask is_zero_or_pinf(f2 a)
-    {
-        return i2{__builtin_amdgcn_classf(a.x, 0x260) ? -1 : 0, __builtin_amdgcn_classf(a.y, 0x260) ? -1 : 0};
-    }
-    static __device__ __forceinline__ f2 next_up(f2 a)
-    {
-        return f2{__uint_as_float(__float_as_uint(a.x) + 1u), __uint_as_float(__float_as_uint(a.y) + 1u)};
-    }
-    static __device__ __forceinline__ f2 next_down(f2 a)
-    {
-        return f2{__uint_as_float(__float_as_uint(a.x) - 1u), __uint_as_float(__float_as_uint(a.y) - 1u)};
-    }
-    static __device__ __forceinline__ f2 rsq_fast(f2 a)
-    {
-        return f2{__builtin_amdgcn_rsqf(a.x), __builtin_amdgcn_rsqf(a.y)};
-    }
-    template <class F> static __device__ __forceinline__ f2 map(f2 a, F f) { return f2{f(a.x), f(a.y)}; }
-};
-
-template <class T>
-struct RayT {
-    T ox, oy, oz, dx, dy, dz, ra, ob;
-};
-using Ray = RayT<float>;
 
 // Math policies.
 //  Ieee: correctly rounded / and sqrt (hipcc's default expansion: 12- and 17-instruction
@@ -159,60 +165,112 @@ using Ray = RayT<float>;
 //  Lean: the same correctly rounded results for every NORMAL-RANGE operand, without the
 //        range scaling (v_div_scale / 2^32 pre-scaling) and special-value fix-up
 //        (v_div_fixup, class tests) that the compiler's sequences carry for denormal, huge
-//        and zero/inf operands -- 6 and 10 instructions instead of 12 and 17:
+//        and zero/inf operands:
 //          div : y0 = rcp(b); y = y0 + y0*(1 - b*y0); q0 = a*y; q = q0 + y*(a - b*q0)
-//                (all via fma).  Verified bit-identical to IEEE on ALL 2^46 mantissa pairs
-//                (sdirt_selftest_math mode 1; the recurrence is exact-scaling in the exponent,
-//                so this covers every operand pair whose exponents stay within +-60).
+//                (all via fma; 5 + v_rcp).  Verified bit-identical to IEEE on ALL 2^46 mantissa
+//                pairs (sdirt_selftest_math mode 2; the recurrence is exact-scaling in the
+//                exponent, so this covers every operand pair whose exponents stay within +-60).
 //                a == 0 gives the correctly signed zero; b == 0 gives NaN instead of inf.
 //          sqrt: s = v_sqrt_f32(x) (<= 1 ulp), then pick among {s-ulp, s, s+ulp} by the sign
 //                of the exact residuals x - s'*s (fma) -- the compiler's own correction
-//                step.  Verified on EVERY positive normal fp32 (mode 0, exhaustive); +-0,
-//                +inf, negative and NaN inputs behave as IEEE; denormal inputs do not.
+//                step (10 + v_sqrt).  Verified on EVERY positive normal fp32 (mode 0,
+//                exhaustive); +-0, +inf, negative and NaN inputs behave as IEEE; denormal
+//                inputs do not.
+//          sqrt_pos: for arguments KNOWN to be positive, finite and normal (1 - a inside the
+//                conic's domain, squared lengths of non-zero vectors): r = v_rsq_f32(x);
+//                s = x*r; h = r/2; e = 1/2 - h*s; h += h*e; s += s*e; s += h*(x - s*s)
+//                (7 + v_rsq) -- the Markstein / Goldschmidt correction LLVM itself emits for
+//                sqrt when denormals are flushed.  Verified on every fp32 in [2^-100, 2^100]
+//                (mode 3, exhaustive); 0, inf and denormals are NOT handled.
 //        No operand on a valid ray is denormal or zero-denominator (eps = 1e-9 guards, unit
 //        direction vectors, |positions| in [1e-6, 2e4] mm), so valid rays are bit-identical
 //        to the Ieee instantiation; tests/test_gpu_parity.py runs both against the oracle.
 struct Ieee {
-    template <class T> static __device__ __forceinline__ T div(T a, T b) { return a / b; }
-    template <class T> static __device__ __forceinline__ T sqrt(T x) { return Lane<T>::sqrt_ieee(x); }
-    template <class T> static __device__ __forceinline__ void div3(T& a0, T& a1, T& a2, T b)
+    static __device__ __forceinline__ float div(float a, float b) { return a / b; }
+    static __device__ __forceinline__ float sqrt(float x) { return __builtin_sqrtf(x); }
+    static __device__ __forceinline__ float sqrt_pos(float x) { return __builtin_sqrtf(x); }
+    static __device__ __forceinline__ void div3(float& a0, float& a1, float& a2, float b)
     {
         a0 = a0 / b; a1 = a1 / b; a2 = a2 / b;
     }
 };
 struct Lean {
-    template <class T> static __device__ __forceinline__ T div(T a, T b)
+    static __device__ __forceinline__ float div(float a, float b)
     {
-        using L = Lane<T>;
-        const T y0 = L::rcp_fast(b);
-        const T y = L::fma(L::fma(-b, y0, L::splat(1.0f)), y0, y0);
-        const T q0 = a * y;
-        return L::fma(L::fma(-b, q0, a), y, q0);
+        const float y0 = __builtin_amdgcn_rcpf(b);
+        const float y = __builtin_fmaf(__builtin_fmaf(-b, y0, 1.0f), y0, y0);
+        const float q0 = a * y;
+        return __builtin_fmaf(__builtin_fmaf(-b, q0, a), y, q0);
     }
     // three numerators over one denominator: the refined reciprocal is computed once; each
     // quotient is the same arithmetic as div(), hence the same bits
-    template <class T> static __device__ __forceinline__ void div3(T& a0, T& a1, T& a2, T b)
+    static __device__ __forceinline__ void div3(float& a0, float& a1, float& a2, float b)
     {
-        using L = Lane<T>;
-        const T y0 = L::rcp_fast(b);
-        const T y = L::fma(L::fma(-b, y0, L::splat(1.0f)), y0, y0);
-        T q = a0 * y; a0 = L::fma(L::fma(-b, q, a0), y, q);
-        q = a1 * y;   a1 = L::fma(L::fma(-b, q, a1), y, q);
-        q = a2 * y;   a2 = L::fma(L::fma(-b, q, a2), y, q);
+        const float y0 = __builtin_amdgcn_rcpf(b);
+        const float y = __builtin_fmaf(__builtin_fmaf(-b, y0, 1.0f), y0, y0);
+        float q = a0 * y; a0 = __builtin_fmaf(__builtin_fmaf(-b, q, a0), y, q);
+        q = a1 * y;       a1 = __builtin_fmaf(__builtin_fmaf(-b, q, a1), y, q);
+        q = a2 * y;       a2 = __builtin_fmaf(__builtin_fmaf(-b, q, a2), y, q);
     }
-    template <class T> static __device__ __forceinline__ T sqrt(T x)
+    static __device__ __forceinline__ float sqrt(float x)
     {
-        using L = Lane<T>;
-        T s = L::sqrt_fast(x);
-        const T sm = L::next_down(s), sp = L::next_up(s);
-        const T rm = L::fma(-sm, s, x);          // x - (s - ulp) * s
-        const T rp = L::fma(-sp, s, x);          // x - (s + ulp) * s
-        s = L::sel(L::le(rm, L::splat(0.0f)), sm, s);
-        s = L::sel(L::gt(rp, L::splat(0.0f)), sp, s);
+        float s = __builtin_amdgcn_sqrtf(x);
+        const float sm = __uint_as_float(__float_as_uint(s) - 1u);
+        const float sp = __uint_as_float(__float_as_uint(s) + 1u);
+        const float rm = __builtin_fmaf(-sm, s, x);          // x - (s - ulp) * s
+        const float rp = __builtin_fmaf(-sp, s, x);          // x - (s + ulp) * s
+        s = rm <= 0.0f ? sm : s;
+        s = rp > 0.0f ? sp : s;
         // +-0 and +inf map to themselves; negative / NaN inputs give NaN through v_sqrt_f32
-        return L::sel(L::is_zero_or_pinf(x), x, s);
+        return __builtin_amdgcn_classf(x, 0x260) ? x : s;   // -0 | +0 | +inf
+    }
+    static __device__ __forceinline__ float sqrt_pos(float x)
+    {
+#ifdef SDIRT_NO_RSQ_SQRT
+        return sqrt(x);
+#else
+        const float r = __builtin_amdgcn_rsqf(x);
+        float s = x * r;
+        float h = 0.5f * r;
+        const float e = __builtin_fmaf(-h, s, 0.5f);
+        h = __builtin_fmaf(h, e, h);
+        s = __builtin_fmaf(s, e, s);
+        const float d = __builtin_fmaf(-s, s, x);
+        return __builtin_fmaf(d, h, s);
+#endif
+    }
+    // div() in two halves: div(a, b) == div_y(a, b, recip(b)).  (The seed must be v_rcp_f32(b):
+    // seeding the Newton step from a related quantity instead -- the square root's own
+    // half-reciprocal for a / sqrt(x), the square of 1/b's reciprocal for a / (b*b) -- was tried to
+    // save the v_rcp_f32 and gives a reciprocal that differs in the last bit for 80 + 6 arguments,
+    // of which the all-ones-mantissa divisors then miss the IEEE quotient for some numerators.)
+    static __device__ __forceinline__ float recip(float b)
+    {
+        const float y0 = __builtin_amdgcn_rcpf(b);
+        return __builtin_fmaf(__builtin_fmaf(-b, y0, 1.0f), y0, y0);
+    }
+    static __device__ __forceinline__ float div_y(float a, float b, float y)
+    {
+        const float q0 = a * y;
+        return __builtin_fmaf(__builtin_fmaf(-b, q0, a), y, q0);
     }
 };
+
+// a / b for a divisor that is the same for every ray of the launch: the refined reciprocal y of
+// Lean::div is computed once (UDiv::make), each quotient is Lean::div's remaining three
+// operations -- the same arithmetic, hence the same (correctly rounded) bits.  Ieee: plain a / b.
+template <class M> struct UDiv;
+template <> struct UDiv<Ieee> {
+    float b;
+    static __device__ __forceinline__ UDiv make(float b) { return UDiv{b}; }
+    __device__ __forceinline__ float operator()(float a) const { return a / b; }
+};
+template <> struct UDiv<Lean> {
+    float b, y;
+    static __device__ __forceinline__ UDiv make(float b) { return UDiv{b, Lean::recip(b)}; }
+    __device__ __forceinline__ float operator()(float a) const { return Lean::div_y(a, b, y); }
+};
+
 __device__ __forceinline__ float clampf(float v, float lo, float hi)
 {
     // torch.clamp semantics: NaN propagates
@@ -222,72 +280,95 @@ __device__ __forceinline__ float clampf(float v, float lo, float hi)
     return v;
 }
 
-template <class T>
-__device__ __forceinline__ T clampv(T v, float lo, float hi)
+// torch.clamp(v, lo, hi) for a value known not to be NaN (one v_med3_f32): the sub-pixel
+// boundaries of a LIVE ray -- dead rays never reach the weights (splat_taps)
+__device__ __forceinline__ float clamp_finite(float v, float lo, float hi)
 {
-    using L = Lane<T>;
-    // a NaN fails both comparisons and passes through, as torch.clamp does
-    T w = L::sel(L::lt(v, L::splat(lo)), L::splat(lo), v);
-    return L::sel(L::gt(w, L::splat(hi)), L::splat(hi), w);
+    return __builtin_amdgcn_fmed3f(v, lo, hi);
+}
+
+// torch.clamp(v, -b, b) in three instructions: v_med3_f32 (returns a bound for a NaN input),
+// then the NaN put back -- a NaN must stay a NaN: it fails the `|f| > tol` test of the next trip
+// exactly as it does in the reference
+__device__ __forceinline__ float clamp_sym(float v, float b)
+{
+    const float m = __builtin_amdgcn_fmed3f(v, -b, b);
+    return v != v ? v : m;
 }
 
 // torch.nn.functional.normalize over a last dim of 3 (basics.py:245,
 // surfaces.py:628): v / max(||v||, 1e-12); torch's CPU kernel accumulates the
 // squares with fused multiply-adds (x*x, then fma y, then fma z).
-template <class M, class T>
-__device__ __forceinline__ void normalize3(T& x, T& y, T& z)
+// NONZERO: the vector is known not to vanish (a direction between distinct points, a surface
+// normal with a -1 / 2(z - centre) component): sqrt_pos applies and the 1e-12 floor is dead.
+template <class M, bool NONZERO = false>
+__device__ __forceinline__ void normalize3(float& x, float& y, float& z)
 {
-    using L = Lane<T>;
-    T acc = x * x;
-    acc = L::fma(y, y, acc);
-    acc = L::fma(z, z, acc);
-    T nrm = M::sqrt(acc);
-    nrm = L::sel(L::lt(nrm, L::splat(1e-12f)), L::splat(1e-12f), nrm);
+    float acc = x * x;
+    acc = __builtin_fmaf(y, y, acc);
+    acc = __builtin_fmaf(z, z, acc);
+    float nrm = NONZERO ? M::sqrt_pos(acc) : M::sqrt(acc);
+    if (!NONZERO) nrm = nrm < 1e-12f ? 1e-12f : nrm;      // a non-zero vector's norm is >= 1e-19
     M::div3(x, y, z, nrm);
 }
 
-// r2 ** n as torch evaluates it on CPU: n==2 -> x*x, n==3 -> (x*x)*x, n>=4 a
-// <=1 ulp vector pow; for n>=4 we return the correctly rounded exact power
-// (product in fp64, rounded once).
-__device__ __forceinline__ float powi(float x, int n)
+// Even-asphere sag g(r2) and dg/d(r2), surfaces.py:787-808 and 811-830 evaluated together
+// (they share sqrt(1-a)).  INSIDE: r2 is known to lie inside the conic's domain with k > -1
+// (0 < 1 - a <= 1), so sqrt_pos applies.  P = Poly: the surface has polynomial terms (deg of
+// them, wave-uniform); P = NoPoly: pure conic (every sphere).
+// r2 ** n as torch evaluates it on CPU: n == 2 -> x*x, n == 3 -> (x*x)*x, n >= 4 a <= 1-ulp
+// vector pow, for which the correctly rounded exact power stands here (running product in
+// fp64, rounded once per term) -- identical in oracle/sdirt_oracle.c.
+// the conic's constants as the Newton loop holds them: in VGPRs.  A vector instruction with an
+// SGPR source operand issues at 0.55x the rate of one with VGPR / inline-constant sources on
+// gfx950 (tools/newton_bench.hip); six per trip are worth five v_mov per surface.
+struct ConicV {
+    float c, c2, onepk, d;
+};
+__device__ __forceinline__ float to_vgpr(float s)
 {
-    if (n == 1) return x;
-    if (n == 2) return x * x;
-    if (n == 3) return (x * x) * x;
-    double p = (double)x, acc = p;
-    for (int i = 1; i < n; ++i) acc *= p;
-    return (float)acc;
+    float v;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(s));
+    return v;
+}
+__device__ __forceinline__ ConicV conic_v(const Surf& s)
+{
+    return ConicV{to_vgpr(s.c()), to_vgpr(s.c2()), to_vgpr(s.onepk()), to_vgpr(s.d())};
+}
+struct ConicS {      // the same constants straight from SGPRs (cold paths)
+    float c, c2, onepk, d;
+};
+__device__ __forceinline__ ConicS conic_s(const Surf& s) { return ConicS{s.c(), s.c2(), s.onepk(), s.d()}; }
+
+template <class M, bool INSIDE, class C>
+__device__ __forceinline__ void sag_g_dgd(const C& k, const NoPoly&, int, float r2, float& g, float& dgd)
+{
+    const float a = (k.onepk * r2) * k.c2;
+    const float sf = INSIDE ? M::sqrt_pos(1.0f - a) : M::sqrt(1.0f - a);
+    const float onesf = 1.0f + sf;
+    g = M::div(r2 * k.c, onesf);
+    dgd = M::div((onesf + M::div(a * 0.5f, sf)) * k.c, onesf * onesf);   // a/2 == a*0.5 exactly
 }
 
-// surfaces.py:787-808 and 811-830 evaluated together (they share sqrt(1-a)).
-template <class M, class T>
-__device__ __forceinline__ void sag_g_dgd(const DevSurface& s, T r2, T& g, T& dgd)
+template <class M, bool INSIDE, class C>
+__device__ __forceinline__ void sag_g_dgd(const C& k, const Poly& pol, int deg, float r2, float& g, float& dgd)
 {
-    using L = Lane<T>;
-    const T a = (s.onepk * r2) * s.c2;
-    const T sf = M::sqrt(1.0f - a);
-    const T onesf = 1.0f + sf;
-    g = M::div(r2 * s.c, onesf);
-    dgd = M::div((onesf + M::div(a * 0.5f, sf)) * s.c, onesf * onesf);   // a/2 == a*0.5 exactly
-    if (s.ai_degree > 0) {
-        dgd = dgd + s.ai[0];
-        g = g + s.ai[0] * r2;
-        T pw = r2;   // r2 ** i
-        for (int i = 1; i < s.ai_degree; ++i) {
-            dgd = dgd + s.kai[i] * pw;
+    sag_g_dgd<M, INSIDE>(k, NoPoly{}, 0, r2, g, dgd);
+    dgd = dgd + pol.ai(0);
+    g = g + pol.ai(0) * r2;
+    float pw = r2;                        // r2 ** i
+    const double xd = (double)r2;
+    double accd = xd;                     // r2 ** n in fp64: ((x*x)*x)*...
+#pragma unroll
+    for (int i = 1; i < kMaxAi; ++i) {
+        if (i < deg) {
+            dgd = dgd + pol.kai(i) * pw;
             const int n = i + 1;
-            pw = L::map(r2, [n](float v) { return powi(v, n); });
-            g = g + s.ai[i] * pw;
+            if (deg > 3) accd = accd * xd;
+            pw = n == 2 ? r2 * r2 : n == 3 ? (r2 * r2) * r2 : (float)accd;
+            g = g + pol.ai(i) * pw;
         }
     }
-}
-
-template <class M, class T>
-__device__ __forceinline__ T sag_dgd_only(const DevSurface& s, T r2)
-{
-    T g, dgd;
-    sag_g_dgd<M>(s, r2, g, dgd);
-    return dgd;
 }
 
 // surfaces.py:523-586.  `trips` loop iterations (wave-uniform), then the extra
@@ -295,159 +376,173 @@ __device__ __forceinline__ T sag_dgd_only(const DevSurface& s, T r2)
 // mask_out (wave-uniform, lives in SGPRs) gets bit j set when ANY active lane of
 // the wave had |f(t)| > 50e-6 in trip j -- the per-wave share of the reference's
 // batch-wide `.any()` loop condition (surfaces.py:547).
-template <class M, bool KGT, class T>
-__device__ __forceinline__ typename Lane<T>::Mask newton_k(const DevSurface& s, const RayT<T>& r,
-                                                           int trips, T& t_out, uint32_t& mask_out)
+template <class M, bool KGT, class P>
+__device__ __forceinline__ bool newton_k(const Surf& s, const P& pol, const Ray& r, int trips, float& t_out,
+                                         uint32_t& mask_out)
 {
-    using L = Lane<T>;
-    using Mk = typename L::Mask;
+    const bool adaptive = trips < 0;
+    const int cap = adaptive ? -trips : trips;
     const float tol_loose = (float)50e-6, tol_tight = (float)10e-6, eps = (float)1e-9;
-    const T t0 = M::div(s.d - r.oz, r.dz);
-    const T dd = r.dx * r.dx + r.dy * r.dy;
-    const T dox = r.dx * r.ox + r.dy * r.oy;
-    const Mk alive = L::gt(r.ra, L::splat(0.0f));
-    T t = t0;
-    uint32_t mask = 0;
+#ifdef SDIRT_CONIC_SGPR
+    const ConicS k = conic_s(s);
+#else
+    const ConicV k = conic_v(s);
+#endif
+    const int deg = s.ai_degree();
+    const float t0 = M::div(k.d - r.oz, r.dz);
+    const float dd = r.dx * r.dx + r.dy * r.dy;
+    const float dox = r.dx * r.ox + r.dy * r.oy;
+    const bool alive = r.ra > 0.0f;
+    // `valid_loose && ra > 0` as ONE comparison per trip: a dead ray compares against a bound no
+    // squared radius can pass (k > -1: rr < lim_loose; k <= -1: rr > 0, surfaces.py:736-743)
+    const float bound = KGT ? (alive ? s.lim_loose() : -1.0f) : (alive ? 0.0f : __builtin_inff());
+    float t = t0;
+    uint32_t mask = 0, bit = 2u;
     // trips >= 0: exactly that many trips (the reference's batch-wide count, supplied by the host).
     // trips < 0: at most -trips, and this WAVE stops as soon as none of its 64 rays is open -- the
     // reference's loop condition evaluated per wave instead of per batch (speed mode, no host check).
-    const bool adaptive = trips < 0;
-    const int cap = adaptive ? -trips : trips;
-    for (int it = 1; it <= cap; ++it) {
-        const T nx = r.ox + r.dx * t, ny = r.oy + r.dy * t, nz = r.oz + r.dz * t;
-        const T rr = nx * nx + ny * ny;
-        const Mk inside = KGT ? L::lt(rr, L::splat(s.lim_loose)) : L::gt(rr, L::splat(0.0f));
+    for (int it = cap; it > 0; --it) {
+        const float nx = r.ox + r.dx * t, ny = r.oy + r.dy * t, nz = r.oz + r.dz * t;
+        const float rr = nx * nx + ny * ny;
         // g(x*valid, y*valid) (surfaces.py:694-696): (x*1)^2 + (y*1)^2 is rr bit for bit, and
         // (x*0)^2 + (y*0)^2 is 0 for every finite position
-        const T r2 = L::sel(L::mand(inside, alive), rr, L::splat(0.0f));
-        T g, dgd;
-        sag_g_dgd<M>(s, r2, g, dgd);
-        const T ft = (g + s.d) - nz;
-        const T dr2dt = 2.0f * (dd * t + dox);
-        const T dfdt = dgd * dr2dt - r.dz;
-        const bool open = L::any(L::gt(L::fabs(ft), L::splat(tol_loose)));
-        const bool wave_open = __ballot(open) != 0ull;
-        mask |= wave_open ? (1u << it) : 0u;
-        t = t - clampv(M::div(ft, dfdt + eps), -kNewtonStepBound, kNewtonStepBound);
+        const float r2 = (KGT ? rr < bound : rr > bound) ? rr : 0.0f;
+        float g, dgd;
+        sag_g_dgd<M, KGT>(k, pol, deg, r2, g, dgd);
+        const float ft = (g + k.d) - nz;
+        const float dr2dt = 2.0f * (dd * t + dox);
+        const float dfdt = dgd * dr2dt - r.dz;
+        const bool wave_open = __ballot(__builtin_fabsf(ft) > tol_loose) != 0ull;
+        mask |= wave_open ? bit : 0u;
+        bit <<= 1;
+        t = t - clamp_sym(M::div(ft, dfdt + eps), kNewtonStepBound);
         if (adaptive && !wave_open) break;
     }
     mask_out = mask;
-    const T t1 = t - t0;   // :563
-    t = t0 + t1;           // :567
-    T nx = r.ox + r.dx * t, ny = r.oy + r.dy * t;
-    const T nz = r.oz + r.dz * t;
-    T rr = nx * nx + ny * ny;
-    Mk v = L::mand(L::lt(rr, L::splat(s.r2_lim)), alive);
-    if (KGT) v = L::mand(v, L::lt(rr, L::splat(s.lim_loose)));
-    const T r2 = L::sel(v, rr, L::splat(0.0f));
-    T g, dgd;
-    sag_g_dgd<M>(s, r2, g, dgd);
-    const T ft = (g + s.d) - nz;
-    const T dr2dt = 2.0f * (dd * t + dox);
-    const T dfdt = dgd * dr2dt - r.dz;
-    t = t - clampv(M::div(ft, dfdt + eps), -kNewtonStepBound, kNewtonStepBound);
+    const float t1 = t - t0;   // :563
+    t = t0 + t1;               // :567
+    float nx = r.ox + r.dx * t, ny = r.oy + r.dy * t;
+    const float nz = r.oz + r.dz * t;
+    float rr = nx * nx + ny * ny;
+    // _valid (surfaces.py:724-733): rr < r2_lim [and rr < lim_loose] = rr < lim_tight
+    const float tight = alive ? s.lim_tight() : -1.0f;
+    const float r2 = rr < tight ? rr : 0.0f;
+    float g, dgd;
+    sag_g_dgd<M, KGT>(k, pol, deg, r2, g, dgd);
+    const float ft = (g + k.d) - nz;
+    const float dr2dt = 2.0f * (dd * t + dox);
+    const float dfdt = dgd * dr2dt - r.dz;
+    t = t - clamp_sym(M::div(ft, dfdt + eps), kNewtonStepBound);
     nx = r.ox + r.dx * t;
     ny = r.oy + r.dy * t;
     rr = nx * nx + ny * ny;
-    v = L::mand(L::lt(rr, L::splat(s.r2_lim)), alive);
-    if (KGT) v = L::mand(v, L::lt(rr, L::splat(s.lim_loose)));
-    v = L::mand(v, L::lt(L::fabs(ft), L::splat(tol_tight)));
-    v = L::mand(v, L::gt(t, L::splat(0.0f)));
+    bool v = rr < tight;
+    v = v && __builtin_fabsf(ft) < tol_tight;
+    v = v && t > 0.0f;
     t_out = t;
     return v;
 }
 
-// k > -1 (every sphere, ellipsoid, mild asphere) and k <= -1 differ only in the domain test
-// (surfaces.py:727-743); the branch is wave-uniform, so it is taken once, outside the loop.
-template <class M, class T>
-__device__ __forceinline__ typename Lane<T>::Mask newton(const DevSurface& s, const RayT<T>& r,
-                                                         int trips, T& t_out, uint32_t& mask_out)
-{
-    if (s.k_gt_m1) return newton_k<M, true>(s, r, trips, t_out, mask_out);
-    return newton_k<M, false>(s, r, trips, t_out, mask_out);
-}
-
 // surfaces.py:633-679 with _normal (:589-630).  FWD: rays travel +z (n negated,
 // eta = n1/n2); !FWD: backward tracing.
-template <bool FWD, class M, class T>
-__device__ __forceinline__ void refract(const DevSurface& s, RayT<T>& r)
+template <bool FWD, class M, class P>
+__device__ __forceinline__ void refract(const Surf& s, const P& pol, Ray& r)
 {
-    using L = Lane<T>;
-    using Mk = typename L::Mask;
-    T nx, ny, nz;
-    if (s.kind == 0) {
-        nx = L::splat(0.0f); ny = L::splat(0.0f); nz = L::splat(-1.0f);
-    } else if (s.kind == 1) {
-        if (s.c > 0.0f) {
-            nx = 2.0f * r.ox; ny = 2.0f * r.oy; nz = 2.0f * r.oz - 2.0f * s.d_plus_R;
-        } else {
-            nx = -2.0f * r.ox; ny = -2.0f * r.oy; nz = -2.0f * r.oz + 2.0f * s.d_plus_R;
-        }
-    } else {
-        const T vf = L::to01(L::gt(r.ra, L::splat(0.0f)));
-        const T xv = r.ox * vf, yv = r.oy * vf;
-        const T ds = sag_dgd_only<M>(s, xv * xv + yv * yv);
-        nx = (ds * 2.0f) * xv; ny = (ds * 2.0f) * yv; nz = L::splat(-1.0f);
+    float nx, ny, nz;
+    if (std::is_same<P, Poly>::value) {
+        const float vf = r.ra > 0.0f ? 1.0f : 0.0f;
+        const float xv = r.ox * vf, yv = r.oy * vf;
+        float g, ds;
+        // _dsdr2 is evaluated at whatever (x, y) the ray holds (surfaces.py:600): general sqrt
+        sag_g_dgd<M, false>(conic_s(s), pol, s.ai_degree(), xv * xv + yv * yv, g, ds);
+        nx = (ds * 2.0f) * xv; ny = (ds * 2.0f) * yv; nz = -1.0f;
+    } else if (s.kind() == 0) {
+        nx = 0.0f; ny = 0.0f; nz = -1.0f;
+    } else if (s.kind() == 1) {
+        const float sg = s.c_pos() ? 2.0f : -2.0f;       // (+-2) * x is exact either way
+        nx = sg * r.ox; ny = sg * r.oy; nz = sg * r.oz - sg * s.d_plus_R();
+    } else {                                              // conic without polynomial terms
+        const float vf = r.ra > 0.0f ? 1.0f : 0.0f;
+        const float xv = r.ox * vf, yv = r.oy * vf;
+        float g, ds;
+        sag_g_dgd<M, false>(conic_s(s), pol, 0, xv * xv + yv * yv, g, ds);
+        nx = (ds * 2.0f) * xv; ny = (ds * 2.0f) * yv; nz = -1.0f;
     }
-    normalize3<M>(nx, ny, nz);
+    // a surface normal never vanishes on a ray that sits on the surface; the radicand of `sr` is
+    // >= 2^-24 by the validity test (sqrt_pos; a dead ray's garbage stays confined to the
+    // discarded candidate direction)
+    normalize3<M, true>(nx, ny, nz);
     if (FWD) { nx = -nx; ny = -ny; nz = -nz; }
-    const float eta = FWD ? s.eta_f : s.eta_b;
-    const float eta2 = FWD ? s.eta2_f : s.eta2_b;
-    const T cosi = (r.dx * nx + r.dy * ny) + r.dz * nz;
-    const T c2i = cosi * cosi;
-    const T omc = 1.0f - c2i;
-    Mk v = L::mand(L::gt(c2i, L::splat(0.1f)), L::lt(eta2 * omc, L::splat(1.0f)));
-    v = L::mand(v, L::gt(r.ra, L::splat(0.0f)));
-    const T vf = L::to01(v);
-    const T sr = M::sqrt(1.0f - (eta2 * omc) * vf);
-    T ndx = sr * nx + eta * (r.dx - cosi * nx);
-    T ndy = sr * ny + eta * (r.dy - cosi * ny);
-    T ndz = sr * nz + eta * (r.dz - cosi * nz);
-    ndx = L::sel(v, ndx, r.dx); ndy = L::sel(v, ndy, r.dy); ndz = L::sel(v, ndz, r.dz);
+    const float eta = s.eta(), eta2 = s.eta2();
+    const float cosi = (r.dx * nx + r.dy * ny) + r.dz * nz;
+    const float c2i = cosi * cosi;
+    const float omc = 1.0f - c2i;
+    const bool v = c2i > 0.1f && eta2 * omc < 1.0f && r.ra > 0.0f;
+    const float vf = v ? 1.0f : 0.0f;
+    const float sr = M::sqrt_pos(1.0f - (eta2 * omc) * vf);
+    float ndx = sr * nx + eta * (r.dx - cosi * nx);
+    float ndy = sr * ny + eta * (r.dy - cosi * ny);
+    float ndz = sr * nz + eta * (r.dz - cosi * nz);
+    ndx = v ? ndx : r.dx; ndy = v ? ndy : r.dy; ndz = v ? ndz : r.dz;
     r.ob = r.ob * ((ndx * r.dx + ndy * r.dy) + ndz * r.dz);
     r.dx = ndx; r.dy = ndy; r.dz = ndz;
     r.ra = r.ra * vf;
 }
 
-// Aspheric.ray_reaction, surfaces.py:391-520.  Returns the Newton convergence
-// mask of this ray on this surface (0 for planes).
-template <bool FWD, class M, class T>
-__device__ __forceinline__ uint32_t surface_reaction(const DevSurface& s, RayT<T>& r, int trips)
+// Curved surface: Newton intersection, validity, refraction (surfaces.py:456-520).  `between` runs
+// after the intersection and before the refraction (the trace loop's prefetch of the next surface).
+template <bool FWD, class M, class P, class F>
+__device__ __forceinline__ uint32_t curved_reaction(const Surf& s, const P& pol, Ray& r, int trips, F between)
 {
-    using L = Lane<T>;
-    using Mk = typename L::Mask;
     uint32_t mask = 0;
-    if (s.kind == 0) {
-        const T t = M::div(s.d - r.oz, r.dz);
-        const T nx = r.ox + t * r.dx, ny = r.oy + t * r.dy, nz = r.oz + t * r.dz;
-        const Mk v = L::mand(L::le(M::sqrt(nx * nx + ny * ny), L::splat(s.r_lim)),
-                             L::gt(r.ra, L::splat(0.0f)));
-        r.ox = L::sel(v, nx, r.ox); r.oy = L::sel(v, ny, r.oy); r.oz = L::sel(v, nz, r.oz);
-        r.ra = r.ra * L::to01(v);
-        if (s.do_refract) refract<FWD, M>(s, r);
-        return 0;
-    }
-    T t;
-    const Mk vn = newton<M>(s, r, trips, t, mask);
-    const T nx = r.ox + t * r.dx, ny = r.oy + t * r.dy, nz = r.oz + t * r.dz;
-    Mk v;
-    if (s.kind == 1) {                                                                    // :464
-        v = L::mand(L::le(nx * nx + ny * ny, L::splat(s.r2_lim)), L::ge(t, L::splat(0.0f)));
-        v = L::mand(v, L::gt(r.ra, L::splat(0.0f)));
+    float t;
+    // k > -1 (every sphere, ellipsoid, mild asphere) and k <= -1 differ only in the domain test
+    // (surfaces.py:727-743); the branch is wave-uniform and taken once, outside the loop
+    const bool vn = s.k_gt_m1() ? newton_k<M, true>(s, pol, r, trips, t, mask)
+                                : newton_k<M, false>(s, pol, r, trips, t, mask);
+    between();
+    const float nx = r.ox + t * r.dx, ny = r.oy + t * r.dy, nz = r.oz + t * r.dz;
+    bool v;
+    if (s.kind() == 1) {                                                                  // :464
+        v = nx * nx + ny * ny <= s.r2_lim() && t >= 0.0f && r.ra > 0.0f;
     } else {
         v = vn;                                                                           // :495
     }
-    r.ox = L::sel(v, nx, r.ox); r.oy = L::sel(v, ny, r.oy); r.oz = L::sel(v, nz, r.oz);
-    r.ra = r.ra * L::to01(v);
-    refract<FWD, M>(s, r);
+    r.ox = v ? nx : r.ox; r.oy = v ? ny : r.oy; r.oz = v ? nz : r.oz;
+    r.ra = r.ra * (v ? 1.0f : 0.0f);
+    refract<FWD, M>(s, pol, r);
     return mask;
 }
 
-// Ray.propagate_to, basics.py:256-264
-template <class M, class T>
-__device__ __forceinline__ void propagate_to(RayT<T>& r, float z)
+// Aspheric.ray_reaction, surfaces.py:391-520, on surface `blk` whose constants `s` are already in
+// registers.  Returns the Newton convergence mask of this wave on this surface (0 for planes).
+template <bool FWD, class M, class F>
+__device__ __forceinline__ uint32_t surface_reaction(const Surf& s, const DevSurface* __restrict__ blk,
+                                                     int trips, Ray& r, F between)
 {
-    const T t = M::div(z - r.oz, r.dz);
+    if (s.kind() == 0) {
+        const float t = M::div(s.d() - r.oz, r.dz);
+        const float nx = r.ox + t * r.dx, ny = r.oy + t * r.dy, nz = r.oz + t * r.dz;
+        const bool v = M::sqrt(nx * nx + ny * ny) <= s.r_lim() && r.ra > 0.0f;
+        r.ox = v ? nx : r.ox; r.oy = v ? ny : r.oy; r.oz = v ? nz : r.oz;
+        r.ra = r.ra * (v ? 1.0f : 0.0f);
+        between();
+        if (s.do_refract()) refract<FWD, M>(s, NoPoly{}, r);
+        return 0;
+    }
+    if (s.ai_degree() > 0) {                      // wave-uniform: the polynomial block is fetched
+        Poly pol;                                 // (one more round trip) on aspheres only
+        pol.w = sload_block(&blk->p);
+        return curved_reaction<FWD, M>(s, pol, r, trips, between);
+    }
+    return curved_reaction<FWD, M>(s, NoPoly{}, r, trips, between);
+}
+
+// Ray.propagate_to, basics.py:256-264
+template <class M>
+__device__ __forceinline__ void propagate_to(Ray& r, float z)
+{
+    const float t = M::div(z - r.oz, r.dz);
     r.ox = r.ox + r.dx * t;
     r.oy = r.oy + r.dy * t;
     r.oz = r.oz + r.dz * t;
@@ -476,23 +571,24 @@ __device__ __forceinline__ float over_r(const DevDpParams& p, float x)
     return p.r_pow2 ? x * p.inv_r : x / p.r;
 }
 
-// monte_carlo.py:169-206 (r <= 0.5)
-__device__ __forceinline__ void dp_weights_small(const DevDpParams& p, float x_tan, float& sl,
-                                                 float& sr)
+// monte_carlo.py:169-206 (r <= 0.5); div_fmh(a) = a / fmh
+template <class Div>
+__device__ __forceinline__ void dp_weights_small(const DevDpParams& p, const Div& div_fmh, float x_tan,
+                                                 float& sl, float& sr)
 {
-    const float r = p.r, rr = p.rr, fmh = p.fmh;
+    const float r = p.r, rr = p.rr;
     const float fx = p.f * x_tan;
-    float xr = p.w - ((fx - p.w) * p.h) / fmh;
-    float xm = ((-fx) * p.h) / fmh;
-    float xl = (-p.w) - ((fx + p.w) * p.h) / fmh;
-    xr = clampf(xr, -r, r); xm = clampf(xm, -r, r); xl = clampf(xl, -r, r);
+    float xr = p.w - div_fmh((fx - p.w) * p.h);
+    float xm = div_fmh((-fx) * p.h);
+    float xl = (-p.w) - div_fmh((fx + p.w) * p.h);
+    xr = clamp_finite(xr, -r, r); xm = clamp_finite(xm, -r, r); xl = clamp_finite(xl, -r, r);
     float sm = seg_acos(over_r(p, xm));
     const float sr_ml = rr * (sm - seg_acos(over_r(p, xr)));
     const float sl_ml = rr * (seg_acos(over_r(p, xl)) - sm);
     const float hx = p.h * x_tan;
     xr = p.w - hx; xm = 0.0f - hx; xl = (-p.w) - hx;
-    xr = clampf(xr, -0.5f, 0.5f); xm = clampf(xm, -0.5f, 0.5f); xl = clampf(xl, -0.5f, 0.5f);
-    const float xri = clampf(xr, -r, r), xmi = clampf(xm, -r, r), xli = clampf(xl, -r, r);
+    xr = clamp_finite(xr, -0.5f, 0.5f); xm = clamp_finite(xm, -0.5f, 0.5f); xl = clamp_finite(xl, -0.5f, 0.5f);
+    const float xri = clamp_finite(xr, -r, r), xmi = clamp_finite(xm, -r, r), xli = clamp_finite(xl, -r, r);
     sm = seg_acos(over_r(p, xmi));
     const float sr_in = rr * (sm - seg_acos(over_r(p, xri)));
     const float sl_in = rr * (seg_acos(over_r(p, xli)) - sm);
@@ -500,6 +596,11 @@ __device__ __forceinline__ void dp_weights_small(const DevDpParams& p, float x_t
     const float sl_mg = (xm - xl) * 1.0f - sl_in;
     sr = sr_ml + sr_mg;
     sl = sl_ml + sl_mg;
+}
+
+__device__ __forceinline__ void dp_weights_small(const DevDpParams& p, float x_tan, float& sl, float& sr)
+{
+    dp_weights_small(p, UDiv<Ieee>::make(p.fmh), x_tan, sl, sr);
 }
 
 // monte_carlo.py:274-338 (r > 0.5)
@@ -557,8 +658,9 @@ struct SplatGeom {
     int32_t ks;
 };
 
-__device__ __forceinline__ bool splat_taps(const SplatGeom& gm, float sx, float sy, float cx,
-                                           float cy, float ra, SplatTaps& tp)
+template <class DivY, class DivX>
+__device__ __forceinline__ bool splat_taps(const SplatGeom& gm, const DivY& div_dy, const DivX& div_dx,
+                                           float sx, float sy, float cx, float cy, float ra, SplatTaps& tp)
 {
     float px = (-sx) - cx;                     // points = -o.xy ; points - pointc_ref
     float py = (-sy) - cy;
@@ -566,8 +668,8 @@ __device__ __forceinline__ bool splat_taps(const SplatGeom& gm, float sx, float 
     w = w * (__builtin_fabsf(py) < gm.lim ? 1.0f : 0.0f);
     if (!(w != 0.0f)) return false;            // adds exact zeros in the reference
     px = px * w; py = py * w;                  // :38
-    const float pf0 = ((py - gm.y_max) / gm.dy_rng) * gm.ksm1;   // row
-    const float pf1 = ((px - gm.x_min) / gm.dx_rng) * gm.ksm1;   // col
+    const float pf0 = div_dy(py - gm.y_max) * gm.ksm1;   // row
+    const float pf1 = div_dx(px - gm.x_min) * gm.ksm1;   // col
     const float fl0 = __builtin_floorf(pf0), fl1 = __builtin_floorf(pf1);
     const float wb = pf0 - fl0, wr = pf1 - fl1;
     const int r0 = (int)fl0, c0 = (int)fl1;
@@ -581,6 +683,12 @@ __device__ __forceinline__ bool splat_taps(const SplatGeom& gm, float sx, float 
     // NaN position can never write outside the tile.
     const bool ok = r0 >= 0 && c0 >= 0 && r1 < ks && c1 < ks && (r0 + 1) < ks && (c0 + 1) < ks;
     return ok;
+}
+
+__device__ __forceinline__ bool splat_taps(const SplatGeom& gm, float sx, float sy, float cx, float cy,
+                                           float ra, SplatTaps& tp)
+{
+    return splat_taps(gm, UDiv<Ieee>::make(gm.dy_rng), UDiv<Ieee>::make(gm.dx_rng), sx, sy, cx, cy, ra, tp);
 }
 
 }  // namespace sdirt

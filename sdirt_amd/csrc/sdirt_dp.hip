@@ -36,27 +36,31 @@ static DevSurface make_dev_surface(const sdirt_surface_desc& in)
 {
     DevSurface s;
     std::memset(&s, 0, sizeof(s));
-    s.kind = in.kind;
-    s.ai_degree = in.kind == SDIRT_ASPHERE ? in.ai_degree : 0;
-    s.d = in.d; s.c = in.c; s.k = in.k;
-    s.k_gt_m1 = in.k > -1.0f;
-    s.r_lim = (float)in.r;
-    s.r2_lim = (float)(in.r * in.r);
-    s.c2 = in.c * in.c;
-    s.onepk = 1.0f + in.k;
+    SurfHot& h = s.h;
+    const int deg = in.kind == SDIRT_ASPHERE ? in.ai_degree : 0;
+    h.d = in.d; h.c = in.c; h.k = in.k;
+    h.r2_lim = (float)(in.r * in.r);
+    h.c2 = in.c * in.c;
+    h.onepk = 1.0f + in.k;
     if (in.kind != SDIRT_PLANE) {
-        float rc = 1.0f / s.c2;                       // tensor.reciprocal()
+        float rc = 1.0f / h.c2;                       // tensor.reciprocal()
         rc = rc * (float)(1.0 - 1e-9);                // * python float (1-EPSILON)
-        s.lim_loose = rc / s.onepk;
-        s.d_plus_R = in.d + 1.0f / in.c;
+        h.lim_loose = rc / h.onepk;
+        h.d_plus_R = in.d + 1.0f / in.c;
+        h.d_plus_R_b = h.d_plus_R;
+        h.lim_tight = in.k > -1.0f ? std::min(h.r2_lim, h.lim_loose) : h.r2_lim;
+    } else {
+        h.lim_tight = (float)in.r;                    // planes: the aperture radius itself
     }
     const double eta_f = in.n1 / in.n2, eta_b = in.n2 / in.n1;
-    s.eta_f = (float)eta_f;  s.eta2_f = (float)(eta_f * eta_f);
-    s.eta_b = (float)eta_b;  s.eta2_b = (float)(eta_b * eta_b);
-    s.do_refract = in.kind == SDIRT_PLANE ? (eta_f != 1.0) : 1;
+    h.eta_f = (float)eta_f;  h.eta2_f = (float)(eta_f * eta_f);
+    h.eta_b = (float)eta_b;  h.eta2_b = (float)(eta_b * eta_b);
+    const bool do_refract = in.kind == SDIRT_PLANE ? (eta_f != 1.0) : true;
+    h.flags = (uint32_t)in.kind | (do_refract ? kFlagRefract : 0u) | (in.k > -1.0f ? kFlagKgtM1 : 0u) |
+              (in.c > 0.0f ? kFlagCpos : 0u) | ((uint32_t)deg << 8);
     for (int i = 0; i < kMaxAi; ++i) {
-        s.ai[i] = i < s.ai_degree ? in.ai[i] : 0.0f;
-        s.kai[i] = (float)(i + 1) * s.ai[i];
+        s.p.ai[i] = i < deg ? in.ai[i] : 0.0f;
+        s.p.kai[i] = (float)(i + 1) * s.p.ai[i];
     }
     return s;
 }
@@ -93,19 +97,47 @@ static SplatGeom make_geom(double ps, int ks)
     return g;
 }
 
-struct TripTable {
-    int8_t t[SDIRT_MAX_SURFACES];
+// Everything the splat of one ray needs (window geometry + dual-pixel parameters), as ONE
+// 64-byte block at offset 0 of k_psf_lr's kernel-argument segment: the kernel fetches it with one
+// scalar load per RAY, right before the splat, instead of keeping ~20 SGPRs alive through the
+// trace (where round 1's build parked them in VGPR lanes: v_writelane / v_readlane traffic).
+struct alignas(64) SplatBlock {
+    float lim, x_min, y_max, dx_rng, dy_rng, ksm1;
+    int32_t ks;
+    float h, f, w, r, fmh, rr, inv_r;
+    int32_t r_pow2;
+    int32_t pad;
 };
+static_assert(sizeof(SplatBlock) == 64, "layout");
+
+static SplatBlock make_splat_block(const SplatGeom& g, const DevDpParams& p)
+{
+    SplatBlock b;
+    b.lim = g.lim; b.x_min = g.x_min; b.y_max = g.y_max; b.dx_rng = g.dx_rng; b.dy_rng = g.dy_rng;
+    b.ksm1 = g.ksm1; b.ks = g.ks;
+    b.h = p.h; b.f = p.f; b.w = p.w; b.r = p.r; b.fmh = p.fmh; b.rr = p.rr; b.inv_r = p.inv_r;
+    b.r_pow2 = p.r_pow2; b.pad = 0;
+    return b;
+}
+
+// Newton trip counts of one launch, one signed byte per surface, passed by value at a FIXED
+// offset of the kernel-argument segment; the kernels read the dword of surface k from there
+// with a scalar load that shares the round trip of the surface's constant block (a byte-indexed
+// by-value table made the compiler issue a vector load and wait for it once per surface).
+struct alignas(64) TripTable {
+    uint32_t w[SDIRT_MAX_SURFACES / 4];
+};
+static_assert(sizeof(TripTable) == 64, "layout");
 
 static int make_trips(const sdirt_lens* lens, const int32_t* trips, TripTable& tt)
 {
-    for (int k = 0; k < SDIRT_MAX_SURFACES; ++k) tt.t[k] = 0;
+    for (int k = 0; k < SDIRT_MAX_SURFACES / 4; ++k) tt.w[k] = 0;
     for (int k = 0; k < lens->n_surfaces; ++k) {
         int v = trips ? trips[k] : SDIRT_NEWTON_MAXITER;
         if (v < -SDIRT_NEWTON_MAXITER || v > SDIRT_NEWTON_MAXITER)
             return fail(SDIRT_ERR_INVALID_ARGUMENT, "trips[%d]=%d outside [-%d,%d]", k, v,
                         SDIRT_NEWTON_MAXITER, SDIRT_NEWTON_MAXITER);
-        tt.t[k] = (int8_t)v;
+        tt.w[k >> 2] |= (uint32_t)(uint8_t)(int8_t)v << ((k & 3) * 8);
     }
     return SDIRT_OK;
 }
@@ -143,17 +175,36 @@ __device__ __forceinline__ void store_ray(const sdirt_rays& R, int64_t i, const 
 
 // Trace one ray through surfaces [first,last) in the travel direction.  The
 // per-wave convergence masks are OR-ed into lds_mask[k] by lane 0.
-template <bool FWD, class M = Ieee, class T = float>
+template <bool FWD, class M = Ieee>
 __device__ __forceinline__ void trace_ray(const DevSurface* __restrict__ lens, int first, int last,
-                                          const TripTable& trips, RayT<T>& r, uint32_t* lds_mask)
+                                          const void* trip_words, Ray& r, uint32_t* lds_mask)
 {
     const int n = last - first;
+    if (n <= 0) return;
+    int k = FWD ? first : last - 1;
+    SurfRaw cur;
+    surf_issue<FWD>(cur, lens + k, trip_words, k);
+    surf_wait(cur);
     for (int step = 0; step < n; ++step) {
-        const int k = FWD ? first + step : last - 1 - step;
-        const uint32_t m = surface_reaction<FWD, M>(lens[k], r, trips.t[k]);
+        // the constants of the next surface (of this one again after the last: a harmless load)
+        const int kn = step + 1 < n ? (FWD ? k + 1 : k - 1) : k;
+        SurfRaw nxt;
+        Surf s;
+        s.a = cur.a; s.b = cur.b;
+        const uint32_t m = surface_reaction<FWD, M>(s, lens + k, surf_trips(cur, k), r,
+                                                    [&] { surf_issue<FWD>(nxt, lens + kn, trip_words, kn); });
         if (lds_mask && m != 0u && ((int)__lane_id() == __builtin_ctzll(__ballot(1))))
             atomicOr(&lds_mask[k], m);
+        surf_wait(nxt);
+        cur = nxt;
+        k = kn;
     }
+}
+
+// byte `off` of this kernel's argument segment
+__device__ __forceinline__ const void* kernarg_at(int off)
+{
+    return (const void*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + off);
 }
 
 // ---------------------------------------------------------------------------
@@ -187,15 +238,14 @@ __global__ void k_pupil_samples(const float* __restrict__ ut, const float* __res
     y2[s] = r * (float)__ocml_sin_f64((double)theta);
 }
 
-template <class M = Ieee, class T = float>
-__device__ __forceinline__ RayT<T> make_ray(float px, float py, float pz, T x2, T y2, float z2)
+template <class M = Ieee>
+__device__ __forceinline__ Ray make_ray(float px, float py, float pz, float x2, float y2, float z2)
 {
-    using L = Lane<T>;
-    RayT<T> r;
-    r.ox = L::splat(px); r.oy = L::splat(py); r.oz = L::splat(pz);
-    r.dx = x2 - px; r.dy = y2 - py; r.dz = L::splat(z2 - pz);   // optics.py:490
-    normalize3<M>(r.dx, r.dy, r.dz);                              // basics.py:245
-    r.ra = L::splat(1.0f); r.ob = L::splat(1.0f);
+    Ray r;
+    r.ox = px; r.oy = py; r.oz = pz;
+    r.dx = x2 - px; r.dy = y2 - py; r.dz = z2 - pz;               // optics.py:490
+    normalize3<M, true>(r.dx, r.dy, r.dz);                        // basics.py:245 (pupil != point)
+    r.ra = 1.0f; r.ob = 1.0f;
     return r;
 }
 
@@ -237,8 +287,8 @@ __global__ void k_rays_to_aos(sdirt_rays R, int64_t M, float* __restrict__ o, fl
 
 template <bool FWD, class MP>
 __global__ void __launch_bounds__(kBlock)
-k_trace(const DevSurface* __restrict__ lens, int K, int first, int last, TripTable trips,
-        sdirt_rays R, int64_t M, uint32_t* __restrict__ conv_mask)
+k_trace(TripTable trips /* kernarg offset 0 */, const DevSurface* __restrict__ lens, int K, int first,
+        int last, sdirt_rays R, int64_t M, uint32_t* __restrict__ conv_mask)
 {
     __shared__ uint32_t lds_mask[SDIRT_MAX_SURFACES];
     if (threadIdx.x < SDIRT_MAX_SURFACES) lds_mask[threadIdx.x] = 0;
@@ -246,7 +296,7 @@ k_trace(const DevSurface* __restrict__ lens, int K, int first, int last, TripTab
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M;
          i += (int64_t)gridDim.x * blockDim.x) {
         Ray r = load_ray(R, i);
-        trace_ray<FWD, MP>(lens, first, last, trips, r, conv_mask ? lds_mask : nullptr);
+        trace_ray<FWD, MP>(lens, first, last, kernarg_at(0), r, conv_mask ? lds_mask : nullptr);
         store_ray(R, i, r);
     }
     __syncthreads();
@@ -357,7 +407,7 @@ __global__ void __launch_bounds__(kBlock) k_psf_normalize(float* __restrict__ ps
 // fixed order (deterministic).
 template <class HotMath>
 __global__ void __launch_bounds__(kFused, 8)
-k_chief_center(const DevSurface* __restrict__ lens, int K, TripTable trips,
+k_chief_center(TripTable trips /* kernarg offset 0 */, const DevSurface* __restrict__ lens, int K,
                const float* __restrict__ po, const float* __restrict__ xc,
                const float* __restrict__ yc, int Sc, float pz, float zs,
                float* __restrict__ center, int32_t* __restrict__ any_valid,
@@ -375,7 +425,7 @@ k_chief_center(const DevSurface* __restrict__ lens, int K, TripTable trips,
     int any = 0;
     for (int s = threadIdx.x; s < Sc; s += blockDim.x) {
         Ray r = make_ray<HotMath>(px, py, pzo, xc[s], yc[s], pz);
-        trace_ray<true, HotMath>(lens, 0, K, trips, r, conv_mask ? lds_mask : nullptr);
+        trace_ray<true, HotMath>(lens, 0, K, kernarg_at(0), r, conv_mask ? lds_mask : nullptr);
         propagate_to<HotMath>(r, zs);
         sx += (double)(r.ox * r.ra);
         sy += (double)(r.oy * r.ra);
@@ -414,7 +464,6 @@ k_chief_center(const DevSurface* __restrict__ lens, int K, TripTable trips,
 // (optics.py:900), reduces the centroid exactly like k_chief_center, and only then splats.
 struct CenterArgs {
     const DevSurface* lens_c;
-    TripTable trips_c;
     const float* xc;
     const float* yc;
     int Sc;
@@ -423,15 +472,16 @@ struct CenterArgs {
     uint32_t* conv_mask_c;
 };
 
-// __launch_bounds__(512, 8): four workgroups per CU = 8 waves per SIMD; without the hint the
-// CENTER instantiations use 101 SGPRs, which the hardware admits only 7 waves per SIMD for.
+// __launch_bounds__(512, 8): four workgroups per CU = 8 waves per SIMD (<= 80 SGPRs, <= 64 VGPRs).
 // The big-radius microlens branch (corner-clipped areas, monte_carlo.py:242-372) needs ~90 VGPRs:
 // capped at 64 it would spill 60 of them to scratch, so it runs at 4 waves per SIMD instead.
+// `sb` MUST stay the first parameter: the kernel reads it as a 64-byte block at offset 0 of its
+// kernel-argument segment (see SplatBlock) and never through the parameter itself.
 template <bool HAVE_R, bool BIG, class HotMath, bool CENTER>
 __global__ void __launch_bounds__(kFused, BIG ? 4 : 8)
-k_psf_lr(const DevSurface* __restrict__ lens, int K, TripTable trips,
-         const float* __restrict__ po, const float* __restrict__ x2, const float* __restrict__ y2,
-         int S, int nsplit, int chunk, float pz, float zs, SplatGeom gm, DevDpParams dp,
+k_psf_lr(SplatBlock sb /* kernarg offset 0 */, TripTable trips /* 64 */, TripTable trips_c /* 128 */,
+         const DevSurface* __restrict__ lens, int K, const float* __restrict__ po, const float* __restrict__ x2, const float* __restrict__ y2,
+         int S, int nsplit, int chunk, float pz, float zs, int ks, float tr, float tl,
          const float* __restrict__ center, uint32_t flags, float* __restrict__ lout,
          float* __restrict__ rout, uint32_t* __restrict__ conv_mask, CenterArgs ca)
 {
@@ -439,8 +489,8 @@ k_psf_lr(const DevSurface* __restrict__ lens, int K, TripTable trips,
     __shared__ uint32_t lds_mask[SDIRT_MAX_SURFACES];
     __shared__ float red[kFused / 64];
     __shared__ float c_sh[2];
-    const int tile = gm.ks * gm.ks;
-    float* tl = tiles;
+    const int tile = ks * ks;
+    float* tl_ = tiles;
     float* trr = tiles + tile;
     const int n = blockIdx.x / nsplit;
     const int j = blockIdx.x - n * nsplit;
@@ -457,7 +507,7 @@ k_psf_lr(const DevSurface* __restrict__ lens, int K, TripTable trips,
         int any = 0;
         for (int s = threadIdx.x; s < ca.Sc; s += blockDim.x) {
             Ray r = make_ray<HotMath>(px, py, pzo, ca.xc[s], ca.yc[s], pz);
-            trace_ray<true, HotMath>(ca.lens_c, 0, K, ca.trips_c, r, ca.conv_mask_c ? lds_mask : nullptr);
+            trace_ray<true, HotMath>(ca.lens_c, 0, K, kernarg_at(128), r, ca.conv_mask_c ? lds_mask : nullptr);
             propagate_to<HotMath>(r, zs);
             sx += (double)(r.ox * r.ra);
             sy += (double)(r.oy * r.ra);
@@ -494,17 +544,33 @@ k_psf_lr(const DevSurface* __restrict__ lens, int K, TripTable trips,
 
     const float cx = CENTER ? c_sh[0] : center[2 * n], cy = CENTER ? c_sh[1] : center[2 * n + 1];
     const int s_end = min(S, (j + 1) * chunk);
+    const void* kernarg = kernarg_at(0);
     auto splat = [&](float sx, float sy, float dx, float dz, float ra) {
+#ifdef SDIRT_ABL_NOSPLAT
+        if (ra > 2.0f) atomicAdd(&tl_[0], sx + sy + dx + dz);
+        return;
+#endif
+        // the splat constants: one 64-byte scalar load per ray, dead again after the splat
+        const u32x16 q = sload_block(kernarg);
+        const auto F = [&](int i) { return __uint_as_float(q[i]); };
+        SplatGeom gm;
+        gm.lim = F(0); gm.x_min = F(1); gm.y_max = F(2); gm.dx_rng = F(3); gm.dy_rng = F(4);
+        gm.ksm1 = F(5); gm.ks = (int)q[6];
+        DevDpParams dp;
+        dp.h = F(7); dp.f = F(8); dp.w = F(9); dp.r = F(10); dp.fmh = F(11); dp.rr = F(12);
+        dp.inv_r = F(13); dp.r_pow2 = (int)q[14]; dp.tr = tr; dp.tl = tl; dp.big = BIG; dp.have_r = HAVE_R;
         SplatTaps tp;
-        if (!splat_taps(gm, sx, sy, cx, cy, ra, tp)) return;
+        if (!splat_taps(gm, UDiv<HotMath>::make(gm.dy_rng), UDiv<HotMath>::make(gm.dx_rng), sx, sy, cx, cy,
+                        ra, tp))
+            return;
         const float x_tan = HotMath::div(-dx, dz);
         float sl, sr;
         if (BIG) dp_weights_big(dp, x_tan, sl, sr);      // separate instantiation: the rarely
-        else dp_weights_small(dp, x_tan, sl, sr);        // used r > 0.5 branch costs registers
-        atomicAdd(&tl[tp.i_tl], tp.w_tl * sl);
-        atomicAdd(&tl[tp.i_tr], tp.w_tr * sl);
-        atomicAdd(&tl[tp.i_bl], tp.w_bl * sl);
-        atomicAdd(&tl[tp.i_br], tp.w_br * sl);
+        else dp_weights_small(dp, UDiv<HotMath>::make(dp.fmh), x_tan, sl, sr);   // used r > 0.5 branch costs registers
+        atomicAdd(&tl_[tp.i_tl], tp.w_tl * sl);
+        atomicAdd(&tl_[tp.i_tr], tp.w_tr * sl);
+        atomicAdd(&tl_[tp.i_bl], tp.w_bl * sl);
+        atomicAdd(&tl_[tp.i_br], tp.w_br * sl);
         if (HAVE_R) {
             atomicAdd(&trr[tp.i_tl], tp.w_tl * sr);
             atomicAdd(&trr[tp.i_tr], tp.w_tr * sr);
@@ -514,7 +580,7 @@ k_psf_lr(const DevSurface* __restrict__ lens, int K, TripTable trips,
     };
     for (int s = j * chunk + threadIdx.x; s < s_end; s += blockDim.x) {
         Ray r = make_ray<HotMath>(px, py, pzo, x2[s], y2[s], pz);
-        trace_ray<true, HotMath>(lens, 0, K, trips, r, conv_mask ? lds_mask : nullptr);
+        trace_ray<true, HotMath>(lens, 0, K, kernarg_at(64), r, conv_mask ? lds_mask : nullptr);
         propagate_to<HotMath>(r, zs);
         splat(r.ox, r.oy, r.dx, r.dz, r.ra);
     }
@@ -523,29 +589,29 @@ k_psf_lr(const DevSurface* __restrict__ lens, int K, TripTable trips,
     float* Lg = lout + (int64_t)n * tile;
     float* Rg = HAVE_R ? rout + (int64_t)n * tile : nullptr;
     if (nsplit == 1) {
-        float denl = 1.0f, denr = 1.0f;
         if (flags & SDIRT_PSF_NORMALIZE) {
             float mx = -INFINITY;
-            for (int i = threadIdx.x; i < tile; i += blockDim.x) mx = fmaxf(mx, tl[i]);
-            denl = block_max(mx, red) + 1e-6f;
+            for (int i = threadIdx.x; i < tile; i += blockDim.x) mx = fmaxf(mx, tl_[i]);
+            const auto div_l = UDiv<HotMath>::make(block_max(mx, red) + 1e-6f);
+            auto div_r = div_l;
             if (HAVE_R) {
                 mx = -INFINITY;
                 for (int i = threadIdx.x; i < tile; i += blockDim.x) mx = fmaxf(mx, trr[i]);
-                denr = block_max(mx, red) + 1e-6f;
+                div_r = UDiv<HotMath>::make(block_max(mx, red) + 1e-6f);
             }
             for (int i = threadIdx.x; i < tile; i += blockDim.x) {
-                Lg[i] = tl[i] / denl;
-                if (HAVE_R) Rg[i] = trr[i] / denr;
+                Lg[i] = div_l(tl_[i]);
+                if (HAVE_R) Rg[i] = div_r(trr[i]);
             }
         } else {
             for (int i = threadIdx.x; i < tile; i += blockDim.x) {
-                Lg[i] = tl[i];
+                Lg[i] = tl_[i];
                 if (HAVE_R) Rg[i] = trr[i];
             }
         }
     } else {
         for (int i = threadIdx.x; i < tile; i += blockDim.x) {
-            const float a = tl[i];
+            const float a = tl_[i];
             if (a != 0.0f) atomicAdd(&Lg[i], a);
             if (HAVE_R) {
                 const float b = trr[i];
@@ -863,6 +929,7 @@ __device__ __forceinline__ uint32_t mix32(uint64_t x)
 //         first = 0, count = 2^32);
 // mode 1: division over pseudo-random operand pairs: mantissas uniform over all 2^23 values,
 //         exponents uniform in [-exp_span, exp_span], random signs;
+// mode 3: sqrt_pos over every fp32 bit pattern i in [first, first+count) inside [2^-100, 2^100];
 // mode 2: division over mantissa pairs i in [first, first+count) of the 2^46 pairs
 //         (a = 1.m_a, b = 1.m_b; exhaustive when first = 0, count = 2^46).
 // out[0] = number of results whose bits differ from the IEEE result, out[1..] = up to 8
@@ -878,6 +945,15 @@ __global__ void k_selftest_math(int mode, uint64_t first, uint64_t count, int ex
             const float a = Lean::sqrt(x), b = __builtin_sqrtf(x);
             const bool same = (__float_as_uint(a) == __float_as_uint(b)) || (a != a && b != b);
             if (!same) {
+                const unsigned long long k = atomicAdd(&out[0], 1ull);
+                if (k < 8) out[1 + k] = i;
+            }
+        } else if (mode == 3) {
+            // sqrt_pos (rsq + Markstein correction) over every fp32 bit pattern in the range it
+            // is specified for, [2^-100, 2^100]
+            const float x = __uint_as_float((uint32_t)i);
+            if (x >= 0x1p-100f && x <= 0x1p100f &&
+                __float_as_uint(Lean::sqrt_pos(x)) != __float_as_uint(__builtin_sqrtf(x))) {
                 const unsigned long long k = atomicAdd(&out[0], 1ull);
                 if (k < 8) out[1 + k] = i;
             }
@@ -1058,8 +1134,8 @@ int sdirt_trace(const sdirt_lens* lens, int32_t first, int32_t last, int32_t bac
     const int grid = grid_for(M, kBlock);
     const bool lean = (flags & SDIRT_PSF_STRICT_IEEE) == 0;
 #define SDIRT_LAUNCH_TRACE(FW, MM)                                                              \
-    k_trace<FW, MM><<<grid, kBlock, 0, as_stream(stream)>>>(lens->dev, lens->n_surfaces, first, \
-                                                            last, tt, rays, M, conv_mask)
+    k_trace<FW, MM><<<grid, kBlock, 0, as_stream(stream)>>>(tt, lens->dev, lens->n_surfaces,    \
+                                                            first, last, rays, M, conv_mask)
     if (backward) {
         if (lean) SDIRT_LAUNCH_TRACE(false, Lean); else SDIRT_LAUNCH_TRACE(false, Ieee);
     } else {
@@ -1139,11 +1215,11 @@ int sdirt_chief_center(const sdirt_lens* lens, const float* point_obj, int64_t N
     if (N == 0) return SDIRT_OK;
     if (!(flags & SDIRT_PSF_STRICT_IEEE))
         k_chief_center<Lean><<<(int)N, kFused, 0, as_stream(stream)>>>(
-            lens->dev, lens->n_surfaces, tt, point_obj, xc, yc, (int)Sc, (float)pupil_z,
+            tt, lens->dev, lens->n_surfaces, point_obj, xc, yc, (int)Sc, (float)pupil_z,
             (float)d_sensor, center, any_valid, conv_mask);
     else
         k_chief_center<Ieee><<<(int)N, kFused, 0, as_stream(stream)>>>(
-            lens->dev, lens->n_surfaces, tt, point_obj, xc, yc, (int)Sc, (float)pupil_z,
+            tt, lens->dev, lens->n_surfaces, point_obj, xc, yc, (int)Sc, (float)pupil_z,
             (float)d_sensor, center, any_valid, conv_mask);
     LAUNCH_CHECK();
     return SDIRT_OK;
@@ -1194,12 +1270,12 @@ static int launch_psf(const sdirt_lens* lens, const float* point_obj, int64_t N,
     if (cen && !fuse_center) {                       // split spp axis: centre as its own launch
         if (lean)
             k_chief_center<Lean><<<(int)N, kFused, 0, st>>>(
-                cen->lens_c->dev, cen->lens_c->n_surfaces, cen->trips_c, point_obj, cen->xc, cen->yc,
+                cen->trips_c, cen->lens_c->dev, cen->lens_c->n_surfaces, point_obj, cen->xc, cen->yc,
                 (int)cen->Sc, (float)pupil_z, (float)d_sensor, cen->center_out, cen->any_valid,
                 cen->conv_mask_c);
         else
             k_chief_center<Ieee><<<(int)N, kFused, 0, st>>>(
-                cen->lens_c->dev, cen->lens_c->n_surfaces, cen->trips_c, point_obj, cen->xc, cen->yc,
+                cen->trips_c, cen->lens_c->dev, cen->lens_c->n_surfaces, point_obj, cen->xc, cen->yc,
                 (int)cen->Sc, (float)pupil_z, (float)d_sensor, cen->center_out, cen->any_valid,
                 cen->conv_mask_c);
         LAUNCH_CHECK();
@@ -1211,13 +1287,16 @@ static int launch_psf(const sdirt_lens* lens, const float* point_obj, int64_t N,
     }
     const SplatGeom gm = make_geom(ps, ks);
     const DevDpParams dpp = make_dp(dp);
+    const SplatBlock sblk = make_splat_block(gm, dpp);
     const int grid = (int)(N * nsplit);
     const bool both = have_r && dpp.have_r;
     size_t lds_bytes = both ? lds : sizeof(float) * tile;
     CenterArgs ca;
+    TripTable ttc;
     std::memset(&ca, 0, sizeof(ca));
+    std::memset(&ttc, 0, sizeof(ttc));
     if (fuse_center) {
-        ca.lens_c = cen->lens_c->dev; ca.trips_c = cen->trips_c; ca.xc = cen->xc; ca.yc = cen->yc;
+        ca.lens_c = cen->lens_c->dev; ttc = cen->trips_c; ca.xc = cen->xc; ca.yc = cen->yc;
         ca.Sc = (int)cen->Sc; ca.center_out = cen->center_out; ca.any_valid = cen->any_valid;
         ca.conv_mask_c = cen->conv_mask_c;
         lds_bytes = std::max(lds_bytes, sizeof(double) * 3 * kFused);   // fp64 reduction scratch
@@ -1229,8 +1308,8 @@ static int launch_psf(const sdirt_lens* lens, const float* point_obj, int64_t N,
                                         hipFuncAttributeMaxDynamicSharedMemorySize,               \
                                         160 * 1024 - 1024));                                      \
         k_psf_lr<HR, BG, MM, CT><<<grid, kFused, lds_bytes, st>>>(                                \
-            lens->dev, lens->n_surfaces, tt, point_obj, x2, y2, (int)S, nsplit, chunk,            \
-            (float)pupil_z, (float)d_sensor, gm, dpp, center, flags, l_psf,                       \
+            sblk, tt, ttc, lens->dev, lens->n_surfaces, point_obj, x2, y2, (int)S, nsplit, chunk, \
+            (float)pupil_z, (float)d_sensor, ks, dpp.tr, dpp.tl, center, flags, l_psf,            \
             both ? r_psf : nullptr, conv_mask, ca);                                               \
     } while (0)
 #define SDIRT_LAUNCH_PSF_C(HR, BG, MM)                                                            \
@@ -1306,7 +1385,7 @@ int sdirt_psf_lr_centered(const sdirt_lens* lens, const sdirt_lens* lens_center,
 int sdirt_selftest_math(int32_t mode, uint64_t first, uint64_t count, int32_t exp_span,
                         uint64_t* out, void* stream)
 {
-    if (!out || mode < 0 || mode > 2 || exp_span < 0 || exp_span > 60)
+    if (!out || mode < 0 || mode > 3 || exp_span < 0 || exp_span > 60)
         return fail(SDIRT_ERR_INVALID_ARGUMENT, "bad argument");
     HIP_TRY(hipMemsetAsync(out, 0, sizeof(uint64_t) * 9, as_stream(stream)));
     if (count == 0) return SDIRT_OK;

@@ -278,6 +278,9 @@ def test_lean_math_is_exact():
     assert run(0, 0x80000000, 1) == 0 and run(0, 0xBF800000, 1) == 0   # -0, -1 -> NaN
     assert run(1, 0, 1 << 36, 40) == 0
     assert run(2, 0x123456789AB, 1 << 36) == 0
+    # sqrt_pos (v_rsq + Markstein correction; positive normal arguments only): EVERY fp32 in
+    # [2^-100, 2^100] -- mode 3 skips bit patterns outside that range by itself
+    assert run(3, 0, 1 << 32) == 0
 
 
 def test_deferred_trip_check_equals_the_immediate_one():

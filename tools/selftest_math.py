@@ -3,7 +3,8 @@
 against the compiler's correctly rounded sequences, on the GPU.
   division: all 2^46 (mantissa_a, mantissa_b) pairs, operands in [1,2)   (~2.5 min)
   sqrt    : every fp32 with exponent in [-100, 128)                      (~0.5 s)
-Output is kept in profiles/r01/selftest_math.txt."""
+  sqrt_pos: every fp32 in [2^-100, 2^100]                                (~0.5 s)
+Output is kept in profiles/rNN/selftest_math.txt."""
 import os
 import sys
 import time
@@ -35,6 +36,9 @@ print("sqrt, every fp32 in [2^-100, inf):", run(0, pat(-100), 0x7F800000 - pat(-
       f"{time.time() - t:.1f} s")
 print("sqrt, +0 / +inf / NaN / -0 / negatives:", run(0, 0, 1), run(0, 0x7F800000, 1),
       run(0, 0x7FC00000, 1), run(0, 0x80000000, 1), run(0, 0x80800000, 0xFF800001 - 0x80800000))
+t = time.time()
+print("sqrt_pos (rsq + Markstein), every fp32 in [2^-100, 2^100]:", run(3, 0, 1 << 32),
+      f"{time.time() - t:.1f} s")
 t = time.time()
 total = 0
 step = 1 << 42
