@@ -318,10 +318,12 @@ __device__ __forceinline__ void normalize3(float& x, float& y, float& z)
 // them, wave-uniform); P = NoPoly: pure conic (every sphere).
 // r2 ** n as torch evaluates it on CPU: n == 2 -> x*x, n == 3 -> (x*x)*x, n >= 4 a <= 1-ulp
 // vector pow, for which the correctly rounded exact power stands here (running product in
-// fp64, rounded once per term) -- identical in oracle/sdirt_oracle.c.
+// fp64, rounded once per term) -- the parity oracle evaluates the same expression.
 // the conic's constants as the Newton loop holds them: in VGPRs.  A vector instruction with an
 // SGPR source operand issues at 0.55x the rate of one with VGPR / inline-constant sources on
-// gfx950 (tools/newton_bench.hip); six per trip are worth five v_mov per surface.
+// gfx950 (tools/newton_bench.hip: 2.65 vs 1.47 cycles per SIMD at 8 waves); six per trip against
+// four v_mov per surface.  (End to end the two forms time the same within run-to-run noise:
+// profiles/r02 kbench logs; SDIRT_CONIC_SGPR selects the SGPR form.)
 struct ConicV {
     float c, c2, onepk, d;
 };
