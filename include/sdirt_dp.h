@@ -37,6 +37,7 @@ extern "C" {
 #define SDIRT_MAX_SURFACES 64
 #define SDIRT_MAX_AI 8
 #define SDIRT_NEWTON_MAXITER 10 /* deeplens/surfaces.py:26 */
+#define SDIRT_MAX_WAVELENGTHS 3 /* wavelength slots of one fused launch (psf_rgb) */
 #define SDIRT_MAX_KS 141        /* two ks*ks fp32 tiles + 1 KiB of bookkeeping fit in 160 KiB of LDS */
 
 typedef enum sdirt_status {
@@ -239,6 +240,25 @@ int sdirt_psf_lr_centered(const sdirt_lens* lens, const sdirt_lens* lens_center,
                           int32_t* any_valid /*dev or NULL*/, float* l_psf /*dev [N,ks,ks]*/,
                           float* r_psf /*dev or NULL*/, uint32_t* conv_mask /*dev [K] or NULL*/,
                           uint32_t* conv_mask_center /*dev [K] or NULL*/, void* stream);
+
+/* Lensgroup.psf_rgb, deeplens/optics.py:999-1015 (and psf_map, :1018-1041, on top of it), as ONE
+ * kernel launch: n_wvln (<= SDIRT_MAX_WAVELENGTHS) independent psf_diff calls -- one lens table,
+ * one primary and one chief-ray pupil sample set (the reference draws fresh samples per
+ * wavelength), one Newton trip table and one convergence-mask row per wavelength slot
+ * (gridDim.y = n_wvln), every chief-ray pass through lens_center (optics.py:900).
+ * Layouts: lens host [n_wvln]; x2 / y2 dev [n_wvln][S]; xc / yc dev [n_wvln][Sc]; trips /
+ * trips_center host [n_wvln][K]; center dev [n_wvln][N][2]; any_valid dev [n_wvln];
+ * l_psf / r_psf dev [N][n_wvln][ks][ks] (the reference's torch.stack(..., dim=-3));
+ * conv_mask / conv_mask_center dev [n_wvln][SDIRT_MAX_SURFACES].
+ * One workgroup per (point, wavelength) whatever N and S are, so the chief-ray pass is always fused. */
+int sdirt_psf_rgb_centered(const sdirt_lens* const* lens /*host [n_wvln]*/, int32_t n_wvln,
+                           const sdirt_lens* lens_center, const float* point_obj /*dev [N,3]*/,
+                           int64_t n_points, const float* x2, const float* y2, int64_t spp,
+                           const float* xc, const float* yc, int64_t spp_center, double pupil_z,
+                           double d_sensor, double ps, int32_t ks, const sdirt_dp_params* dp,
+                           const int32_t* trips, const int32_t* trips_center, uint32_t flags,
+                           float* center, int32_t* any_valid, float* l_psf, float* r_psf,
+                           uint32_t* conv_mask, uint32_t* conv_mask_center, void* stream);
 
 /* ---- diagnostics ----------------------------------------------------------- */
 

@@ -15,6 +15,7 @@ MAX_SURFACES = 64
 MAX_AI = 8
 NEWTON_MAXITER = 10
 MAX_KS = 141
+MAX_WAVELENGTHS = 3
 PSF_NORMALIZE = 1
 PSF_STRICT_IEEE = 4
 
@@ -70,6 +71,9 @@ SIGNATURES = {
     "sdirt_psf_lr_centered": (C.c_int, [_P, _P, _P, _I64, _P, _P, _I64, _P, _P, _I64, _D, _D, _D, _I32,
                                         C.POINTER(DpParams), C.POINTER(_I32), C.POINTER(_I32), _U32,
                                         _P, _P, _P, _P, _P, _P, _P]),
+    "sdirt_psf_rgb_centered": (C.c_int, [C.POINTER(_P), _I32, _P, _P, _I64, _P, _P, _I64, _P, _P, _I64, _D, _D, _D,
+                                         _I32, C.POINTER(DpParams), C.POINTER(_I32), C.POINTER(_I32), _U32,
+                                         _P, _P, _P, _P, _P, _P, _P]),
     "sdirt_selftest_math": (C.c_int, [_I32, C.c_uint64, C.c_uint64, _I32, _P, _P]),
     "sdirt_local_psf_render": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P, _P]),
     "sdirt_psfnet_render": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P]),

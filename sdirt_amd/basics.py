@@ -138,6 +138,23 @@ class Ray:
         if obliq is not None:
             self.obliq = obliq
 
+    @classmethod
+    def from_normalized(cls, o, d, wvln=DEFAULT_WAVE, ra=None, device=None):
+        """Adopt unit direction vectors exactly as given (the constructor re-normalises, as the
+        reference's does; renormalising an already normalised vector can move its last bit).
+        For ray-level hand-off: rays captured AFTER the reference's Ray.__init__ (basics.py:245)."""
+        device = torch.device(device) if device is not None else default_device()
+        o = torch.as_tensor(o).to(device=device, dtype=torch.float32).contiguous()
+        d = torch.as_tensor(d).to(device=device, dtype=torch.float32).expand_as(o).contiguous()
+        self = cls.__new__(cls)
+        self._init_empty(tuple(o.shape[:-1]), wvln, device)
+        ra_d = None
+        if ra is not None:
+            ra_d = ra.to(device=device, dtype=torch.float32).expand(self.shape).contiguous()
+        _lib.check(_lib.lib().sdirt_rays_from_aos(dptr(o), dptr(d), dptr(ra_d), self.numel, 0,
+                                                  self.c_rays(), stream_ptr(device)))
+        return self
+
     # -- construction helpers -------------------------------------------------
     def _init_empty(self, shape, wvln, device):
         require_gpu(device)

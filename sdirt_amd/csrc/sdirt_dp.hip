@@ -477,12 +477,21 @@ struct CenterArgs {
 // capped at 64 it would spill 60 of them to scratch, so it runs at 4 waves per SIMD instead.
 // `sb` MUST stay the first parameter: the kernel reads it as a 64-byte block at offset 0 of its
 // kernel-argument segment (see SplatBlock) and never through the parameter itself.
+// blockIdx.y = wavelength slot w of a multi-wavelength launch (psf_rgb: gridDim.y = 3, one lens
+// table, pupil sample set, trip table and mask row per slot; a plain call has gridDim.y = 1): the
+// output is [N, gridDim.y, ks, ks], the reference's psf_rgb layout (optics.py:1015).
+struct LensSet {
+    const DevSurface* p[SDIRT_MAX_WAVELENGTHS];
+};
+struct TripSet {
+    TripTable t[SDIRT_MAX_WAVELENGTHS];
+};
 template <bool HAVE_R, bool BIG, class HotMath, bool CENTER>
 __global__ void __launch_bounds__(kFused, BIG ? 4 : 8)
-k_psf_lr(SplatBlock sb /* kernarg offset 0 */, TripTable trips /* 64 */, TripTable trips_c /* 128 */,
-         const DevSurface* __restrict__ lens, int K, const float* __restrict__ po, const float* __restrict__ x2, const float* __restrict__ y2,
-         int S, int nsplit, int chunk, float pz, float zs, int ks, float tr, float tl,
-         const float* __restrict__ center, uint32_t flags, float* __restrict__ lout,
+k_psf_lr(SplatBlock sb /* kernarg offset 0 */, TripSet trips /* 64 */, TripSet trips_c /* 64 + 64 W */,
+         LensSet lens_set, int K, const float* __restrict__ po, const float* __restrict__ x2,
+         const float* __restrict__ y2, int S, int nsplit, int chunk, float pz, float zs, int ks, float tr,
+         float tl, const float* __restrict__ center, uint32_t flags, float* __restrict__ lout,
          float* __restrict__ rout, uint32_t* __restrict__ conv_mask, CenterArgs ca)
 {
     extern __shared__ __attribute__((aligned(16))) float tiles[];   // [L | R] ks*ks each
@@ -494,6 +503,20 @@ k_psf_lr(SplatBlock sb /* kernarg offset 0 */, TripTable trips /* 64 */, TripTab
     float* trr = tiles + tile;
     const int n = blockIdx.x / nsplit;
     const int j = blockIdx.x - n * nsplit;
+    const int w = blockIdx.y, W = gridDim.y;
+    const int N = gridDim.x / nsplit;
+    const DevSurface* __restrict__ lens = lens_set.p[w];
+    constexpr int kTripsAt = 64, kTripsCAt = 64 + 64 * SDIRT_MAX_WAVELENGTHS;
+    x2 += (int64_t)w * S; y2 += (int64_t)w * S;
+    if (conv_mask) conv_mask += w * SDIRT_MAX_SURFACES;
+    if (CENTER) {
+        ca.xc += (int64_t)w * ca.Sc; ca.yc += (int64_t)w * ca.Sc;
+        ca.center_out += (int64_t)w * N * 2;
+        if (ca.any_valid) ca.any_valid += w;
+        if (ca.conv_mask_c) ca.conv_mask_c += w * SDIRT_MAX_SURFACES;
+    } else if (center) {
+        center += (int64_t)w * N * 2;
+    }
     const float px = po[3 * n], py = po[3 * n + 1], pzo = po[3 * n + 2];
 
     if (CENTER) {
@@ -507,7 +530,8 @@ k_psf_lr(SplatBlock sb /* kernarg offset 0 */, TripTable trips /* 64 */, TripTab
         int any = 0;
         for (int s = threadIdx.x; s < ca.Sc; s += blockDim.x) {
             Ray r = make_ray<HotMath>(px, py, pzo, ca.xc[s], ca.yc[s], pz);
-            trace_ray<true, HotMath>(ca.lens_c, 0, K, kernarg_at(128), r, ca.conv_mask_c ? lds_mask : nullptr);
+            trace_ray<true, HotMath>(ca.lens_c, 0, K, kernarg_at(kTripsCAt + 64 * w), r,
+                                     ca.conv_mask_c ? lds_mask : nullptr);
             propagate_to<HotMath>(r, zs);
             sx += (double)(r.ox * r.ra);
             sy += (double)(r.oy * r.ra);
@@ -580,14 +604,14 @@ k_psf_lr(SplatBlock sb /* kernarg offset 0 */, TripTable trips /* 64 */, TripTab
     };
     for (int s = j * chunk + threadIdx.x; s < s_end; s += blockDim.x) {
         Ray r = make_ray<HotMath>(px, py, pzo, x2[s], y2[s], pz);
-        trace_ray<true, HotMath>(lens, 0, K, kernarg_at(64), r, conv_mask ? lds_mask : nullptr);
+        trace_ray<true, HotMath>(lens, 0, K, kernarg_at(kTripsAt + 64 * w), r, conv_mask ? lds_mask : nullptr);
         propagate_to<HotMath>(r, zs);
         splat(r.ox, r.oy, r.dx, r.dz, r.ra);
     }
     __syncthreads();
 
-    float* Lg = lout + (int64_t)n * tile;
-    float* Rg = HAVE_R ? rout + (int64_t)n * tile : nullptr;
+    float* Lg = lout + ((int64_t)n * W + w) * tile;
+    float* Rg = HAVE_R ? rout + ((int64_t)n * W + w) * tile : nullptr;
     if (nsplit == 1) {
         if (flags & SDIRT_PSF_NORMALIZE) {
             float mx = -INFINITY;
@@ -1225,30 +1249,23 @@ int sdirt_chief_center(const sdirt_lens* lens, const float* point_obj, int64_t N
     return SDIRT_OK;
 }
 
-// Shared launcher of sdirt_psf_lr / sdirt_psf_lr_centered.  `cen` != nullptr requests the
-// chief-ray pass: inside the same kernel when one workgroup owns a point (nsplit == 1), as a
-// preceding k_chief_center launch otherwise.
+// Shared launcher of sdirt_psf_lr / sdirt_psf_lr_centered / sdirt_psf_rgb_centered.  `cen` != nullptr
+// requests the chief-ray pass: inside the same kernel when one workgroup owns a point (nsplit ==
+// 1), as a preceding k_chief_center launch otherwise.  W wavelength slots (W > 1 needs nsplit == 1):
+// lens[w], trips[w], x2 / y2 [W][S], outputs [N][W][ks][ks], masks [W][SDIRT_MAX_SURFACES].
 struct CenterRequest {
     const sdirt_lens* lens_c;
-    const float* xc;
+    const float* xc;              // [W][Sc]
     const float* yc;
     int64_t Sc;
-    TripTable trips_c;
-    float* center_out;
-    int32_t* any_valid;
-    uint32_t* conv_mask_c;
+    TripSet trips_c;
+    float* center_out;            // [W][N][2]
+    int32_t* any_valid;           // [W]
+    uint32_t* conv_mask_c;        // [W][SDIRT_MAX_SURFACES]
 };
 
-static int launch_psf(const sdirt_lens* lens, const float* point_obj, int64_t N, const float* x2,
-                      const float* y2, int64_t S, double pupil_z, double d_sensor, double ps,
-                      int32_t ks, const float* center, const CenterRequest* cen,
-                      const sdirt_dp_params* dp, const TripTable& tt, uint32_t flags, float* l_psf,
-                      float* r_psf, uint32_t* conv_mask, void* stream)
+static int spp_split(int64_t N, int64_t S, int* chunk_out)
 {
-    const bool have_r = r_psf != nullptr;
-    const int tile = ks * ks;
-    const size_t lds = sizeof(float) * tile * (have_r ? 2 : 1);
-
     // Fill the chip: at least ~4 workgroups per CU; split the spp axis when the
     // number of points alone cannot (e.g. PSFNet training: N=64, S=20000).
     int nsplit = 1;
@@ -1263,6 +1280,24 @@ static int launch_psf(const sdirt_lens* lens, const float* point_obj, int64_t N,
     chunk = ((chunk + kFused - 1) / kFused) * kFused;
     nsplit = (int)((S + chunk - 1) / (chunk > 0 ? chunk : 1));
     if (nsplit < 1) nsplit = 1;
+    if (chunk_out) *chunk_out = chunk;
+    return nsplit;
+}
+
+static int launch_psf(const sdirt_lens* const* lens, int W, const float* point_obj, int64_t N,
+                      const float* x2, const float* y2, int64_t S, double pupil_z, double d_sensor,
+                      double ps, int32_t ks, const float* center, const CenterRequest* cen,
+                      const sdirt_dp_params* dp, const TripSet& tt, uint32_t flags, float* l_psf,
+                      float* r_psf, uint32_t* conv_mask, void* stream)
+{
+    const bool have_r = r_psf != nullptr;
+    const int tile = ks * ks;
+    const size_t lds = sizeof(float) * tile * (have_r ? 2 : 1);
+    // a multi-wavelength launch keeps one workgroup per (point, wavelength): the chief-ray pass
+    // stays fused and the whole of psf_rgb is one kernel, also for the few points of a psf_map
+    int chunk = ((int)S + kFused - 1) / kFused * kFused;
+    const int nsplit = W > 1 ? 1 : spp_split(N, S, &chunk);
+    const int K = lens[0]->n_surfaces;
 
     hipStream_t st = as_stream(stream);
     const bool lean = (flags & SDIRT_PSF_STRICT_IEEE) == 0;
@@ -1270,14 +1305,12 @@ static int launch_psf(const sdirt_lens* lens, const float* point_obj, int64_t N,
     if (cen && !fuse_center) {                       // split spp axis: centre as its own launch
         if (lean)
             k_chief_center<Lean><<<(int)N, kFused, 0, st>>>(
-                cen->trips_c, cen->lens_c->dev, cen->lens_c->n_surfaces, point_obj, cen->xc, cen->yc,
-                (int)cen->Sc, (float)pupil_z, (float)d_sensor, cen->center_out, cen->any_valid,
-                cen->conv_mask_c);
+                cen->trips_c.t[0], cen->lens_c->dev, K, point_obj, cen->xc, cen->yc, (int)cen->Sc,
+                (float)pupil_z, (float)d_sensor, cen->center_out, cen->any_valid, cen->conv_mask_c);
         else
             k_chief_center<Ieee><<<(int)N, kFused, 0, st>>>(
-                cen->trips_c, cen->lens_c->dev, cen->lens_c->n_surfaces, point_obj, cen->xc, cen->yc,
-                (int)cen->Sc, (float)pupil_z, (float)d_sensor, cen->center_out, cen->any_valid,
-                cen->conv_mask_c);
+                cen->trips_c.t[0], cen->lens_c->dev, K, point_obj, cen->xc, cen->yc, (int)cen->Sc,
+                (float)pupil_z, (float)d_sensor, cen->center_out, cen->any_valid, cen->conv_mask_c);
         LAUNCH_CHECK();
         center = cen->center_out;
     }
@@ -1288,13 +1321,16 @@ static int launch_psf(const sdirt_lens* lens, const float* point_obj, int64_t N,
     const SplatGeom gm = make_geom(ps, ks);
     const DevDpParams dpp = make_dp(dp);
     const SplatBlock sblk = make_splat_block(gm, dpp);
-    const int grid = (int)(N * nsplit);
+    const dim3 grid((unsigned)(N * nsplit), (unsigned)W);
     const bool both = have_r && dpp.have_r;
     size_t lds_bytes = both ? lds : sizeof(float) * tile;
     CenterArgs ca;
-    TripTable ttc;
+    TripSet ttc;
+    LensSet ls;
     std::memset(&ca, 0, sizeof(ca));
     std::memset(&ttc, 0, sizeof(ttc));
+    std::memset(&ls, 0, sizeof(ls));
+    for (int w = 0; w < W; ++w) ls.p[w] = lens[w]->dev;
     if (fuse_center) {
         ca.lens_c = cen->lens_c->dev; ttc = cen->trips_c; ca.xc = cen->xc; ca.yc = cen->yc;
         ca.Sc = (int)cen->Sc; ca.center_out = cen->center_out; ca.any_valid = cen->any_valid;
@@ -1308,9 +1344,9 @@ static int launch_psf(const sdirt_lens* lens, const float* point_obj, int64_t N,
                                         hipFuncAttributeMaxDynamicSharedMemorySize,               \
                                         160 * 1024 - 1024));                                      \
         k_psf_lr<HR, BG, MM, CT><<<grid, kFused, lds_bytes, st>>>(                                \
-            sblk, tt, ttc, lens->dev, lens->n_surfaces, point_obj, x2, y2, (int)S, nsplit, chunk, \
-            (float)pupil_z, (float)d_sensor, ks, dpp.tr, dpp.tl, center, flags, l_psf,            \
-            both ? r_psf : nullptr, conv_mask, ca);                                               \
+            sblk, tt, ttc, ls, K, point_obj, x2, y2, (int)S, nsplit, chunk, (float)pupil_z,       \
+            (float)d_sensor, ks, dpp.tr, dpp.tl, center, flags, l_psf, both ? r_psf : nullptr,    \
+            conv_mask, ca);                                                                       \
     } while (0)
 #define SDIRT_LAUNCH_PSF_C(HR, BG, MM)                                                            \
     do {                                                                                          \
@@ -1325,7 +1361,7 @@ static int launch_psf(const sdirt_lens* lens, const float* point_obj, int64_t N,
     } else {
         if (dpp.big) SDIRT_LAUNCH_PSF_M(false, true); else SDIRT_LAUNCH_PSF_M(false, false);
         // param_list=None leaves the R grid all-zero (monte_carlo.py:230-235)
-        if (have_r) HIP_TRY(hipMemsetAsync(r_psf, 0, sizeof(float) * (size_t)N * tile, st));
+        if (have_r) HIP_TRY(hipMemsetAsync(r_psf, 0, sizeof(float) * (size_t)N * W * tile, st));
     }
 #undef SDIRT_LAUNCH_PSF_M
 #undef SDIRT_LAUNCH_PSF_C
@@ -1349,10 +1385,11 @@ int sdirt_psf_lr(const sdirt_lens* lens, const float* point_obj, int64_t N, cons
         return fail(SDIRT_ERR_INVALID_ARGUMENT, "bad argument");
     if (int rc = check_ks(ks)) return rc;
     if (dp && !(dp->r > 0.0)) return fail(SDIRT_ERR_INVALID_ARGUMENT, "dp->r must be > 0");
-    TripTable tt;
-    if (int rc = make_trips(lens, trips, tt)) return rc;
+    TripSet tt;
+    std::memset(&tt, 0, sizeof(tt));
+    if (int rc = make_trips(lens, trips, tt.t[0])) return rc;
     if (N == 0) return SDIRT_OK;
-    return launch_psf(lens, point_obj, N, x2, y2, S, pupil_z, d_sensor, ps, ks, center, nullptr, dp,
+    return launch_psf(&lens, 1, point_obj, N, x2, y2, S, pupil_z, d_sensor, ps, ks, center, nullptr, dp,
                       tt, flags, l_psf, r_psf, conv_mask, stream);
 }
 
@@ -1364,21 +1401,43 @@ int sdirt_psf_lr_centered(const sdirt_lens* lens, const sdirt_lens* lens_center,
                           float* center, int32_t* any_valid, float* l_psf, float* r_psf,
                           uint32_t* conv_mask, uint32_t* conv_mask_center, void* stream)
 {
-    if (!lens || !lens_center || !point_obj || !x2 || !y2 || !xc || !yc || !center || !l_psf ||
-        N < 0 || S < 0 || Sc < 0 || S > (1ll << 30) || Sc > (1ll << 30) || N > (1ll << 30))
+    return sdirt_psf_rgb_centered(&lens, 1, lens_center, point_obj, N, x2, y2, S, xc, yc, Sc, pupil_z,
+                                  d_sensor, ps, ks, dp, trips, trips_center, flags, center, any_valid,
+                                  l_psf, r_psf, conv_mask, conv_mask_center, stream);
+}
+
+int sdirt_psf_rgb_centered(const sdirt_lens* const* lens, int32_t W, const sdirt_lens* lens_center,
+                           const float* point_obj, int64_t N, const float* x2, const float* y2,
+                           int64_t S, const float* xc, const float* yc, int64_t Sc, double pupil_z,
+                           double d_sensor, double ps, int32_t ks, const sdirt_dp_params* dp,
+                           const int32_t* trips, const int32_t* trips_center, uint32_t flags,
+                           float* center, int32_t* any_valid, float* l_psf, float* r_psf,
+                           uint32_t* conv_mask, uint32_t* conv_mask_center, void* stream)
+{
+    if (!lens || W < 1 || W > SDIRT_MAX_WAVELENGTHS || !lens_center || !point_obj || !x2 || !y2 || !xc ||
+        !yc || !center || !l_psf || N < 0 || S < 0 || Sc < 0 || S > (1ll << 30) || Sc > (1ll << 30) ||
+        N > (1ll << 30))
         return fail(SDIRT_ERR_INVALID_ARGUMENT, "bad argument");
-    if (lens_center->n_surfaces != lens->n_surfaces)
-        return fail(SDIRT_ERR_INVALID_ARGUMENT, "lens and lens_center differ in surface count");
+    for (int w = 0; w < W; ++w)
+        if (!lens[w] || lens[w]->n_surfaces != lens_center->n_surfaces)
+            return fail(SDIRT_ERR_INVALID_ARGUMENT, "lens[%d] missing or surface count differs from lens_center", w);
     if (int rc = check_ks(ks)) return rc;
     if (dp && !(dp->r > 0.0)) return fail(SDIRT_ERR_INVALID_ARGUMENT, "dp->r must be > 0");
-    TripTable tt;
+    const int K = lens_center->n_surfaces;
+    TripSet tt;
     CenterRequest cr;
-    if (int rc = make_trips(lens, trips, tt)) return rc;
-    if (int rc = make_trips(lens_center, trips_center, cr.trips_c)) return rc;
+    std::memset(&tt, 0, sizeof(tt));
+    std::memset(&cr.trips_c, 0, sizeof(cr.trips_c));
+    for (int w = 0; w < W; ++w) {
+        if (int rc = make_trips(lens[w], trips ? trips + (size_t)w * K : nullptr, tt.t[w])) return rc;
+        if (int rc = make_trips(lens_center, trips_center ? trips_center + (size_t)w * K : nullptr,
+                                cr.trips_c.t[w]))
+            return rc;
+    }
     if (N == 0) return SDIRT_OK;
     cr.lens_c = lens_center; cr.xc = xc; cr.yc = yc; cr.Sc = Sc; cr.center_out = center;
     cr.any_valid = any_valid; cr.conv_mask_c = conv_mask_center;
-    return launch_psf(lens, point_obj, N, x2, y2, S, pupil_z, d_sensor, ps, ks, nullptr, &cr, dp, tt,
+    return launch_psf(lens, W, point_obj, N, x2, y2, S, pupil_z, d_sensor, ps, ks, nullptr, &cr, dp, tt,
                       flags, l_psf, r_psf, conv_mask, stream);
 }
 

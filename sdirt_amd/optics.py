@@ -666,27 +666,102 @@ class Lensgroup:
             R = R.squeeze(0) if R is not None else None
         return L, R
 
-    def psf_rgb(self, points, ks=31, spp=GEO_SPP, center=True, param_list=None):
-        """optics.py:999-1015: [N,3,ks,ks] (or [3,ks,ks])."""
-        n_points = points.shape[0] if torch.is_tensor(points) and points.dim() == 2 else 1
-        if center and n_points > 0:
-            # the three wavelengths are independent calls (fresh pupil draws each, in the
-            # reference's order): enqueue all three, then run the three trip checks -- one host
-            # wait instead of three, the kernels back to back on the GPU
-            pending = [self.psf_diff(points=points, wvln=w, ks=ks, spp=spp, center=center,
-                                     param_list=param_list, _defer=True) for w in WAVE_RGB]
-            psfs = [p.wait() for p in pending]
-        else:
-            psfs = [self.psf_diff(points=points, wvln=w, ks=ks, spp=spp, center=center,
-                                  param_list=param_list) for w in WAVE_RGB]
+    def psf_rgb(self, points, ks=31, spp=GEO_SPP, center=True, param_list=None, pupil_xy=None,
+                center_pupil_xy=None):
+        """optics.py:999-1015: [N,3,ks,ks] (or [3,ks,ks]) -- the three wavelengths of WAVE_RGB, each an
+        independent psf_diff (fresh pupil draws, in the reference's order; every chief-ray centre
+        through the green lens).  With center=True the three calls are
+        ONE kernel launch whatever the number of points (sdirt_psf_rgb_centered: lens table, pupil sets, trip tables and mask rows
+        indexed by blockIdx.y) and one control-block readback.
+        pupil_xy [2, 3, spp] / center_pupil_xy [2, 3, 2048]: explicit pupil sample points per
+        wavelength instead of random draws (ray-level parity hand-off)."""
+        if not torch.is_tensor(points):
+            points = torch.tensor(points)
+        n_points = points.shape[0] if points.dim() == 2 else 1
+        fused = center and n_points > 0 and self.device.type == "cuda" and self.mask_reduce is None
+        if fused:
+            return self._psf_rgb_fused(points, ks, spp, param_list, pupil_xy, center_pupil_xy)
+        if pupil_xy is not None or center_pupil_xy is not None:
+            raise ValueError("explicit pupil points need the fused path (center=True)")
+        psfs = [self.psf_diff(points=points, wvln=w, ks=ks, spp=spp, center=center,
+                              param_list=param_list) for w in WAVE_RGB]
         return torch.stack(psfs, dim=-3)
 
+    @torch.no_grad()
+    def _psf_rgb_fused(self, points, ks, spp, param_list, pupil_xy=None, center_pupil_xy=None):
+        single_point = points.dim() == 1
+        pts = points.reshape(-1, 3)
+        N, W, K, MS = pts.shape[0], len(WAVE_RGB), len(self.surfaces), _lib.MAX_SURFACES
+        direct, dp_ref, dpp = "l", None, None
+        if param_list is not None:
+            h, f, w_, r, direct = param_list
+            dpp = _lib.DpParams(float(h), float(f), float(w_), float(r))
+            dp_ref = C.byref(dpp)
+        want_r = direct != "l"
+        po = self._points_to_object(pts)
+        pupilz, pupilr = self.entrance_pupil()
+        _, pupilr_c = self.entrance_pupil(shrink_pupil=True)
+        # the reference's draw order: per wavelength, primary samples then chief-ray samples
+        prim, cent = [], []
+        for _ in WAVE_RGB:
+            if pupil_xy is None:
+                prim.append(torch.stack(self._pupil_samples(spp, pupilr)))
+            if center_pupil_xy is None:
+                cent.append(torch.stack(self._pupil_samples(GEO_SPP, pupilr_c)))
+        as_dev = lambda v: torch.as_tensor(v).to(self.device, torch.float32).contiguous()
+        prim = torch.stack(prim, 1).contiguous() if pupil_xy is None else as_dev(pupil_xy)              # [2, W, S]
+        cent = torch.stack(cent, 1).contiguous() if center_pupil_xy is None else as_dev(center_pupil_xy)
+        spp = prim.shape[2]
+        handles = (C.c_void_p * W)(*[self.dev_lens(w).value for w in WAVE_RGB])
+        handle_c = self.dev_lens(DEFAULT_WAVE)                # optics.py:900: always green
+        cen = torch.empty((W, N, 2), dtype=torch.float32, device=self.device)
+        L = torch.empty((N, W, ks, ks), dtype=torch.float32, device=self.device)
+        R = torch.empty_like(L) if want_r else None
+        flags = _lib.PSF_NORMALIZE | self._math_flags()
+        # one control block: [primary masks W x MS | chief-ray masks W x MS | any-valid W]
+        ctl = torch.zeros(2 * W * MS + W, dtype=torch.int32, device=self.device)
+        masks = ctl[:2 * W * MS].view(2, W, MS)
+        anyv = ctl[2 * W * MS:]
+        reference = self.trip_policy == "reference"
+
+        def enqueue(tables):
+            tp = np.concatenate([np.asarray(t, np.int32) for t in tables[:W]])
+            tc = np.concatenate([np.asarray(t, np.int32) for t in tables[W:]])
+            with self._timed("psf_rgb_centered"):
+                _lib.check(_lib.lib().sdirt_psf_rgb_centered(
+                    handles, W, handle_c, dptr(po), N, dptr(prim[0]), dptr(prim[1]), spp,
+                    dptr(cent[0]), dptr(cent[1]), GEO_SPP, float(pupilz), float(self.d_sensor),
+                    float(self.pixel_size), ks, dp_ref, (C.c_int32 * (W * K))(*tp.tolist()),
+                    (C.c_int32 * (W * K))(*tc.tolist()), flags, dptr(cen), dptr(anyv), dptr(L), dptr(R),
+                    dptr(masks[0]) if reference else None, dptr(masks[1]) if reference else None,
+                    stream_ptr(self.device)))
+
+        if reference:
+            keys = [("psf", round(float(w), 6), self.precision) for w in WAVE_RGB] + \
+                   [("center", self.precision)] * W
+
+            def launch(tables):
+                ctl.zero_()
+                enqueue(tables)
+                host = ctl.cpu().numpy()
+                launch.any_valid = host[2 * W * MS:]
+                m = host[:2 * W * MS].reshape(2 * W, MS)[:, :K].astype(np.int64) & 0xFFFFFFFF
+                return list(m)
+            self.trips.run_many(keys, self._curved(), list(range(K)), launch)
+            assert bool(np.all(launch.any_valid == 1)), "No sampled rays is valid."   # optics.py:902
+        else:
+            full = self._fixed_trips()
+            enqueue([full] * (2 * W))
+        out = R if want_r else L
+        return out.squeeze(0) if single_point else out
+
     def psf_map(self, depth=DEPTH, grid=7, ks=51, spp=GEO_SPP, center=True):
-        """optics.py:1018-1041: [3, grid*ks, grid*ks] mosaic (torchvision make_grid, padding 0)."""
-        points = self.point_source_grid(depth=depth, grid=grid).reshape(-1, 3)
-        psfs = self.psf_rgb(points=points, ks=ks, center=center, spp=spp)   # [grid^2,3,ks,ks]
-        p = psfs.reshape(grid, grid, 3, ks, ks).permute(2, 0, 3, 1, 4)
-        return p.reshape(3, grid * ks, grid * ks)
+        """optics.py:1018-1041: the RGB PSFs of a grid x grid field of point sources at one depth,
+        tiled into one [3, grid*ks, grid*ks] image (what torchvision's make_grid(nrow=grid,
+        padding=0) assembles: PSF i sits in tile row i // grid, tile column i % grid)."""
+        field = self.point_source_grid(depth=depth, grid=grid).reshape(grid * grid, 3)
+        tiles = self.psf_rgb(points=field, ks=ks, center=center, spp=spp)        # [grid^2, 3, ks, ks]
+        return tiles.view(grid, grid, 3, ks, ks).permute(2, 0, 3, 1, 4).reshape(3, grid * ks, grid * ks)
 
     # ------------------------------------------------------- geometrical optics
     def calc_scale_pinhole(self, depth):

@@ -201,3 +201,67 @@ def test_torch_port_follows_the_reference(oracle, lens_name, fx):
     L2, R2, _, _ = tp.psf(st, g["points"], g["pupil_x2"], g["pupil_y2"], g["pupil_xc"],
                           g["pupil_yc"], ks, dp=DP)
     assert np.abs(L2.numpy() - lo).max() < 3e-3 and np.abs(R2.numpy() - ro).max() < 3e-3
+
+
+def _f14_oracle(oracle, centre_key):
+    st, g = load_state("rf50mm"), load_golden("f14_rf50_mini_c2_rays")
+    ks = int(g["ks"])
+    S, N = g["ray_d0"].shape[:2]
+    surf = oracle.surfaces_from_state(st, 0.589)
+    o0 = np.broadcast_to(g["point_obj"][None], (S, N, 3)).copy()
+    out = oracle.trace(surf, o0, g["ray_d0"], np.ones((S, N), np.float32))
+    assert np.array_equal(out["trips"], g["trips"])
+    osen = oracle.propagate_to(st["d_sensor"], out["o"], out["d"])
+    lg, rg = oracle.forward_integral(osen, out["d"], out["ra"], st["pixel_size"], ks, g[centre_key], dp=DP)
+    return g, oracle.psf_normalize(lg), oracle.psf_normalize(rg)
+
+
+def test_ray_handoff_against_the_reference_with_correctly_rounded_math(oracle):
+    """Fixture F14: the reference's own post-normalise rays of the 3x3x3 / 4096 spp / ks 65 volume go
+    in; trace -> propagate -> splat -> normalise is the oracle's.
+
+    Against the reference as it runs (MKL VML sqrt / acos / sin, < 1 ulp but not correctly
+    rounded): 2.9e-5 of the PSF peak.  Against the SAME reference code with those functions
+    correctly rounded (`*_cr`, oracle/gen_golden_handoff.py): 2.4e-7 -- the whole distance is the
+    math library's last bit, which also moves the reference away from ITSELF by 2.9e-5."""
+    g, L, R = _f14_oracle(oracle, "center_cr")
+    assert np.abs(L - g["psf_cr"]).max() <= 1e-6
+    assert np.abs(R - oracle.psf_normalize(g["grid_r_cr"])).max() <= 1e-6
+    g, L, R = _f14_oracle(oracle, "center")
+    d_plain = np.abs(L - g["psf"]).max()
+    d_self = np.abs(g["psf_cr"] - g["psf"]).max()
+    assert d_plain <= 4e-5 and d_plain <= 1.05 * d_self            # no farther than the reference from itself
+    # chief-ray pass from the reference's own chief rays
+    st = load_state("rf50mm")
+    Sc, N = g["cen_d0"].shape[:2]
+    oc = np.broadcast_to(g["point_obj"][None], (Sc, N, 3)).copy()
+    out = oracle.trace(oracle.surfaces_from_state(st, 0.589), oc, g["cen_d0"], np.ones((Sc, N), np.float32))
+    assert np.array_equal(out["trips"], g["trips_center"])
+    cen, ok = oracle.center_from_rays(oracle.propagate_to(st["d_sensor"], out["o"], out["d"]), out["ra"])
+    assert ok and np.abs(cen - g["center"]).max() <= 4e-6 and np.abs(cen - g["center_cr"]).max() <= 4e-6
+
+
+def test_fp64_truth_sits_between(oracle):
+    """oracle/fp64_truth.py (the same operation sequence in binary64 on the same fp32 rays): the
+    oracle's PSFs are as close to it as the reference's.  (Both are ~2e-3 away at the maximum: WHICH
+    rays pass the 1e-5 mm Newton tolerance on the two aspheres is decided by fp32 rounding noise.)"""
+    from oracle import fp64_truth as tr
+    st = load_state("rf50mm")
+    g, L, R = _f14_oracle(oracle, "center")
+    S, N = g["ray_d0"].shape[:2]
+    o0 = np.broadcast_to(g["point_obj"][None], (S, N, 3))
+    Lt, Rt = tr.psf_from_rays(st, o0, g["ray_d0"], g["trips"], g["center"], int(g["ks"]), DP)
+    rms = lambda a, b: float(np.sqrt(np.mean((a - b) ** 2)))
+    assert rms(L, Lt) <= 1.02 * rms(g["psf"], Lt)
+    assert np.abs(L - Lt).max() <= 1.02 * np.abs(g["psf"] - Lt).max()
+
+
+def test_rms_centre_branch(oracle):
+    """forward_integral(pointc_ref=None) (monte_carlo.py:27-31), fixture F15."""
+    g = load_golden("f15_rms_center")
+    S, N = g["ra"].shape
+    cen, _ = oracle.center_from_rays(g["o"], g["ra"])
+    assert np.abs(cen - g["rms_center"]).max() <= 2e-6
+    lg, rg = oracle.forward_integral(g["o"], g["d"], g["ra"], float(g["ps"]), int(g["ks"]), cen, dp=DP)
+    assert np.abs(lg - g["grid_l_l"]).max() <= 2e-5 * g["grid_l_l"].max()
+    assert np.abs(rg - g["grid_r_l"]).max() <= 2e-5 * g["grid_r_l"].max()
