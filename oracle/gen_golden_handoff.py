@@ -197,6 +197,43 @@ def main():
                     centers=np.stack(rec.centers), wvlns=np.asarray(gg.WAVE_RGB, np.float64))
     gg.save(os.path.abspath(args.out), "f17_rf50_rgb_field", gg.twice(rgb_field))
 
+    # F18 = local_psf_render_high_res (render_psf.py:191-208): the image cut into patches, each
+    # rendered on its own by local_psf_render (so every patch is replicate-padded at ITS border).
+    # The reference's function itself raises (it assigns local_psf_render's (left, right) tuple into
+    # one tensor); the fixture is what its loop computes when both halves are kept: the reference's
+    # own local_psf_render applied patch by patch.
+    def high_res():
+        g = torch.Generator().manual_seed(18)
+        B, C, H, W, ks, patch = 2, 3, 10, 14, 5, (4, 6)
+        img = torch.rand(B, C, H, W, generator=g)
+        psf = torch.rand(B, H, W, 2, ks, ks, generator=g)
+        psf = psf / psf.sum((-1, -2), keepdim=True)
+        rl, rr = torch.zeros_like(img), torch.zeros_like(img)
+        for i0 in range(0, H, patch[0]):
+            for j0 in range(0, W, patch[1]):
+                i1, j1 = min(i0 + patch[0], H), min(j0 + patch[1], W)
+                a, b = gg.ref_render.local_psf_render(img[:, :, i0:i1, j0:j1].clone(),
+                                                      psf[:, i0:i1, j0:j1].clone(), kernel_size=ks)
+                rl[:, :, i0:i1, j0:j1], rr[:, :, i0:i1, j0:j1] = a, b
+        return dict(img=img.numpy(), psf=psf.numpy(), ks=np.int32(ks), patch=np.asarray(patch, np.int32),
+                    left=rl.numpy(), right=rr.numpy())
+    gg.save(os.path.abspath(args.out), "f18_render_high_res", gg.twice(high_res))
+
+    # F19 = point_source_grid (optics.py:816-861) for every option combination the shim mirrors
+    def grids():
+        out = {}
+        for grid in (1, 2, 5, 8):
+            for center in (False, True):
+                for quater in (False, True):
+                    for normalized in (True, False):
+                        if grid == 1 and quater:
+                            continue
+                        p = rf50.point_source_grid(depth=-1234.5, grid=grid, normalized=normalized,
+                                                   quater=quater, center=center)
+                        out[f"g{grid}_c{int(center)}_q{int(quater)}_n{int(normalized)}"] = p.numpy()
+        return out
+    gg.save(os.path.abspath(args.out), "f19_point_source_grid", gg.twice(grids))
+
 
 if __name__ == "__main__":
     main()

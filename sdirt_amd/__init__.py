@@ -12,11 +12,11 @@ from .monte_carlo import (assign_points_to_pixels_big_r, assign_points_to_pixels
 from .optics import Lensgroup, PendingPSF
 from .psfnet import PSFNet
 from .dfdp import DfDPNet, dp_cost_volume
-from .render_psf import (local_dp_psf_render, local_psf_render, local_psf_render_fast, render_psf,
-                         render_psf_map)
+from .render_psf import (local_dp_psf_render, local_psf_render, local_psf_render_fast,
+                         local_psf_render_high_res, render_psf, render_psf_map)
 from .surfaces import Aspheric
 
 __all__ = ["Lensgroup", "PSFNet", "DfDPNet", "dp_cost_volume", "PendingPSF", "Ray", "Material", "Aspheric", "SdirtError", "forward_integral",
            "forward_integral_lr", "assign_points_to_pixels_small_r",
            "assign_points_to_pixels_big_r", "local_psf_render", "local_psf_render_fast",
-           "local_dp_psf_render", "render_psf", "render_psf_map", "DEFAULT_WAVE", "WAVE_RGB", "GEO_SPP", "EPSILON", "DEPTH"]
+           "local_dp_psf_render", "local_psf_render_high_res", "render_psf", "render_psf_map", "DEFAULT_WAVE", "WAVE_RGB", "GEO_SPP", "EPSILON", "DEPTH"]

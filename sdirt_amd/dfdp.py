@@ -25,7 +25,10 @@ from .basics import dptr, stream_ptr
 
 
 def _cost_volume_reference(x, y, d_max):
-    """The reference's formulation (dddnet.py:136-148): zero-fill, then 2 * d_max slice copies."""
+    """The signed-shift cost volume in stock torch ops (zero-fill, then 2 * d_max slice copies, as
+    dddnet.py:136-148 builds it).  DfDPNet is a stock-torch module (MIOpen / CPU convolutions) and
+    runs wherever torch runs; this is what CPU tensors take.  CUDA tensors always take the HIP
+    kernel -- there is no silent fallback from it."""
     B, C, H, W = x.shape
     cost = torch.zeros(B, C * 2, d_max, H, W).type_as(x)
     for i in range(d_max):
@@ -64,9 +67,11 @@ class _CostVolume(torch.autograd.Function):
 
 def dp_cost_volume(x, y, d_max=20):
     """dddnet.py:155-178 / 136-148: x, y [B,C,H,W] -> [B,2C,d_max,H,W] (differentiable)."""
-    if x.is_cuda and x.dtype in (torch.float16, torch.float32):
+    if x.is_cuda:
+        if x.dtype not in (torch.float16, torch.float32):
+            raise _lib.SdirtError(f"sdirt_dp_cost_volume is built for fp16 / fp32, got {x.dtype}")
         return _CostVolume.apply(x, y, d_max)
-    return _cost_volume_reference(x, y, d_max)          # CPU (host-logic tests only)
+    return _cost_volume_reference(x, y, d_max)          # CPU tensors: stock torch ops
 
 
 class BasicConv(nn.Module):

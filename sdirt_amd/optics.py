@@ -409,27 +409,30 @@ class Lensgroup:
 
     # --------------------------------------------------------------------- PSF
     def point_source_grid(self, depth, grid=9, normalized=True, quater=False, center=False):
-        """optics.py:816-861."""
+        """optics.py:816-861: [grid, grid, 3] field of point sources at one depth; entry [i, j] is
+        (x_j, y_i, depth) with x running left to right and y from the top edge down.  Edge samples
+        sit at +-0.98 of the normalised field (or at patch centres, +-(1 - 1/(2(grid-1))), with
+        center=True); quater keeps the upper-left ceil(grid/2) x ceil(grid/2) block."""
         if grid == 1:
-            x, y = torch.tensor([[0.0]]), torch.tensor([[0.0]])
             assert not quater, "Quater should be False when grid is 1."
-        elif center:
-            hb = 1 / 2 / (grid - 1)
-            x, y = torch.meshgrid(torch.linspace(-1 + hb, 1 - hb, grid),
-                                  torch.linspace(1 - hb, -1 + hb, grid), indexing="xy")
+            axis = torch.zeros(1)
         else:
-            x, y = torch.meshgrid(torch.linspace(-0.98, 0.98, grid),
-                                  torch.linspace(0.98, -0.98, grid), indexing="xy")
-        z = torch.full((grid, grid), float(depth))
-        ps = torch.stack([x, y, z], dim=-1)
+            edge = 1 - 1 / 2 / (grid - 1) if center else 0.98
+            axis = torch.linspace(-edge, edge, grid)
+        field = torch.empty(grid, grid, 3)
+        field[..., 0] = axis.view(1, grid)
+        field[..., 1] = -axis.view(grid, 1)
+        field[..., 2] = float(depth)
         if quater:
-            b = grid // 2 if grid % 2 == 0 else grid // 2 + 1
-            ps = ps[0:b, 0:b, :]
+            keep = (grid + 1) // 2
+            field = field[:keep, :keep]
         if not normalized:
+            # object-space millimetres; x takes the sensor HEIGHT here (the reference's convention in
+            # this function, optics.py:858-859 -- psf_diff uses the width for x)
             scale = self.calc_scale_pinhole(depth)
-            ps[..., 0] *= scale * self.sensor_size[0] / 2
-            ps[..., 1] *= scale * self.sensor_size[1] / 2
-        return ps
+            field[..., 0] *= scale * self.sensor_size[0] / 2
+            field[..., 1] *= scale * self.sensor_size[1] / 2
+        return field
 
     def _points_to_object(self, points):
         if not points.is_cuda:
@@ -774,40 +777,43 @@ class Lensgroup:
 
     @torch.no_grad()
     def calc_fov(self):
-        """optics.py:1203-1233: 100 rays from the sensor edge through the shrunk
-        exit pupil, traced backward; mean exit slope -> half diagonal FoV."""
-        M = 100
-        pupilz, pupilx = self.exit_pupil(shrink_pupil=True)
-        o1 = torch.tensor([self.r_last, 0, self.d_sensor]).repeat(M, 1).to(torch.float32)
-        x2 = torch.linspace(-pupilx, pupilx, M)
-        o2 = torch.stack((x2, torch.full_like(x2, 0), torch.full_like(x2, pupilz)), dim=-1)
-        ray = Ray(o1, o2 - o1, device=self.device)
-        ray, _, _ = self.trace(ray, forward=False)
-        d, ra = ray.d.cpu(), ray.ra.cpu()
-        tan_fov = d[..., 0] / d[..., 2]
-        fov = torch.atan(torch.sum(tan_fov * ra) / torch.sum(ra))
-        if torch.isnan(fov):
+        """optics.py:1203-1233: half diagonal field of view = atan of the validity-weighted mean slope
+        dx/dz with which a fan of 100 rays leaves the lens towards the object, the fan starting at the
+        sensor corner (r_last, 0, d_sensor) and aimed at points across the shrunk exit pupil."""
+        n_fan = 100
+        z_pupil, r_pupil = self.exit_pupil(shrink_pupil=True)
+        corner = torch.tensor([float(self.r_last), 0.0, float(self.d_sensor)])
+        aim = torch.zeros(n_fan, 3)
+        aim[:, 0] = torch.linspace(-r_pupil, r_pupil, n_fan)
+        aim[:, 2] = z_pupil
+        fan = Ray(corner.expand(n_fan, 3), aim - corner, device=self.device)
+        self.trace(fan, forward=False)
+        dx, dz, weight = (fan.soa[row, :n_fan].cpu() for row in (3, 5, 6))
+        half_fov = torch.atan((dx / dz * weight).sum() / weight.sum())
+        if torch.isnan(half_fov):
             print("computed fov is NaN, use 0.5 rad instead.")
             return 0.5
-        return fov.item()
+        return half_fov.item()
 
     @torch.no_grad()
     def refocus(self, depth=DEPTH):
-        """optics.py:1170-1196: move the sensor to the least-squares focus of green
-        rays from an on-axis point at `depth`."""
-        s0 = self.surfaces[0]
-        x2, y2 = self._pupil_samples(GEO_SPP, s0.r)              # surfaces.py:189-199
-        o = torch.stack((x2, y2, torch.full_like(x2, float(s0.d))), 1)
-        d = o - torch.tensor([0, 0, depth], dtype=torch.float32, device=self.device)
-        ray = Ray(o, d, wvln=DEFAULT_WAVE, device=self.device)
-        ray, _, _ = self.trace(ray, forward=True)
-        o_, d_, ra = ray.o.cpu(), ray.d.cpu(), ray.ra.cpu()
-        t = (d_[..., 0] * o_[..., 0] + d_[..., 1] * o_[..., 1]) / (d_[..., 0] ** 2 + d_[..., 1] ** 2)
-        t = t * ra
-        focus_d = (o_[..., 2] - d_[..., 2] * t).numpy()
-        focus_d = focus_d[ra.numpy() > 0]
-        focus_d = focus_d[~np.isnan(focus_d) & (focus_d > 0)]
-        d_sensor_new = float(np.mean(focus_d))
+        """optics.py:1170-1196: put the sensor where green rays from the on-axis point at `depth`
+        come closest to the axis.  GEO_SPP rays start on the first surface's aperture disc
+        (surfaces.py:189-199; two vectors of uniforms from the CPU generator); each traced ray
+        o + t d is nearest the axis at t = -(d.o)_xy / |d_xy|^2, i.e. at z = o_z - d_z (d.o)_xy /
+        |d_xy|^2; the new sensor position is the mean of those z over the live rays (z > 0)."""
+        front = self.surfaces[0]
+        x, y = self._pupil_samples(GEO_SPP, front.r)
+        start = torch.stack((x, y, torch.full_like(x, float(front.d))), dim=1)
+        source = torch.tensor([0.0, 0.0, float(depth)], device=self.device)
+        bundle = Ray(start, start - source, wvln=DEFAULT_WAVE, device=self.device)
+        self.trace(bundle, forward=True)
+        ox, oy, oz, dx, dy, dz, live = (row.cpu().numpy() for row in bundle.soa[:7, :x.shape[0]])
+        with np.errstate(divide="ignore", invalid="ignore"):
+            t_axis = (dx * ox + dy * oy) / (dx ** 2 + dy ** 2) * live
+            z_axis = oz - dz * t_axis
+        z_axis = z_axis[(live > 0) & ~np.isnan(z_axis) & (z_axis > 0)]
+        d_sensor_new = float(np.mean(z_axis))
         assert d_sensor_new > 0, "sensor position is negative."
         self.d_sensor = d_sensor_new
         self.post_computation()

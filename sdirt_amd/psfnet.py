@@ -120,6 +120,8 @@ class PSFNet(Lensgroup):
         ckpt = torch.load(net_path, map_location=self.device)
         own.update({k: v for k, v in ckpt.items() if k in own and own[k].shape == v.shape})
         self.psfnet.load_state_dict(own)
+        if hasattr(self.psfnet, "invalidate_packed"):
+            self.psfnet.invalidate_packed()
 
     def train_psfnet(self, iters=10000, bs=128, lr=1e-4, spp=2048, evaluate_every=1000,
                      result_dir="./results/temp", pipelined=None):
@@ -133,8 +135,9 @@ class PSFNet(Lensgroup):
         batch size (64 rows through 11 small GEMMs, forward and backward), so forward + backward
         are captured once in a hipGraph and replayed, the optimiser runs as one fused kernel
         without reading the inf-check back, and batch i+1 is ray-traced on a second stream
-        while step i runs.  Same draws from the RNGs in the same order, same arithmetic per
-        step; `pipelined=False` is the plain loop."""
+        while step i runs.  Same draws from the RNGs in the same order (prefetching stops at an
+        evaluation step, whose test-set draws come first, and resumes after it), same arithmetic
+        per step; `pipelined=False` is the plain loop."""
         psfnet = self.psfnet
         psfnet.train()
         on_gpu = torch.device(self.device).type == "cuda"
@@ -220,8 +223,17 @@ class PSFNet(Lensgroup):
             with torch.cuda.graph(graph):
                 static_loss = fwd_bwd()
             queue = [first]
-            while produced[0] < min(iters + 1, 3):
-                queue.append(produce())
+            evals_done = [0]
+
+            def refill():
+                # up to two batches ahead -- but never past an evaluation that has not run yet:
+                # evaluate(i) draws the test set from the same CPU generators BEFORE batch i+1 in
+                # the plain loop (and in the reference), so batch b waits for b // evaluate_every
+                # evaluations; the queue drains at those boundaries and fills up again after them
+                while (len(queue) < 3 and produced[0] < iters + 1
+                       and produced[0] // evaluate_every <= evals_done[0]):
+                    queue.append(produce())
+            refill()
             for i in range(iters + 1):
                 item = queue.pop(0)
                 inp, psf, ready = item if len(item) == 3 else consume(item)
@@ -229,14 +241,15 @@ class PSFNet(Lensgroup):
                 static_inp.copy_(inp); static_psf.copy_(psf)
                 inp.record_stream(main); psf.record_stream(main)
                 graph.replay()                                 # grads are rewritten, not accumulated
-                if produced[0] < iters + 1:
-                    queue.append(produce())
+                refill()
                 scaler.step(optim)
                 scaler.update()
                 sche.step()
                 losses.append(static_loss.detach().clone())
                 if (i + 1) % evaluate_every == 0:
                     evaluate(i)
+                    evals_done[0] += 1
+                    refill()
         torch.save(psfnet.state_dict(), os.path.join(result_dir, f"PSFNet_{self.model_name}.pkl"))
         return [float(v) for v in losses]
 

@@ -17,20 +17,25 @@ from . import _lib
 from .basics import dptr, stream_ptr
 
 
+@torch.no_grad()
 def initialize_weights(m):
-    """psfnet_arch.py:291-303."""
+    """psfnet_arch.py:291-303.  In-place initialisers on the parameters themselves (not on
+    `.data`): the writes bump the tensors' version counters, which the packed-weight cache of the
+    fused MLP kernel keys on."""
     if isinstance(m, nn.Conv2d):
-        nn.init.kaiming_uniform_(m.weight.data, nonlinearity="relu")
+        nn.init.kaiming_uniform_(m.weight, nonlinearity="relu")
         if m.bias is not None:
-            nn.init.constant_(m.bias.data, 0)
+            nn.init.constant_(m.bias, 0)
     elif isinstance(m, nn.BatchNorm2d):
-        nn.init.constant_(m.weight.data, 1)
-        nn.init.constant_(m.bias.data, 0)
+        nn.init.constant_(m.weight, 1)
+        nn.init.constant_(m.bias, 0)
     elif isinstance(m, nn.Linear):
-        nn.init.kaiming_uniform_(m.weight.data)
-        nn.init.constant_(m.bias.data, 0)
+        nn.init.kaiming_uniform_(m.weight)
+        nn.init.constant_(m.bias, 0)
     elif isinstance(m, nn.ConvTranspose2d):
         nn.init.xavier_uniform_(m.weight)
+    if hasattr(m, "invalidate_packed"):
+        m.invalidate_packed()
 
 
 def _autocast_for(t):
@@ -66,9 +71,16 @@ class MLP(nn.Module):
                 and all(w == 512 for w in widths[2:-1]) and 1 <= widths[-1] <= 512
                 and all(m.bias is not None for m in lin))
 
+    def invalidate_packed(self):
+        """Forget the packed fp16 weight fragments of the fused kernel.  Needed only after writing
+        parameters THROUGH `.data` (which does not bump their version counters): optimiser steps,
+        load_state_dict, in-place initialisers and .to() are noticed by themselves."""
+        self._pack_cache = None
+
     def _packed(self):
         """Weights as fp16 MFMA fragments + fp32 biases in one device buffer, rebuilt whenever a
-        parameter was written (optimiser step, load_state_dict) or moved."""
+        parameter was written (optimiser step, load_state_dict, in-place init) or moved; see
+        invalidate_packed() for writes through `.data`."""
         lin = self._linears()
         params = [p for m in lin for p in (m.weight, m.bias)]
         key = tuple((p.data_ptr(), p._version) for p in params)

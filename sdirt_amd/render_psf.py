@@ -66,34 +66,57 @@ def psfnet_render(input, raw_l, raw_r, kernel_size):
     return rl, rr
 
 
+def local_psf_render_high_res(input, psf, patch_size=[320, 480], kernel_size=11):
+    """render_psf.py:191-208: the image cut into patch_size tiles, every tile rendered on its own
+    by local_psf_render -- so each tile is replicate-padded at ITS OWN border.  Returns (rl, rr)
+    [N,C,H,W].  (The reference's version assigns local_psf_render's (left, right) tuple into one
+    tensor and raises TypeError; this is what its loop computes with both halves kept, pinned by
+    fixture F18 = the reference's local_psf_render applied tile by tile.)"""
+    _, _, height, width = input.shape
+    rl, rr = torch.zeros_like(input), torch.zeros_like(input)
+    for top in range(0, height, patch_size[0]):
+        for left in range(0, width, patch_size[1]):
+            rows = slice(top, min(top + patch_size[0], height))
+            cols = slice(left, min(left + patch_size[1], width))
+            rl[:, :, rows, cols], rr[:, :, rows, cols] = local_psf_render(
+                input[:, :, rows, cols], psf[:, rows, cols], kernel_size=kernel_size)
+    return rl, rr
+
+
+def _depthwise_convolution(padded, kernels):
+    """True (flipped-kernel) 2-D convolution of every channel with its own [ks, ks] kernel, no
+    further padding: stock depthwise conv2d (MIOpen), which correlates, on the flipped kernels."""
+    flipped = kernels.flip(-2, -1).unsqueeze(1)                     # [C, 1, ks, ks]
+    return torch.nn.functional.conv2d(padded, flipped, groups=padded.shape[1])
+
+
 def render_psf(img, psf):
-    """render_psf.py:12-28: one PSF for the whole image, [B,C,H,W] x [C,ks,ks].  A plain
-    grouped convolution with reflect padding: dense conv work that stock PyTorch-ROCm
-    (MIOpen) already covers -- kept for API completeness, not a custom kernel."""
-    _, ks, _ = psf.shape
-    padding = int(ks / 2)
-    k = torch.flip(psf, [1, 2]).unsqueeze(1)
-    img_pad = torch.nn.functional.pad(img, (padding, padding, padding, padding), mode="reflect")
-    return torch.nn.functional.conv2d(img_pad, k, groups=img.shape[1], padding=0, bias=None)
+    """render_psf.py:12-28: one PSF per channel for the whole image, [B,C,H,W] * [C,ks,ks], reflect
+    padding.  Dense depthwise convolution: library work, no custom kernel."""
+    half = psf.shape[-1] // 2
+    return _depthwise_convolution(torch.nn.functional.pad(img, (half,) * 4, mode="reflect"), psf)
 
 
 def render_psf_map(img, psf_map, grid):
-    """render_psf.py:31-73: a grid x grid mosaic of PSFs, one per image patch."""
+    """render_psf.py:31-73: psf_map [C, grid*ks, grid*ks] holds one PSF per image tile (tile (i, j)
+    covers rows int(i/grid*H) .. int((i+1)/grid*H) and the matching columns); every tile is
+    convolved with its PSF, reading across the tile border into the (reflect-padded) image."""
     assert img.dim() == 4, "Input image should be [B, C, H, W]"
-    Cpsf, Hpsf, Wpsf = psf_map.shape
-    assert Hpsf % grid == 0 and Wpsf % grid == 0, "PSF map size should be divisible by grid"
-    ks = int(Hpsf / grid)
+    channels, map_h, map_w = psf_map.shape
+    assert map_h % grid == 0 and map_w % grid == 0, "PSF map size should be divisible by grid"
+    ks = map_h // grid
     assert ks % 2 == 1, "PSF kernel size should be odd"
-    B, C, H, W = img.shape
-    assert C == Cpsf, "PSF map should have the same channel as image"
-    pad = int((ks - 1) / 2)
-    img_pad = torch.nn.functional.pad(img, (pad, pad, pad, pad), mode="reflect")
+    _, c, height, width = img.shape
+    assert c == channels, "PSF map should have the same channel as image"
+    half = (ks - 1) // 2
+    padded = torch.nn.functional.pad(img, (half,) * 4, mode="reflect")
+    tiles = psf_map.view(channels, grid, ks, grid, ks).permute(1, 3, 0, 2, 4)    # [grid, grid, C, ks, ks]
+    row_edge = [int(i / grid * height) for i in range(grid + 1)]
+    col_edge = [int(j / grid * width) for j in range(grid + 1)]
     out = torch.zeros_like(img)
     for i in range(grid):
         for j in range(grid):
-            k = torch.flip(psf_map[:, i * ks:(i + 1) * ks, j * ks:(j + 1) * ks], [1, 2]).unsqueeze(1)
-            h0, w0 = int(i / grid * H), int(j / grid * W)
-            h1, w1 = int((i + 1) / grid * H), int((j + 1) / grid * W)
-            patch = img_pad[:, :, h0:h1 + 2 * pad, w0:w1 + 2 * pad]
-            out[:, :, h0:h1, w0:w1] = torch.nn.functional.conv2d(patch, k, groups=C, padding="valid")
+            window = padded[:, :, row_edge[i]:row_edge[i + 1] + 2 * half, col_edge[j]:col_edge[j + 1] + 2 * half]
+            out[:, :, row_edge[i]:row_edge[i + 1], col_edge[j]:col_edge[j + 1]] = \
+                _depthwise_convolution(window, tiles[i, j])
     return out

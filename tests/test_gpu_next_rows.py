@@ -42,6 +42,23 @@ def test_local_psf_render_against_reference():
     assert torch.allclose(rl, exp.half().float(), atol=0)
 
 
+def test_local_psf_render_high_res_against_reference_tiles():
+    """render_psf.py:191-208 (fixture F18: the reference's local_psf_render applied tile by tile, which
+    is what the reference's loop computes; its own function raises on the (left, right) tuple)."""
+    from sdirt_amd import local_psf_render, local_psf_render_high_res
+    g = load_golden("f18_render_high_res")
+    img, psf, ks = t(g["img"]), t(g["psf"]), int(g["ks"])
+    rl, rr = local_psf_render_high_res(img, psf, patch_size=[int(v) for v in g["patch"]], kernel_size=ks)
+    assert rl.shape == img.shape
+    assert np.abs(rl.cpu().numpy() - g["left"]).max() <= 5e-4 and np.abs(rr.cpu().numpy() - g["right"]).max() <= 5e-4
+    assert np.mean(rl.cpu().numpy() == g["left"]) > 0.9
+    # one tile covering the image is the plain renderer; interior tiles differ from it (own padding)
+    whole_l, _ = local_psf_render(img, psf, kernel_size=ks)
+    one_l, _ = local_psf_render_high_res(img, psf, patch_size=[64, 64], kernel_size=ks)
+    assert torch.equal(whole_l, one_l)
+    assert not torch.equal(whole_l, rl)
+
+
 def test_render_production_size_runs_and_conserves_energy():
     """512x768, ks 21 (config 5 of BASELINE.json): normalised kernels keep a flat image flat."""
     from sdirt_amd import local_psf_render_fast
@@ -188,10 +205,14 @@ def test_pipelined_training_loop_equals_the_plain_loop(tmp_path):
         m.refocus(-1000 + m.d_sensor)
         m.psfnet = MLP(3, 121, hidden_features=64, hidden_layers=2).to(DEV)
         m.psfnet.apply(initialize_weights)
-        losses = m.train_psfnet(iters=30, bs=32, lr=1e-3, spp=512, evaluate_every=10 ** 6,
+        # evaluations (which draw the test set from the same CPU generators) fall INSIDE the run:
+        # the prefetcher must not draw batch i+1 before evaluate(i) has drawn
+        losses = m.train_psfnet(iters=30, bs=32, lr=1e-3, spp=512, evaluate_every=7,
                                 result_dir=str(tmp_path), pipelined=pipelined)
-        runs.append((np.asarray(losses), {k: v.clone() for k, v in m.psfnet.state_dict().items()}))
-    (la, wa), (lb, wb) = runs
+        runs.append((np.asarray(losses), {k: v.clone() for k, v in m.psfnet.state_dict().items()},
+                     float(torch.rand(1)), float(np.random.rand())))
+    (la, wa, ta, na), (lb, wb, tb, nb) = runs
+    assert ta == tb and na == nb                             # both generators end in the same state
     assert la.shape == lb.shape == (31,)
     assert la[0] == pytest.approx(lb[0], rel=1e-3)           # same first batch, same weights
     np.testing.assert_allclose(la, lb, rtol=0.05)            # fp16 GEMMs + fused vs foreach AdamW

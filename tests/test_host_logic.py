@@ -68,6 +68,14 @@ def test_point_source_grid_and_scale():
     gc = lens.point_source_grid(depth=-1000.0, grid=5, center=True)
     assert float(gc[0, 0, 0]) == pytest.approx(-1 + 1 / 8)
     assert lens.point_source_grid(depth=-5.0, grid=1).shape == (1, 1, 3)
+    # every option combination, bit for bit against the reference (fixture F19)
+    from conftest import load_golden
+    ref = load_golden("f19_point_source_grid")
+    for key in ref.files:
+        grid, center, quater, normalized = (int(v[1:]) for v in key.split("_"))
+        mine = lens.point_source_grid(depth=-1234.5, grid=grid, normalized=bool(normalized),
+                                      quater=bool(quater), center=bool(center))
+        assert mine.shape == ref[key].shape and np.array_equal(mine.numpy(), ref[key]), key
     assert lens.calc_scale_pinhole(-1000.0) == pytest.approx(1000 * np.tan(st["hfov"]) / st["r_last"])
     assert lens.calc_efl() == pytest.approx(st["foclen"], rel=1e-12)
 
@@ -258,6 +266,10 @@ def test_global_psf_convolution_matches_reference_fixture():
     # a 1x1 "map" is the same thing
     out2 = render_psf_map(torch.tensor(g["img"]), torch.tensor(g["psf_global"]), 1)
     assert np.abs(out2.numpy() - g["global"]).max() < 1e-6
+    # a 2x2 map of the same PSF: identical away from nothing -- tiles read across their borders
+    tiled = torch.tensor(g["psf_global"]).repeat(1, 2, 2)
+    out3 = render_psf_map(torch.tensor(g["img"]), tiled, 2)
+    assert np.abs(out3.numpy() - g["global"]).max() < 1e-6
 
 
 def test_host_pupil_mapping_expressions_match_the_reference():
