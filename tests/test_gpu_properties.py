@@ -447,3 +447,18 @@ def test_random_dual_pixel_parameters_splat_against_the_oracle(oracle, seed):
     assert scale > 0
     assert np.abs(lg.cpu().numpy() - lg0).max() <= 3e-6 * scale, (h, f, w, r)
     assert np.abs(rg.cpu().numpy() - rg0).max() <= 3e-6 * scale, (h, f, w, r)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs")
+def test_lens_on_another_gpu_than_the_current_device():
+    """Every launch runs on the GPU its stream belongs to (_lib.StreamArg), whatever the caller's
+    current device is: a lens on cuda:1 driven while cuda:0 is current gives cuda:0's results."""
+    torch.cuda.set_device(0)
+    g = load_golden("f8_rf50_mini_c2")
+    kw = dict(ks=33, spp=512, pupil_xy=(g["pupil_x2"][:512], g["pupil_y2"][:512]),
+              center_pupil_xy=(g["pupil_xc"], g["pupil_yc"]))
+    L0, R0 = make_lens("rf50mm", "cuda:0").psf_lr(torch.tensor(g["points"]), **kw)
+    lens1 = make_lens("rf50mm", "cuda:1")
+    L1, R1 = lens1.psf_lr(torch.tensor(g["points"]), **kw)
+    assert torch.cuda.current_device() == 0 and L1.device.index == 1
+    assert torch.allclose(L0.cpu(), L1.cpu(), atol=2e-6) and torch.allclose(R0.cpu(), R1.cpu(), atol=2e-6)
