@@ -486,6 +486,9 @@ struct LensSet {
 struct TripSet {
     TripTable t[SDIRT_MAX_WAVELENGTHS];
 };
+#ifdef SDIRT_DBG_CLOCK
+__device__ unsigned long long g_dbg_clock[4];
+#endif
 template <bool HAVE_R, bool BIG, class HotMath, bool CENTER>
 __global__ void __launch_bounds__(kFused, BIG ? 4 : 8)
 k_psf_lr(SplatBlock sb /* kernarg offset 0 */, TripSet trips /* 64 */, TripSet trips_c /* 64 + 64 W */,
@@ -518,6 +521,9 @@ k_psf_lr(SplatBlock sb /* kernarg offset 0 */, TripSet trips /* 64 */, TripSet t
         center += (int64_t)w * N * 2;
     }
     const float px = po[3 * n], py = po[3 * n + 1], pzo = po[3 * n + 2];
+#ifdef SDIRT_DBG_CLOCK
+    const unsigned long long dbg_t0 = __builtin_readcyclecounter(), dbg_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
     if (CENTER) {
         // ---- chief-ray centre of this point (same arithmetic and reduction order as
@@ -645,7 +651,20 @@ k_psf_lr(SplatBlock sb /* kernarg offset 0 */, TripSet trips /* 64 */, TripSet t
     }
     if (conv_mask && (int)threadIdx.x < K && lds_mask[threadIdx.x])
         atomicOr(&conv_mask[threadIdx.x], lds_mask[threadIdx.x]);
+#ifdef SDIRT_DBG_CLOCK
+    if (threadIdx.x == 0 && blockIdx.x == gridDim.x / 2) {      // a workgroup from the middle of the launch
+        g_dbg_clock[0] = __builtin_readcyclecounter() - dbg_t0;
+        g_dbg_clock[1] = __builtin_amdgcn_s_memrealtime() - dbg_r0;
+    }
+#endif
 }
+
+#ifdef SDIRT_DBG_CLOCK
+extern "C" int sdirt_debug_clock(unsigned long long* out)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg_clock), sizeof(unsigned long long) * 4) == hipSuccess ? 0 : -3;
+}
+#endif
 
 // ---------------------------------------------------------------------------
 // per-pixel PSF convolution (render_psf.py:76-188)

@@ -27,6 +27,9 @@ def main():
     ap.add_argument("--ks", type=int, default=65)
     ap.add_argument("--lens", default="rf50mm")
     ap.add_argument("--flags", type=int, default=0, help="4 = SDIRT_PSF_STRICT_IEEE")
+    ap.add_argument("--trips", type=int, default=None,
+                    help="this many Newton trips on EVERY curved surface of both passes (for the per-trip "
+                         "cost: time two values and divide the difference)")
     args = ap.parse_args()
     from conftest import load_state, make_lens
     from sdirt_amd import _lib
@@ -49,6 +52,8 @@ def main():
         tm, tc = [10, 3, 4, 3, 4, 0, 3, 3, 4, 4, 2, 3], [10, 3, 3, 3, 3, 0, 3, 3, 3, 3, 2, 3]
     else:
         tm = [10 if i == 0 else (0 if i == 7 else 3) for i in range(K)]; tc = tm
+    if args.trips is not None:
+        tm = tc = [args.trips if s.kind != 0 else 0 for s in lens.surfaces]
     trips, tripc = (C.c_int32 * K)(*tm), (C.c_int32 * K)(*tc)
     N, ks = pts.shape[0], args.ks
     cen = torch.empty((N, 2), device=dev)

@@ -100,6 +100,18 @@ __global__ void __launch_bounds__(256) k_inst(int reps, unsigned long long* out,
                          : "+v"(a0), "+v"(a1) : "v"(c0), "v"(c1));
         } else if (KIND == 19) {  // s_nop 0 x32
             asm volatile(REP32("s_nop 0\n\t"));
+        } else if (KIND == 20) {  // v_fma_f32, three sources in three different VGPR banks (v41, v42, v43)
+            asm volatile("v_mov_b32 v41, %0\n\tv_mov_b32 v42, %1\n\tv_mov_b32 v43, %2\n\t"
+                         REP32("v_fma_f32 v41, v41, v42, v43\n\t") "v_mov_b32 %0, v41"
+                         : "+v"(a0) : "v"(c0), "v"(c1) : "v41", "v42", "v43");
+        } else if (KIND == 21) {  // v_fma_f32, three sources in the SAME bank (v40, v44, v48)
+            asm volatile("v_mov_b32 v40, %0\n\tv_mov_b32 v44, %1\n\tv_mov_b32 v48, %2\n\t"
+                         REP32("v_fma_f32 v40, v40, v44, v48\n\t") "v_mov_b32 %0, v40"
+                         : "+v"(a0) : "v"(c0), "v"(c1) : "v40", "v44", "v48");
+        } else if (KIND == 22) {  // v_mul_f32 (VOP2), two sources in the same bank (v40, v44)
+            asm volatile("v_mov_b32 v40, %0\n\tv_mov_b32 v44, %1\n\t"
+                         REP32("v_mul_f32 v40, v40, v44\n\t") "v_mov_b32 %0, v40"
+                         : "+v"(a0) : "v"(c0) : "v40", "v44");
         }
     }
     const unsigned long long t1 = __builtin_readcyclecounter();
@@ -127,6 +139,7 @@ __global__ void __launch_bounds__(256) k_newton(FakeSurf fs, int outer, int trip
     r.ra = 1.0f; r.ob = 1.0f;
     float acc = 0.0f;
     const unsigned long long t0 = __builtin_readcyclecounter();
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
     for (int i = 0; i < outer; ++i) {
         float t;
         uint32_t mask;
@@ -137,6 +150,8 @@ __global__ void __launch_bounds__(256) k_newton(FakeSurf fs, int outer, int trip
     }
     const unsigned long long t1 = __builtin_readcyclecounter();
     if ((threadIdx.x & 63) == 0) out[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
+    if (threadIdx.x == 0 && blockIdx.x == gridDim.x / 2)            // shader clock seen by one wave: ticks per 10 ns
+        out[gridDim.x * 4] = (t1 - t0) * 100ull / (__builtin_amdgcn_s_memrealtime() - r0);
     sink[blockIdx.x * 256 + threadIdx.x] = acc;
 }
 
@@ -158,7 +173,7 @@ int main()
     unsigned long long* d_out;
     float* d_sink;
     const int maxb = 256 * 8;
-    CHECK(hipMalloc(&d_out, sizeof(unsigned long long) * maxb * 4));
+    CHECK(hipMalloc(&d_out, sizeof(unsigned long long) * (maxb * 4 + 1)));
     CHECK(hipMalloc(&d_sink, sizeof(float) * maxb * 256));
     std::vector<unsigned long long> h(maxb * 4);
     const char* names[] = {"v_fma_f32 dep", "v_fma_f32 ind8", "v_mul_f32 dep", "v_rcp_f32 dep", "v_rcp_f32 ind8",
@@ -166,13 +181,14 @@ int main()
                            "v_fma_f32 sgpr operand dep", "s_add_u32 dep (SALU)", "v_rsq_f32 dep",
                            "v_fma dep + s_add 1:1 (pair)", "v_mul_f32 inline const dep", "v_add_f32 literal dep",
                            "v_mul_f64 dep", "v_cndmask sgpr-pair mask dep", "v_cmp -> sgpr pair", "v_cmp -> vcc",
-                           "v_fma_f32 two chains (ILP 2)", "s_nop 0"};
-    const int per_block[] = {32, 32, 32, 32, 32, 16, 32, 32, 32, 32, 32, 16, 32, 32, 32, 32, 32, 32, 32, 32};
+                           "v_fma_f32 two chains (ILP 2)", "s_nop 0", "v_fma_f32 srcs in 3 banks (v41,v42,v43)",
+                           "v_fma_f32 srcs in 1 bank (v40,v44,v48)", "v_mul_f32 srcs in 1 bank (v40,v44)"};
+    const int per_block[] = {32, 32, 32, 32, 32, 16, 32, 32, 32, 32, 32, 16, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32};
     printf("# part 1: cycles per instruction as ONE wave sees them | cycles per instruction per SIMD (= that / W),\n"
            "#         W waves on every SIMD (256-thread workgroups, 256 * W of them)\n");
     printf("%-40s %11s %11s %11s %11s %11s\n", "kind", "W=1", "W=2", "W=4", "W=6", "W=8");
     const int reps = 2000;
-    for (int kind = 0; kind < 20; ++kind) {
+    for (int kind = 0; kind < 23; ++kind) {
         printf("%-40s", names[kind]);
         for (int W : {1, 2, 4, 6, 8}) {
             const int grid = 256 * W;
@@ -181,7 +197,7 @@ int main()
                 switch (kind) {
                     LAUNCH(0) LAUNCH(1) LAUNCH(2) LAUNCH(3) LAUNCH(4) LAUNCH(5) LAUNCH(6) LAUNCH(7) LAUNCH(8)
                     LAUNCH(9) LAUNCH(10) LAUNCH(11) LAUNCH(12) LAUNCH(13) LAUNCH(14) LAUNCH(15) LAUNCH(16)
-                    LAUNCH(17) LAUNCH(18) LAUNCH(19)
+                    LAUNCH(17) LAUNCH(18) LAUNCH(19) LAUNCH(20) LAUNCH(21) LAUNCH(22)
                 }
                 CHECK(hipDeviceSynchronize());
             }
@@ -204,19 +220,45 @@ int main()
     printf("\n# part 2: newton_k<M, k > -1, no polynomial>: cycles per trip (10-trip calls, the regain evaluation\n"
            "#         counted as an 11th trip): one wave's view | per SIMD\n");
     printf("%-28s %12s %12s %12s %12s %12s\n", "math", "W=1", "W=2", "W=4", "W=6", "W=8");
+    float wall_ms[2][5];
+    double clock_mhz[2][5];
     for (int variant = 0; variant < 2; ++variant) {
+        int wi = 0;
         printf("%-28s", variant == 0 ? "Lean" : "Ieee");
         for (int W : {1, 2, 4, 6, 8}) {
             const int grid = 256 * W, outer = 200, trips = 10;
+            hipEvent_t e0, e1;
+            CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+            float ms = 0.f;
             for (int pass = 0; pass < 2; ++pass) {
+                CHECK(hipEventRecord(e0));
                 if (variant == 0) k_newton<Lean, 0><<<grid, 256>>>(fs, outer, trips, d_out, d_sink);
                 else k_newton<Ieee, 0><<<grid, 256>>>(fs, outer, trips, d_out, d_sink);
+                CHECK(hipEventRecord(e1));
                 CHECK(hipDeviceSynchronize());
+                CHECK(hipEventElapsedTime(&ms, e0, e1));
             }
+            wall_ms[variant][wi++] = ms;
+            h.resize(grid * 4 + 1);
+            CHECK(hipMemcpy(h.data(), d_out, sizeof(unsigned long long) * (grid * 4 + 1), hipMemcpyDeviceToHost));
+            clock_mhz[variant][wi - 1] = (double)h[grid * 4];
             h.resize(grid * 4);
-            CHECK(hipMemcpy(h.data(), d_out, sizeof(unsigned long long) * grid * 4, hipMemcpyDeviceToHost));
             const double cyc = median_cycles(h) / ((double)outer * (trips + 1));
             printf(" %6.0f|%5.0f", cyc, cyc / W);
+        }
+        printf("\n");
+    }
+    printf("%-28s", "Lean: shader clock, MHz");
+    for (int i = 0; i < 5; ++i) printf(" %12.0f", clock_mhz[0][i]);
+    printf("   (s_memtime ticks per s_memrealtime tick x 100 MHz: the chip lowers its clock under this load)\n");
+    // the same launches by the wall clock: kernel time / trips per wave = ns per trip per wave; x 2.4 GHz
+    // = what the loop costs in nominal-clock cycles, i.e. in time (one trip at W = 8: this / 2.4 ns)
+    for (int variant = 0; variant < 2; ++variant) {
+        printf("%-28s", variant == 0 ? "Lean, wall clock x 2.4 GHz" : "Ieee, wall clock x 2.4 GHz");
+        const int Ws[] = {1, 2, 4, 6, 8};
+        for (int i = 0; i < 5; ++i) {
+            const double cyc = wall_ms[variant][i] * 1e-3 * 2.4e9 / (200.0 * 11);
+            printf(" %6.0f|%5.0f", cyc, cyc / Ws[i]);
         }
         printf("\n");
     }
