@@ -677,12 +677,22 @@ __device__ __forceinline__ float round_half(float v) { return (float)(_Float16)v
 // has 22 significant bits and fits fp32 -- and the two widening accumulations.
 typedef _Float16 hpair __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ hpair half_pair(float lo, float hi) { return hpair{(_Float16)lo, (_Float16)hi}; }
+// acc += float(low / high half of the packed pair p), one v_fma_mix_f32 each (the compiler
+// splits fma(x, 1, acc) into a conversion and an addition)
+__device__ __forceinline__ void acc_halves(hpair p, float& accl, float& accr)
+{
+    asm("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(accl) : "v"(p));
+    asm("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(accr) : "v"(p));
+}
 __device__ __forceinline__ void mul_acc_half(float v, hpair w, float& accl, float& accr)
 {
     const _Float16 vh = (_Float16)v;
-    const hpair p = hpair{vh, vh} * w;
-    accl = __builtin_fmaf((float)p[0], 1.0f, accl);
-    accr = __builtin_fmaf((float)p[1], 1.0f, accr);
+    acc_halves(hpair{vh, vh} * w, accl, accr);
+}
+// the same with the image value already rounded to fp16 (the pipelined kernel keeps its patch so)
+__device__ __forceinline__ void mul_acc_half(_Float16 vh, hpair w, float& accl, float& accr)
+{
+    acc_halves(hpair{vh, vh} * w, accl, accr);
 }
 
 // One WAVE per output pixel: the 64 lanes stride over the 2*ks*ks kernel taps of that
@@ -772,38 +782,53 @@ __device__ __forceinline__ float wave_sum(float v)
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
-// LDS-tiled variant: a workgroup streams the [L | R] kernels of PIX consecutive pixels (one
-// contiguous, 16-byte aligned run of PIX*2*ks*ks floats) into LDS with 16-B-per-lane loads --
-// every PSF byte is read from HBM exactly once, at full coalescing width -- then each wave
-// convolves PIX/4 of those pixels reading its weights from LDS.  Several workgroups per CU
-// overlap one group's staging with another's arithmetic.
+// LDS-tiled renderer for any kernel size up to 64 and 1 / 3 / 4 channels: a workgroup streams the
+// [L | R] kernels of PIX consecutive pixels of one image row (one contiguous run of PIX*2*ks*ks
+// floats) into LDS with 16-byte loads -- every PSF byte is read from HBM exactly once, at full
+// coalescing width -- then each wave convolves PIX/4 of those pixels reading its weights from LDS.
+// blockIdx.y is an image row (b * H + y), blockIdx.x strides over that row's pixel groups.
+// Round 1's kernel walked a flat pixel index and paid a 64-bit division per pixel to recover
+// (b, y, x) -- a software sequence of ~150 scalar and vector instructions, a third of its
+// instruction stream.  Here (b, y) cost one 32-bit division per workgroup, the tap geometry of a
+// lane (its row / column inside the kernel, its flipped offsets, its LDS index) is computed once,
+// and the per-tap work is: one clamp of the row coordinate, one address, C image gathers, two LDS
+// reads, the fp16 arithmetic.  The group's [L | R] kernels are one contiguous run of the PSF
+// tensor; it is copied with 16-byte loads whatever its alignment (the LDS image is shifted by the
+// run's misalignment so that source and destination stay congruent modulo 16 bytes).
 template <int C, bool HALF, int PIX, int KS>
 __global__ void __launch_bounds__(kBlock)
-k_local_psf_render_tiled(const float* __restrict__ img, const float* __restrict__ psf, int B, int H,
-                         int W, int ks_rt, float* __restrict__ outl, float* __restrict__ outr)
+k_local_psf_render_rows(const float* __restrict__ img, const float* __restrict__ psf, int H, int W,
+                        int ks_rt, float* __restrict__ outl, float* __restrict__ outr)
 {
-    // KS > 0: kernel size fixed at compile time -> the tap loop unrolls and all image gathers
-    // of a pixel are in flight together; KS == 0: run-time size
-    const int ks = KS > 0 ? KS : ks_rt;
-    extern __shared__ __attribute__((aligned(16))) float wts[];     // [PIX][2][ks*ks]
-    const int64_t HW = (int64_t)H * W;
-    const int64_t P = (int64_t)B * HW;
+    const int ks = KS > 0 ? KS : ks_rt;                              // ks <= 64 on this path
+    extern __shared__ __attribute__((aligned(16))) float wts[];     // 4 + [PIX][2][ks*ks]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pad = (ks - 1) / 2, kk = ks * ks;
-    const int rows_per_iter = ks <= 64 ? 64 / ks : 1;
-    const int lane_row = ks <= 64 ? lane / ks : 0;
-    const int lane_col = ks <= 64 ? lane - lane_row * ks : lane;
-    const int64_t ngroups = (P + PIX - 1) / PIX;
-    for (int64_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
-        const int64_t p0 = g * PIX;
-        const int npix = (int)min((int64_t)PIX, P - p0);
-        const int nfl = npix * 2 * kk;                                // floats in this group
-        const float* src = psf + p0 * 2 * kk;                         // 16-B aligned (PIX even)
-        const int nf4 = nfl >> 2;
-        typedef float fl4 __attribute__((ext_vector_type(4)));
-        const fl4* src4 = reinterpret_cast<const fl4*>(src);
-        fl4* dst4 = reinterpret_cast<fl4*>(wts);
-        // keep STAGE_U 16-byte loads per thread in flight before the first LDS write
+    const int row = blockIdx.y;
+    const int b = row / H, y = row - b * H;
+    const int HW = H * W;
+    const float* __restrict__ img_b = img + (int64_t)b * C * HW;
+    // this lane's tap: lanes tile the kernel as (rows_per_iter x ks)
+    const int rows_per_iter = 64 / ks;
+    const int lane_row = lane / ks, lane_col = lane - lane_row * ks;
+    const bool lane_on = lane_row < rows_per_iter;
+    const int dx = (ks - 1 - lane_col) - pad;                        // flipped tap -> neighbour offset (render_psf.py:138)
+    const int dy0 = (ks - 1 - lane_row) - pad;
+    const int f0 = lane_row * ks + lane_col;
+    const int groups = (W + PIX - 1) / PIX;
+    typedef float fl4 __attribute__((ext_vector_type(4)));
+    for (int gx = blockIdx.x; gx < groups; gx += gridDim.x) {
+        const int x0 = gx * PIX;
+        const int npix = min(PIX, W - x0);
+        const int64_t first = ((int64_t)row * W + x0) * 2 * kk;       // first float of the run
+        const int nfl = npix * 2 * kk;
+        const int sh = (int)(first & 3);                              // misalignment, in floats
+        const float* src = psf + first;
+        float* dst = wts + sh;
+        const int head = min((4 - sh) & 3, nfl);
+        const int nf4 = (nfl - head) >> 2;
+        const fl4* src4 = reinterpret_cast<const fl4*>(src + head);
+        fl4* dst4 = reinterpret_cast<fl4*>(dst + head);
         constexpr int STAGE_U = 8;
         for (int base = threadIdx.x; base < nf4; base += kBlock * STAGE_U) {
             fl4 v[STAGE_U];
@@ -814,37 +839,60 @@ k_local_psf_render_tiled(const float* __restrict__ img, const float* __restrict_
             for (int u = 0; u < STAGE_U; ++u)
                 if (base + u * kBlock < nf4) dst4[base + u * kBlock] = v[u];
         }
-        for (int i = (nf4 << 2) + threadIdx.x; i < nfl; i += blockDim.x) wts[i] = src[i];
+        if ((int)threadIdx.x < head) dst[threadIdx.x] = src[threadIdx.x];
+        for (int i = head + (nf4 << 2) + threadIdx.x; i < nfl; i += blockDim.x) dst[i] = src[i];
         __syncthreads();
         for (int q = wave; q < npix; q += kBlock / 64) {
-            const int64_t p = p0 + q;
-            const int b = (int)(p / HW);
-            const int64_t r = p - (int64_t)b * HW;
-            const int y = (int)(r / W), x = (int)(r - (int64_t)y * W);
-            const float* kl = wts + q * 2 * kk;
-            const float* kr = kl + kk;
+            const int x = x0 + q;
+            const int xx = min(max(x + dx, 0), W - 1);
+            const float* kl = dst + q * 2 * kk + f0;
             float accl[C], accr[C];
 #pragma unroll
             for (int c = 0; c < C; ++c) { accl[c] = 0.0f; accr[c] = 0.0f; }
-#pragma unroll KS > 0 ? 8 : 1
-            for (int i0 = 0; i0 < ks; i0 += rows_per_iter) {
-                for (int j0 = 0; j0 < ks; j0 += 64) {
-                    const int fi = i0 + lane_row, fj = j0 + lane_col;
-                    if (lane_row < rows_per_iter && fi < ks && fj < ks) {
-                        const int f = fi * ks + fj;
-                        const int yy = min(max(y + (ks - 1 - fi) - pad, 0), H - 1);
-                        const int xx = min(max(x + (ks - 1 - fj) - pad, 0), W - 1);
-                        const float wl = kl[f], wr = kr[f];
+            if (KS > 0) {
+                // compile-time kernel size: ALL image gathers of the pixel are issued before the first
+                // one is used (the kernel is bound by the latency of these L2 hits, not by their count)
+                constexpr int NI = KS > 0 ? (KS + (64 / (KS > 0 ? KS : 1)) - 1) / (64 / (KS > 0 ? KS : 1)) : 1;
+                float v[NI][C];
+#pragma unroll
+                for (int it = 0; it < NI; ++it) {
+                    const int i0 = it * rows_per_iter;
+                    const int yy = min(max(y + dy0 - i0, 0), H - 1);
+                    const int off = yy * W + xx;
+#pragma unroll
+                    for (int c = 0; c < C; ++c) v[it][c] = img_b[c * HW + off];
+                }
+#pragma unroll
+                for (int it = 0; it < NI; ++it) {
+                    const int i0 = it * rows_per_iter;
+                    const bool on = lane_on && i0 + lane_row < ks;
+                    const float wl = on ? kl[i0 * ks] : 0.0f, wr = on ? kl[kk + i0 * ks] : 0.0f;
+                    const hpair wpair = half_pair(wl, wr);
+#pragma unroll
+                    for (int c = 0; c < C; ++c) {
+                        if (HALF) {
+                            mul_acc_half(v[it][c], wpair, accl[c], accr[c]);
+                        } else {
+                            accl[c] += v[it][c] * wl;
+                            accr[c] += v[it][c] * wr;
+                        }
+                    }
+                }
+            } else {
+                for (int i0 = 0; i0 < ks; i0 += rows_per_iter) {
+                    if (lane_on && i0 + lane_row < ks) {
+                        const int yy = min(max(y + dy0 - i0, 0), H - 1);
+                        const float wl = kl[i0 * ks], wr = kl[kk + i0 * ks];
                         const hpair wpair = half_pair(wl, wr);
-                        const float* px = img + ((int64_t)b * C * H + yy) * W + xx;
+                        const int off = yy * W + xx;
 #pragma unroll
                         for (int c = 0; c < C; ++c) {
-                            float v = px[(int64_t)c * HW];
+                            const float vv = img_b[c * HW + off];
                             if (HALF) {
-                                mul_acc_half(v, wpair, accl[c], accr[c]);
+                                mul_acc_half(vv, wpair, accl[c], accr[c]);
                             } else {
-                                accl[c] += v * wl;
-                                accr[c] += v * wr;
+                                accl[c] += vv * wl;
+                                accr[c] += vv * wr;
                             }
                         }
                     }
@@ -862,6 +910,191 @@ k_local_psf_render_tiled(const float* __restrict__ img, const float* __restrict_
         }
         __syncthreads();
     }
+}
+
+// Software-pipelined renderer for a compile-time kernel size (the reference's ks 21): while a
+// workgroup convolves the 8 pixels of group g out of LDS, the loads of group g+1 -- its 28 KB of
+// [L | R] kernels AND the (KS x (8 + KS - 1)) x C image patch the 8 pixels read, replicate-clamped --
+// are in flight into registers.  The compute phase issues NO global loads (vmcnt returns in order:
+// a gather issued behind the prefetch would wait for all of it), its image reads are LDS reads at
+// immediate offsets, no coordinate clamps.  k_local_psf_render_rows staged, computed, staged, ...
+// with the phases of all workgroups of a CU aligned: 0.44 ms against a 0.19 ms read-only stream of
+// the same bytes.
+template <int C, bool HALF, int KS, int PIX>
+__global__ void __launch_bounds__(kBlock)
+k_local_psf_render_pipe(const float* __restrict__ img, const float* __restrict__ psf, int H, int W,
+                        int64_t total_floats, float* __restrict__ outl, float* __restrict__ outr)
+{
+    constexpr int kk = KS * KS, pad = (KS - 1) / 2;
+    constexpr int PW = PIX + KS - 1;                 // patch width
+    constexpr int NI = (kk + 63) / 64;               // wave passes over the kernel's taps
+    constexpr int NPSF = PIX * 2 * kk;
+    constexpr int NV = (NPSF / 4 + 1 + kBlock - 1) / kBlock;      // fl4 per thread (run + shift slack)
+    constexpr int NPATCH = C * KS * PW;
+    constexpr int NQ = (NPATCH + kBlock - 1) / kBlock;
+    typedef float fl4 __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* wts = lds;                                // [NPSF + 4] (the run, shifted by its misalignment)
+    // the image patch [C][KS][PW]: rounded to fp16 once, at staging, for the fp16 arithmetic of the
+    // _fast renderer (every element is read by up to 8 x KS taps), fp32 for the fp32 renderer
+    typedef typename std::conditional<HALF, _Float16, float>::type PatchT;
+    PatchT* patch = reinterpret_cast<PatchT*>(lds + ((NPSF + 4 + 3) & ~3));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.y;
+    const int b = row / H, y = row - b * H;
+    const int HW = H * W;
+    const float* __restrict__ img_b = img + (int64_t)b * C * HW;
+    // pass `it` of a wave covers taps f = 64 it + lane of the kernel (consecutive lanes read
+    // consecutive weights); tap (fi, fj) multiplies the neighbour at the flipped offset
+    // (render_psf.py:138), i.e. patch row KS-1-fi, patch column q + KS-1-fj.  Only the last pass has
+    // lanes without a tap (448 - 441 of them at ks 21).
+    int ptap[NI];
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+        const int f = min(it * 64 + lane, kk - 1);
+        const int fi = f / KS, fj = f - fi * KS;
+        ptap[it] = (KS - 1 - fi) * PW + (KS - 1 - fj);
+    }
+    const int groups = (W + PIX - 1) / PIX;
+    const int64_t total4 = total_floats >> 2;
+
+    fl4 pv[NV];
+    float pq[NQ];
+    int sh_next = 0;
+    // patch element e = threadIdx.x + u * kBlock of this thread: its image row never changes (the
+    // workgroup stays on one row), its column moves with the group
+    int prow[NQ], pcol[NQ];
+#pragma unroll
+    for (int u = 0; u < NQ; ++u) {
+        const int e = min((int)threadIdx.x + u * kBlock, NPATCH - 1);
+        const int c = e / (KS * PW), r = (e - c * KS * PW) / PW;
+        pcol[u] = e - c * KS * PW - r * PW - pad;
+        prow[u] = c * HW + min(max(y + r - pad, 0), H - 1) * W;
+    }
+    const fl4* src4 = reinterpret_cast<const fl4*>(psf);
+    auto fetch = [&](int gx) {
+        const int x0 = gx * PIX;
+        const int npix = min(PIX, W - x0);
+        const int64_t first = ((int64_t)row * W + x0) * 2 * kk;
+        const int sh = (int)(first & 3);
+        sh_next = sh;
+        const int64_t v0 = (first - sh) >> 2;                       // first 16-byte vector of the run
+        const int nv = (sh + npix * 2 * kk + 3) >> 2;
+        if (v0 + nv <= total4) {                                    // (always, but for the tensor's last bytes)
+#pragma unroll
+            for (int u = 0; u < NV; ++u) {
+                const int i = threadIdx.x + u * kBlock;
+                if (u + 1 < NV || i < nv) pv[u] = __builtin_nontemporal_load(&src4[v0 + min(i, nv - 1)]);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < NV; ++u) {
+                const int i = threadIdx.x + u * kBlock;
+                fl4 t = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (i < nv)
+                    for (int e = 0; e < 4; ++e)
+                        if (((v0 + i) << 2) + e < total_floats) t[e] = psf[((v0 + i) << 2) + e];
+                pv[u] = t;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NQ; ++u)
+            pq[u] = img_b[prow[u] + min(max(x0 + pcol[u], 0), W - 1)];
+    };
+    auto commit = [&](int gx) {
+        const int npix = min(PIX, W - gx * PIX);
+        const int nv = (sh_next + npix * 2 * kk + 3) >> 2;
+        fl4* dst4 = reinterpret_cast<fl4*>(wts);
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int i = threadIdx.x + u * kBlock;
+            if (i < nv) dst4[i] = pv[u];
+        }
+#pragma unroll
+        for (int u = 0; u < NQ; ++u) {
+            const int e = threadIdx.x + u * kBlock;
+            if (e < NPATCH) patch[e] = (PatchT)pq[u];
+        }
+    };
+
+    int gx = blockIdx.x;
+    if (gx >= groups) return;
+#ifdef SDIRT_DBG_CLOCK
+    const unsigned long long dbg_t0 = __builtin_readcyclecounter(), dbg_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    fetch(gx);
+    commit(gx);
+    int sh = sh_next;
+    __syncthreads();
+    for (; gx < groups; gx += gridDim.x) {
+        const int gn = gx + gridDim.x;
+#ifndef SDIRT_ABL_NOFETCH
+        if (gn < groups) fetch(gn);                  // in flight during the convolution below
+#endif
+        const int x0 = gx * PIX;
+#ifdef SDIRT_ABL_NOCOMPUTE
+        const int npix = 0;
+#else
+        const int npix = min(PIX, W - x0);
+#endif
+        for (int q = wave; q < npix; q += kBlock / 64) {
+            // every lane reads unconditionally (a predicated read costs a branch and a wait of its
+            // own); the tap-less lanes of the last pass read in-bounds elements and are zeroed
+            const float* kl = wts + sh + q * 2 * kk + lane;
+            float accl[C], accr[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) { accl[c] = 0.0f; accr[c] = 0.0f; }
+            float rwl[NI], rwr[NI];
+            PatchT rv[NI][C];
+#pragma unroll
+            for (int it = 0; it < NI; ++it) {
+                const bool in = it * 64 + 63 < kk;                   // compile-time: whole pass inside the kernel
+                const int f = in ? it * 64 : min(it * 64, kk - 1 - lane);
+                rwl[it] = kl[f];
+                rwr[it] = kl[kk + f];
+                const PatchT* pp = patch + ptap[it] + q;
+#pragma unroll
+                for (int c = 0; c < C; ++c) rv[it][c] = pp[c * KS * PW];
+            }
+#pragma unroll
+            for (int it = 0; it < NI; ++it) {
+                const bool on = it * 64 + 63 < kk || it * 64 + lane < kk;
+                const float wl = on ? rwl[it] : 0.0f, wr = on ? rwr[it] : 0.0f;
+                const hpair wpair = half_pair(wl, wr);
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    const PatchT v = on ? rv[it][c] : (PatchT)0.0f;
+                    if (HALF) {
+                        mul_acc_half(v, wpair, accl[c], accr[c]);
+                    } else {
+                        accl[c] += v * wl;
+                        accr[c] += v * wr;
+                    }
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const float a = wave_sum(accl[c]), rr = wave_sum(accr[c]);
+                if (lane == 0) {
+                    const int64_t o = ((int64_t)(b * C + c) * H + y) * W + x0 + q;
+                    outl[o] = HALF ? round_half(a) : a;
+                    outr[o] = HALF ? round_half(rr) : rr;
+                }
+            }
+        }
+        __syncthreads();                             // everyone is done reading this group's LDS image
+        if (gn < groups) {
+            commit(gn);
+            sh = sh_next;
+        }
+        __syncthreads();
+    }
+#ifdef SDIRT_DBG_CLOCK
+    if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == gridDim.y / 2) {
+        g_dbg_clock[2] = __builtin_readcyclecounter() - dbg_t0;
+        g_dbg_clock[3] = __builtin_amdgcn_s_memrealtime() - dbg_r0;
+    }
+#endif
 }
 
 // PSFNet.pred (psfnet.py:317-336) + local_psf_render_fast (render_psf.py:120-155) in one pass
@@ -954,6 +1187,163 @@ k_psfnet_render(const float* __restrict__ img, const _Float16* __restrict__ raw_
                     outr[o] = round_half(rr);
                 }
             }
+        }
+        __syncthreads();
+    }
+}
+
+// k_psfnet_render with the structure of k_local_psf_render_pipe (compile-time kernel size, one image
+// row per workgroup row, 8-pixel groups): the two fp16 runs of group g+1 and its image patch are in
+// flight into registers while group g is convolved out of LDS; image patch kept in fp16; taps
+// mapped linearly onto lanes (f = 64 it + lane); accumulation with v_fma_mix_f32.  Same arithmetic,
+// same results as k_psfnet_render.
+template <int C, int KS>
+__global__ void __launch_bounds__(kBlock)
+k_psfnet_render_pipe(const float* __restrict__ img, const _Float16* __restrict__ raw_l,
+                     const _Float16* __restrict__ raw_r, int H, int W, int64_t total_halves,
+                     float* __restrict__ outl, float* __restrict__ outr)
+{
+    constexpr int PIX = 8, kk = KS * KS, pad = (KS - 1) / 2;
+    constexpr int PW = PIX + KS - 1;
+    constexpr int NI = (kk + 63) / 64;
+    constexpr int NH = PIX * kk;                                   // halves per side and group
+    constexpr int SIDE = (NH + 8 + 7) & ~7;                        // LDS halves per side (+ shift slack)
+    constexpr int NV = (NH / 8 + 1 + kBlock - 1) / kBlock;         // 16-byte vectors per thread and side
+    constexpr int NPATCH = C * KS * PW;
+    constexpr int NQ = (NPATCH + kBlock - 1) / kBlock;
+    typedef float fl4 __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) _Float16 ldh[];
+    _Float16* wl_ = ldh;                                           // [SIDE]
+    _Float16* wr_ = ldh + SIDE;                                    // [SIDE]
+    _Float16* patch = ldh + 2 * SIDE;                              // [C][KS][PW]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.y;
+    const int b = row / H, y = row - b * H;
+    const int HW = H * W;
+    const float* __restrict__ img_b = img + (int64_t)b * C * HW;
+    int ptap[NI], fflip[NI];
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+        const int f = min(it * 64 + lane, kk - 1);
+        const int fi = f / KS, fj = f - fi * KS;
+        ptap[it] = (KS - 1 - fi) * PW + (KS - 1 - fj);
+        fflip[it] = fi * KS + (KS - 1 - fj);                        // fliplr of the right kernel (psfnet.py:330)
+    }
+    const int groups = (W + PIX - 1) / PIX;
+    const int64_t total8 = total_halves >> 3;
+
+    fl4 pl[NV], pr[NV];
+    float pq[NQ];
+    int prow[NQ], pcol[NQ];
+#pragma unroll
+    for (int u = 0; u < NQ; ++u) {
+        const int e = min((int)threadIdx.x + u * kBlock, NPATCH - 1);
+        const int c = e / (KS * PW), r = (e - c * KS * PW) / PW;
+        pcol[u] = e - c * KS * PW - r * PW - pad;
+        prow[u] = c * HW + min(max(y + r - pad, 0), H - 1) * W;
+    }
+    int sh_next = 0;
+    const fl4* sl4 = reinterpret_cast<const fl4*>(raw_l);
+    const fl4* sr4 = reinterpret_cast<const fl4*>(raw_r);
+    auto fetch = [&](int gx) {
+        const int x0 = gx * PIX;
+        const int npix = min(PIX, W - x0);
+        const int64_t first = ((int64_t)row * W + x0) * kk;           // first half of both runs
+        const int sh = (int)(first & 7);
+        sh_next = sh;
+        const int64_t v0 = (first - sh) >> 3;
+        const int nv = (sh + npix * kk + 7) >> 3;
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int i = min((int)threadIdx.x + u * kBlock, nv - 1);
+            if (v0 + i < total8) {
+                pl[u] = __builtin_nontemporal_load(&sl4[v0 + i]);
+                pr[u] = __builtin_nontemporal_load(&sr4[v0 + i]);
+            } else {                                                // the tensors' last, partial vector
+                union { fl4 v; _Float16 h[8]; } a, c;
+                for (int e = 0; e < 8; ++e) {
+                    const int64_t k = ((v0 + i) << 3) + e;
+                    a.h[e] = k < total_halves ? raw_l[k] : (_Float16)0.0f;
+                    c.h[e] = k < total_halves ? raw_r[k] : (_Float16)0.0f;
+                }
+                pl[u] = a.v; pr[u] = c.v;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NQ; ++u)
+            pq[u] = img_b[prow[u] + min(max(x0 + pcol[u], 0), W - 1)];
+    };
+    auto commit = [&](int gx) {
+        const int npix = min(PIX, W - gx * PIX);
+        const int nv = (sh_next + npix * kk + 7) >> 3;
+        fl4* dl4 = reinterpret_cast<fl4*>(wl_);
+        fl4* dr4 = reinterpret_cast<fl4*>(wr_);
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int i = threadIdx.x + u * kBlock;
+            if (i < nv) { dl4[i] = pl[u]; dr4[i] = pr[u]; }
+        }
+#pragma unroll
+        for (int u = 0; u < NQ; ++u) {
+            const int e = threadIdx.x + u * kBlock;
+            if (e < NPATCH) patch[e] = (_Float16)pq[u];
+        }
+    };
+
+    int gx = blockIdx.x;
+    if (gx >= groups) return;
+    fetch(gx);
+    commit(gx);
+    int sh = sh_next;
+    __syncthreads();
+    for (; gx < groups; gx += gridDim.x) {
+        const int gn = gx + gridDim.x;
+        if (gn < groups) fetch(gn);
+        const int x0 = gx * PIX;
+        const int npix = min(PIX, W - x0);
+        for (int q = wave; q < npix; q += kBlock / 64) {
+            const _Float16* kl = wl_ + sh + q * kk;
+            const _Float16* kr = wr_ + sh + q * kk;
+            float rl[NI], rrf[NI], sl = 0.0f, sr = 0.0f;
+            _Float16 rv[NI][C];
+#pragma unroll
+            for (int it = 0; it < NI; ++it) {
+                const bool on = it * 64 + 63 < kk || it * 64 + lane < kk;
+                const int f = min(it * 64 + lane, kk - 1);
+                const float a = (float)kl[f], c = (float)kr[f];
+                rl[it] = on ? a : 0.0f;
+                sl += on ? a : 0.0f;
+                sr += on ? c : 0.0f;
+                rrf[it] = on ? (float)kr[fflip[it]] : 0.0f;
+                const _Float16* pp = patch + ptap[it] + q;
+#pragma unroll
+                for (int ch = 0; ch < C; ++ch) rv[it][ch] = pp[ch * KS * PW];
+            }
+            const float inv_l = 1.0f / (round_half(wave_sum(sl)) + 1e-9f);
+            const float inv_r = 1.0f / (round_half(wave_sum(sr)) + 1e-9f);
+            float accl[C], accr[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) { accl[c] = 0.0f; accr[c] = 0.0f; }
+#pragma unroll
+            for (int it = 0; it < NI; ++it) {
+                const hpair wpair = half_pair(rl[it] * inv_l, rrf[it] * inv_r);
+#pragma unroll
+                for (int c = 0; c < C; ++c) mul_acc_half(rv[it][c], wpair, accl[c], accr[c]);
+            }
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const float a = wave_sum(accl[c]), rr = wave_sum(accr[c]);
+                if (lane == 0) {
+                    const int64_t o = ((int64_t)(b * C + c) * H + y) * W + x0 + q;
+                    outl[o] = round_half(a);
+                    outr[o] = round_half(rr);
+                }
+            }
+        }
+        __syncthreads();
+        if (gn < groups) {
+            commit(gn);
+            sh = sh_next;
         }
         __syncthreads();
     }
@@ -1483,27 +1873,40 @@ int sdirt_local_psf_render(const float* img, const float* psf, int32_t B, int32_
     const int64_t P = (int64_t)B * H * W;
     const int grid = grid_for(P * 64, kBlock, 256 * 32);      // one wave per pixel, grid-stride
     hipStream_t st = as_stream(stream);
-    // LDS-tiled kernel whenever 8 (or 4, or 2) pixels' kernels fit in 64 KB of LDS, else the
-    // direct one-wave-per-pixel kernel
+    // row-mapped LDS-tiled kernel whenever 8 (or 4, or 2) pixels' kernels fit in 64 KB of LDS and the
+    // image fits 32-bit offsets, else the direct one-wave-per-pixel kernel
     const size_t per_pixel = sizeof(float) * 2 * (size_t)ks * ks;
-    const int pix = per_pixel * 8 <= 64 * 1024 ? 8 : per_pixel * 4 <= 64 * 1024 ? 4
-                    : per_pixel * 2 <= 64 * 1024 ? 2 : 0;
-    const size_t lds_tile = per_pixel * pix;
-    const int grid_t = pix ? (int)std::min<int64_t>((P + pix - 1) / pix, 256 * 64) : 0;
+    const bool small = ks <= 64 && (int64_t)C * H * W < (1ll << 30) && (int64_t)B * H < 65536;
+    const int pix = !small ? 0 : per_pixel * 8 + 16 <= 64 * 1024 ? 8 : per_pixel * 4 + 16 <= 64 * 1024 ? 4
+                    : per_pixel * 2 + 16 <= 64 * 1024 ? 2 : 0;
+    const size_t lds_tile = per_pixel * pix + 16;
+    const int groups = pix ? (W + pix - 1) / pix : 0;
+    // ~16 workgroups per CU in flight; the rest of a row's groups are walked by the same workgroup
+    const int gx = pix ? std::max(1, std::min(groups, (int)((256 * 16 + (int64_t)B * H - 1) / ((int64_t)B * H)))) : 0;
+    const dim3 grid_t((unsigned)gx, (unsigned)(B * H));
+    // pipelined kernel (ks 21, RGB): each workgroup walks >= ~6 groups of its row so that the prologue
+    // fetch is amortised; LDS = shifted kernel run + image patch
+#ifndef SDIRT_PIPE_PIX
+#define SDIRT_PIPE_PIX 8
+#endif
+    const int groups_p = (W + SDIRT_PIPE_PIX - 1) / SDIRT_PIPE_PIX;
+    const dim3 grid_p((unsigned)std::max(1, std::min(groups_p, std::max(gx, (groups_p + 11) / 12))), (unsigned)(B * H));
+    const size_t lds_pipe = sizeof(float) * (((SDIRT_PIPE_PIX * 2 * 441 + 4 + 3) & ~3) + 3 * 21 * (SDIRT_PIPE_PIX + 20));
+    const int64_t total_floats = P * 2 * ks * ks;
 #define SDIRT_RENDER_T(CC, HF, PP)                                                               \
     do {                                                                                         \
         if (lds_tile > 48 * 1024)                                                                \
-            HIP_TRY(hipFuncSetAttribute((const void*)k_local_psf_render_tiled<CC, HF, PP, 0>,    \
+            HIP_TRY(hipFuncSetAttribute((const void*)k_local_psf_render_rows<CC, HF, PP, 0>,     \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)); \
-        k_local_psf_render_tiled<CC, HF, PP, 0><<<grid_t, kBlock, lds_tile, st>>>(               \
-            img, psf, B, H, W, ks, out_l, out_r);                                                \
+        k_local_psf_render_rows<CC, HF, PP, 0><<<grid_t, kBlock, lds_tile, st>>>(                \
+            img, psf, H, W, ks, out_l, out_r);                                                   \
     } while (0)
 #define SDIRT_RENDER_H(CC, HF)                                                                   \
     do {                                                                                         \
         /* the reference's PSFNet kernel size (configs/dfdp_by_sdirt_rf50mm.yml: ks 21) on RGB */ \
         if (pix == 8 && ks == 21 && CC == 3)                                                     \
-            k_local_psf_render_tiled<3, HF, 8, 21><<<grid_t, kBlock, lds_tile, st>>>(            \
-                img, psf, B, H, W, ks, out_l, out_r);                                            \
+            k_local_psf_render_pipe<3, HF, 21, SDIRT_PIPE_PIX><<<grid_p, kBlock, lds_pipe, st>>>(\
+                img, psf, H, W, total_floats, out_l, out_r);                                     \
         else if (pix == 8) SDIRT_RENDER_T(CC, HF, 8);                                            \
         else if (pix == 4) SDIRT_RENDER_T(CC, HF, 4);                                            \
         else if (pix == 2) SDIRT_RENDER_T(CC, HF, 2);                                            \
@@ -1555,7 +1958,13 @@ int sdirt_psfnet_render(const float* img, const void* raw_l, const void* raw_r, 
     } while (0)
 #define SDIRT_PN_C(CC)                                                                           \
     do {                                                                                         \
-        if (ks == 21 && CC == 3) SDIRT_PN(3, 16, 21);                                            \
+        if (ks == 21 && CC == 3 && (int64_t)3 * H * W < (1ll << 30) && (int64_t)B * H < 65536) { \
+            const int groups = (W + 7) / 8;                                                      \
+            const int gx = std::max(1, std::min(groups, std::max((int)((256 * 16 + (int64_t)B * H - 1) / ((int64_t)B * H)), (groups + 11) / 12))); \
+            const size_t lds = sizeof(_Float16) * (2 * ((8 * 441 + 8 + 7) & ~7) + 3 * 21 * 28);  \
+            k_psfnet_render_pipe<3, 21><<<dim3((unsigned)gx, (unsigned)(B * H)), kBlock, lds, st>>>( \
+                img, rl, rr, H, W, P * 441, out_l, out_r);                                       \
+        } else if (ks == 21 && CC == 3) SDIRT_PN(3, 16, 21);                                     \
         else if (per_pixel * 16 <= 32 * 1024) SDIRT_PN(CC, 16, 0);                               \
         else SDIRT_PN(CC, 8, 0);                                                                 \
     } while (0)

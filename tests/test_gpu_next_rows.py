@@ -59,6 +59,27 @@ def test_local_psf_render_high_res_against_reference_tiles():
     assert not torch.equal(whole_l, rl)
 
 
+@pytest.mark.parametrize("shape", [(2, 3, 9, 13, 21), (1, 3, 5, 8, 21), (1, 3, 33, 70, 21), (1, 3, 4, 97, 21),
+                                   (1, 1, 7, 10, 21), (1, 3, 6, 11, 7), (1, 4, 5, 9, 33)])
+def test_render_kernels_equal_a_plain_torch_convolution(shape):
+    """Every dispatch path of sdirt_local_psf_render (software-pipelined ks 21 RGB kernel, row-mapped
+    LDS-tiled kernel for other sizes / channel counts) on ragged shapes -- rows shorter than a
+    pixel group, widths that are not a multiple of 8, odd run alignments, the tensor's last partial
+    16-byte vector -- against the definition: replicate padding, flipped per-pixel kernels, fp32."""
+    from sdirt_amd import local_dp_psf_render
+    B, C, H, W, ks = shape
+    g = torch.Generator(device=DEV).manual_seed(sum(shape))
+    img = torch.rand(B, C, H, W, device=DEV, generator=g)
+    psf = torch.rand(B, H, W, 2, ks, ks, device=DEV, generator=g)
+    out = local_dp_psf_render(img, psf, kernel_size=ks)                       # [B, 2C, H, W]
+    pad = (ks - 1) // 2
+    patches = torch.nn.functional.unfold(torch.nn.functional.pad(img.double(), (pad,) * 4, mode="replicate"),
+                                         (ks, ks)).view(B, C, ks * ks, H * W)
+    k = torch.flip(psf.double(), [-2, -1]).view(B, H * W, 2, ks * ks).permute(0, 2, 3, 1)   # [B,2,ks*ks,HW]
+    ref = torch.cat([(patches * k[:, s:s + 1]).sum(2).view(B, C, H, W) for s in (0, 1)], dim=1)
+    assert torch.allclose(out.double(), ref, rtol=0, atol=2e-5 * float(ref.max()))
+
+
 def test_render_production_size_runs_and_conserves_energy():
     """512x768, ks 21 (config 5 of BASELINE.json): normalised kernels keep a flat image flat."""
     from sdirt_amd import local_psf_render_fast
