@@ -178,10 +178,13 @@ struct Ray {
 //                inputs do not.
 //          sqrt_pos: for arguments KNOWN to be positive, finite and normal (1 - a inside the
 //                conic's domain, squared lengths of non-zero vectors): r = v_rsq_f32(x);
-//                s = x*r; h = r/2; e = 1/2 - h*s; h += h*e; s += s*e; s += h*(x - s*s)
-//                (7 + v_rsq) -- the Markstein / Goldschmidt correction LLVM itself emits for
-//                sqrt when denormals are flushed.  Verified on every fp32 in [2^-100, 2^100]
-//                (mode 3, exhaustive); 0, inf and denormals are NOT handled.
+//                s = x*r; s += (r/2)*(x - s*s) with the residual formed exactly by one fma
+//                (4 + v_rsq).  The Goldschmidt refinements of s and r/2 that LLVM's own
+//                flush-denormal sqrt expansion carries in between (3 more fma) change no result:
+//                verified on every fp32 in [2^-100, 2^100] with and without them (mode 3,
+//                exhaustive); 0, inf and denormals are NOT handled.  (The analogous shortening of
+//                the division -- unrefined v_rcp seed, one residual correction -- is NOT exact:
+//                47045 of the 2^46 mantissa pairs miss the IEEE quotient.)
 //        No operand on a valid ray is denormal or zero-denominator (eps = 1e-9 guards, unit
 //        direction vectors, |positions| in [1e-6, 2e4] mm), so valid rays are bit-identical
 //        to the Ieee instantiation; tests/test_gpu_parity.py runs both against the oracle.
@@ -230,12 +233,9 @@ struct Lean {
         return sqrt(x);
 #else
         const float r = __builtin_amdgcn_rsqf(x);
-        float s = x * r;
-        float h = 0.5f * r;
-        const float e = __builtin_fmaf(-h, s, 0.5f);
-        h = __builtin_fmaf(h, e, h);
-        s = __builtin_fmaf(s, e, s);
-        const float d = __builtin_fmaf(-s, s, x);
+        const float s = x * r;
+        const float h = 0.5f * r;
+        const float d = __builtin_fmaf(-s, s, x);            // exact residual of the 1-ulp estimate
         return __builtin_fmaf(d, h, s);
 #endif
     }
