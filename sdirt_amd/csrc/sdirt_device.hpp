@@ -21,6 +21,7 @@
 namespace sdirt {
 
 constexpr int kMaxAi = 8;
+constexpr int kPeriodicFrom = 4;        // Newton tables longer than this run the periodicity test
 constexpr float kNewtonStepBound = 5.0f;   // deeplens/surfaces.py:29
 
 // ---------------------------------------------------------------------------
@@ -399,11 +400,29 @@ __device__ __forceinline__ bool newton_k(const Surf& s, const P& pol, const Ray&
     // squared radius can pass (k > -1: rr < lim_loose; k <= -1: rr > 0, surfaces.py:736-743)
     const float bound = KGT ? (alive ? s.lim_loose() : -1.0f) : (alive ? 0.0f : __builtin_inff());
     float t = t0;
-    uint32_t mask = 0, bit = 2u;
+    // Loop bookkeeping in four scalar instructions per trip (the compiler's own rendering of
+    // `mask |= open ? bit : 0; bit <<= 1; if (adaptive && !open) break;` took thirteen and three
+    // branches): SCC = "some ray of this wave is open"; it is shifted into `rmask` from the right
+    // (s_addc: rmask + rmask + SCC), so the trips sit in REVERSE order there, and in adaptive mode
+    // a closed wave clears the count of trips left.
     // trips >= 0: exactly that many trips (the reference's batch-wide count, supplied by the host).
     // trips < 0: at most -trips, and this WAVE stops as soon as none of its 64 rays is open -- the
     // reference's loop condition evaluated per wave instead of per batch (speed mode, no host check).
-    for (int it = cap; it > 0; --it) {
+    uint32_t rmask = 0;
+    const uint32_t amask = adaptive ? ~0u : 0u;
+    int left = cap;
+    // Exact early exit.  A trip maps t to F(t) and nothing else changes, so once t[n+1] == t[n-1]
+    // bit for bit the sequence is periodic (a fixed point, or the two-value flip of a last bit)
+    // and the remaining trips can be written down instead of run: with `r` of them left the final
+    // t is t[n+1] (r even) or t[n] (r odd), and the wave's open flags repeat with period two.
+    // When EVERY ray of the wave is there, the wave leaves the loop.  (On the first surface the
+    // reference runs to its 10-trip cap for distant objects -- t ~ 2e4 mm resolves the surface to
+    // 1e-3 mm only, |f| never gets below 50e-6 -- while every wave is periodic after 2 to 4.)
+    uint32_t tp = 0xffffffffu;            // t two trips back: none yet (no trip produces this NaN)
+    float t_odd = t;
+    int skipped = 0;
+    auto trip = [&](auto periodic_exit) __attribute__((always_inline)) {
+        left -= 1;
         const float nx = r.ox + r.dx * t, ny = r.oy + r.dy * t, nz = r.oz + r.dz * t;
         const float rr = nx * nx + ny * ny;
         // g(x*valid, y*valid) (surfaces.py:694-696): (x*1)^2 + (y*1)^2 is rr bit for bit, and
@@ -414,12 +433,51 @@ __device__ __forceinline__ bool newton_k(const Surf& s, const P& pol, const Ray&
         const float ft = (g + k.d) - nz;
         const float dr2dt = 2.0f * (dd * t + dox);
         const float dfdt = dgd * dr2dt - r.dz;
-        const bool wave_open = __ballot(__builtin_fabsf(ft) > tol_loose) != 0ull;
-        mask |= wave_open ? bit : 0u;
-        bit <<= 1;
-        t = t - clamp_sym(M::div(ft, dfdt + eps), kNewtonStepBound);
-        if (adaptive && !wave_open) break;
+        const unsigned long long open = __ballot(__builtin_fabsf(ft) > tol_loose);
+        const float tn = t - clamp_sym(M::div(ft, dfdt + eps), kNewtonStepBound);
+        uint32_t tmp;
+        if (decltype(periodic_exit)::value) {
+            asm volatile("v_cmp_eq_u32 vcc, %6, %7\n\t"
+                         "s_cmp_lg_u64 %4, 0\n\t"             // SCC = open
+                         "s_cselect_b32 %3, 0, %5\n\t"
+                         "s_addc_u32 %0, %0, %0\n\t"
+                         "s_andn2_b32 %1, %1, %3\n\t"
+                         "s_cmp_eq_u64 vcc, exec\n\t"         // SCC = every ray of the wave is periodic
+                         "s_cselect_b32 %2, %1, %2\n\t"
+                         "s_cselect_b32 %1, 0, %1"
+                         : "+s"(rmask), "+s"(left), "+s"(skipped), "=&s"(tmp)
+                         : "s"(open), "s"(amask), "v"(tn), "v"(tp) : "scc", "vcc");
+            tp = __float_as_uint(t);
+            t_odd = t;
+        } else {
+            asm volatile("s_cmp_lg_u64 %3, 0\n\t"
+                         "s_cselect_b32 %2, 0, %4\n\t"
+                         "s_addc_u32 %0, %0, %0\n\t"
+                         "s_andn2_b32 %1, %1, %2"
+                         : "+s"(rmask), "+s"(left), "=&s"(tmp) : "s"(open), "s"(amask) : "scc");
+        }
+        t = tn;
+    };
+    // the periodicity test costs three vector and four scalar instructions per trip: it is run
+    // where it can pay, on tables longer than kPeriodicFrom trips (a wave-uniform choice of loop)
+#ifndef SDIRT_NO_PERIODIC_EXIT
+    if (cap > kPeriodicFrom) {
+        while (left > 0) trip(std::true_type{});
+    } else
+#endif
+    {
+        while (left > 0) trip(std::false_type{});
     }
+    if (skipped > 0) {
+        // the open flags of the skipped trips: ...ABAB with A = the flag before last, B = the last
+        rmask = (rmask << skipped) | (((rmask & 3u) * 0x5555u) >> (16 - skipped));
+        t = (skipped & 1) ? t_odd : t;
+    }
+    // trip j (0-based) -> bit j + 1.  n trips ran: cap, or in adaptive mode up to and including
+    // the first closed one (rmask = 1..10 then; an all-open run ends in a 1)
+    uint32_t n = (uint32_t)cap;
+    if (adaptive && !(rmask & 1u)) n = 32u - (uint32_t)__builtin_clz(rmask | 1u);
+    const uint32_t mask = __builtin_bitreverse32(rmask) >> (31u - n);
     mask_out = mask;
     const float t1 = t - t0;   // :563
     t = t0 + t1;               // :567

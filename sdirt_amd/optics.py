@@ -15,6 +15,8 @@ libsdirt_dp.so is not built or no MI355X is visible.
 import ctypes as C
 import json
 
+import weakref
+
 import numpy as np
 import torch
 
@@ -349,16 +351,26 @@ class Lensgroup:
             return xy[0], xy[1]
         # draw straight into page-locked memory (same generator, same values as torch.rand(spp))
         # so that the upload is a true asynchronous copy: from pageable memory it would block
-        # the host until the stream has drained, i.e. until the previous call's kernel is done
-        stage, done = self._staging(spp)
-        torch.rand(spp, out=stage[0])
-        torch.rand(spp, out=stage[1])
-        u = stage.to(self.device, non_blocking=True)
-        done.record(torch.cuda.current_stream(self.device))
-        xy = torch.empty((2, spp), dtype=torch.float32, device=self.device)
-        _lib.check(_lib.lib().sdirt_pupil_samples(dptr(u[0]), dptr(u[1]), spp, float(pupil_r),
-                                                  dptr(xy[0]), dptr(xy[1]),
-                                                  stream_ptr(self.device)))
+        # the host until the stream has drained, i.e. until the previous call's kernel is done.
+        # Upload and mapping depend on nothing the caller has queued, so they go on a side stream
+        # (they run beside the previous call's kernel instead of behind it) and the caller's
+        # stream waits for their event.
+        main = torch.cuda.current_stream(self.device)
+        side = self.__dict__.get("_sample_stream")
+        if side is None:
+            side = self.__dict__["_sample_stream"] = torch.cuda.Stream(self.device)
+        with torch.cuda.stream(side):
+            stage, done = self._staging(spp)
+            torch.rand(spp, out=stage[0])
+            torch.rand(spp, out=stage[1])
+            u = stage.to(self.device, non_blocking=True)
+            done.record(side)
+            xy = torch.empty((2, spp), dtype=torch.float32, device=self.device)
+            _lib.check(_lib.lib().sdirt_pupil_samples(dptr(u[0]), dptr(u[1]), spp, float(pupil_r),
+                                                      dptr(xy[0]), dptr(xy[1]),
+                                                      stream_ptr(self.device)))
+        main.wait_stream(side)
+        xy.record_stream(main)
         return xy[0], xy[1]
 
     # ----------------------------------------------------------------- tracing
@@ -434,7 +446,39 @@ class Lensgroup:
             field[..., 1] *= scale * self.sensor_size[1] / 2
         return field
 
+    def _side_stream(self, name):
+        st = self.__dict__.get(name)
+        if st is None:
+            st = self.__dict__[name] = torch.cuda.Stream(self.device)
+        return st
+
+    def _zeroed_control_block(self, n, rows=64):
+        """An int32 [n] device block that is zero, cut from a pool that is cleared `rows` blocks
+        at a time (one fill kernel per `rows` launches instead of one per launch)."""
+        pool = self.__dict__.get("_ctl_pool")
+        if pool is None or pool["n"] != n or pool["next"] >= rows:
+            pool = self.__dict__["_ctl_pool"] = {
+                "n": n, "next": 0, "buf": torch.zeros((rows, n), dtype=torch.int32, device=self.device)}
+        row = pool["buf"][pool["next"]]
+        pool["next"] += 1
+        return row
+
     def _points_to_object(self, points):
+        """[N,3] normalised points -> object space (optics.py:959-960, 1305), on the device.  The
+        result for the LAST tensor is kept: a caller that renders the same grid call after call (a
+        PSF volume, an evaluation set) pays for the conversion once.  The key is the tensor object
+        itself, its version counter (any in-place write bumps it) and every lens scalar used."""
+        key = (points._version, tuple(points.shape), points.dtype, float(np.tan(self.hfov)),
+               float(self.r_last), float(self.sensor_size[1]), float(self.sensor_size[0]),
+               str(self.device), torch.cuda.current_stream(self.device).cuda_stream)
+        hit = self.__dict__.get("_p2o_cache")
+        if hit is not None and hit[0]() is points and hit[1] == key:
+            return hit[2]
+        out = self._points_to_object_now(points)
+        self.__dict__["_p2o_cache"] = (weakref.ref(points), key, out)
+        return out
+
+    def _points_to_object_now(self, points):
         if not points.is_cuda:
             # page-locked staging: an upload from pageable memory blocks the host until the
             # stream has drained (i.e. until the previous call's kernel has finished)
@@ -582,13 +626,13 @@ class Lensgroup:
             handle_c = self.dev_lens(DEFAULT_WAVE)
             MS = _lib.MAX_SURFACES
             # one control block: [primary masks | chief-ray masks | any-valid flag] -> one readback
-            ctl = torch.zeros(2 * MS + 1, dtype=torch.int32, device=self.device)
-            masks, anyv = ctl[:2 * MS].view(2, MS), ctl[2 * MS:]
             reference = self.trip_policy == "reference"
+            ctl = self._zeroed_control_block(2 * MS + 1)
 
             def enqueue2(tp, tc):
                 if N == 0:
                     return
+                masks, anyv = ctl[:2 * MS].view(2, MS), ctl[2 * MS:]
                 with self._timed("psf_lr_centered"):
                     _lib.check(_lib.lib().sdirt_psf_lr_centered(
                         handle, handle_c, dptr(po), N, dptr(x2), dptr(y2), spp, dptr(xc), dptr(yc),
@@ -610,8 +654,10 @@ class Lensgroup:
                 keys = [("psf", wkey, self.precision), ("center", self.precision)]
                 keep = (po, x2, y2, xc, yc, cen)              # alive until the kernel has run
 
-                def enqueue_round(tables):
-                    ctl.zero_()
+                def enqueue_round(tables, again=True):
+                    nonlocal ctl
+                    if again:                                  # a re-launch: a fresh zeroed block
+                        ctl = self._zeroed_control_block(2 * MS + 1)
                     enqueue2(tables[0], tables[1])
                     if self.mask_reduce is not None:
                         # masks AND the any-valid flag, OR-ed over ranks: every rank verifies the
@@ -630,11 +676,18 @@ class Lensgroup:
 
                 if defer:
                     tables = [self.trips.initial(k, self._curved()) for k in keys]
-                    enqueue_round(tables)
+                    enqueue_round(tables, again=False)
+                    # the readback runs on its own stream: on the caller's it would sit between this
+                    # kernel and the next call's
+                    main = torch.cuda.current_stream(self.device)
+                    rb = self._side_stream("_readback_stream")
+                    rb.wait_stream(main)
                     host = torch.empty(ctl.shape, dtype=ctl.dtype, pin_memory=True)
-                    host.copy_(ctl, non_blocking=True)
+                    with torch.cuda.stream(rb):
+                        host.copy_(ctl, non_blocking=True)
+                    ctl.record_stream(rb)
                     done = torch.cuda.Event()
-                    done.record(torch.cuda.current_stream(self.device))
+                    done.record(rb)
 
                     def finish():
                         done.synchronize()
@@ -645,7 +698,15 @@ class Lensgroup:
                         assert launch.any_valid == 1, "No sampled rays is valid."   # optics.py:902
                         return squeeze(L, R) if keep else None
                     return PendingPSF(finish)
-                self.trips.run_many(keys, self._curved(), list(range(K)), launch)
+                first_round = [True]
+
+                def launch_sync(tables):
+                    enqueue_round(tables, again=not first_round[0])
+                    first_round[0] = False
+                    host = ctl.cpu().numpy()
+                    launch.any_valid = int(host[2 * MS])
+                    return read_masks(host)
+                self.trips.run_many(keys, self._curved(), list(range(K)), launch_sync)
                 assert launch.any_valid == 1, "No sampled rays is valid."   # optics.py:902
             else:
                 full = self._fixed_trips()

@@ -462,3 +462,40 @@ def test_lens_on_another_gpu_than_the_current_device():
     L1, R1 = lens1.psf_lr(torch.tensor(g["points"]), **kw)
     assert torch.cuda.current_device() == 0 and L1.device.index == 1
     assert torch.allclose(L0.cpu(), L1.cpu(), atol=2e-6) and torch.allclose(R0.cpu(), R1.cpu(), atol=2e-6)
+
+
+def test_object_point_cache_follows_in_place_writes_and_new_tensors(lens):
+    """The conversion of the normalised points is kept for the last tensor seen: an in-place
+    write, a different tensor at the same address and a changed lens scalar must all miss."""
+    pts = torch.tensor([[0.1, 0.2, -1000.0], [-0.4, 0.3, -5000.0]], device=DEV)
+    a = lens._points_to_object(pts)
+    assert lens._points_to_object(pts) is a                               # hit
+    assert torch.equal(a, lens._points_to_object_now(pts))
+    pts[0, 0] = 0.5                                                       # in-place write
+    b = lens._points_to_object(pts)
+    assert b is not a and torch.equal(b, lens._points_to_object_now(pts)) and not torch.equal(a, b)
+    addr = pts.data_ptr()
+    del pts
+    for _ in range(4):                                                    # same block, new tensor
+        q = torch.tensor([[0.7, -0.2, -300.0], [0.0, 0.0, -20000.0]], device=DEV)
+        if q.data_ptr() == addr:
+            break
+    assert torch.equal(lens._points_to_object(q), lens._points_to_object_now(q))
+    r_last = lens.r_last
+    try:
+        lens.r_last = r_last * 1.5                                        # a lens scalar of the mapping
+        assert torch.equal(lens._points_to_object(q), lens._points_to_object_now(q))
+    finally:
+        lens.r_last = r_last
+    L0, _ = lens.psf_lr(q, ks=21, spp=256)
+    q[:, :2] *= 0.5
+    L1, _ = lens.psf_lr(q, ks=21, spp=256)
+    assert not torch.allclose(L0, L1)
+
+
+def test_control_blocks_from_the_pool_are_zero_and_distinct(lens):
+    blocks = [lens._zeroed_control_block(65) for _ in range(130)]        # crosses two pool refills
+    assert all(int(b.abs().sum()) == 0 for b in blocks)
+    assert len({b.data_ptr() for b in blocks}) == len(blocks)
+    blocks[0].fill_(7)
+    assert int(blocks[1].abs().sum()) == 0

@@ -95,12 +95,12 @@ def kernel_body(lines, pattern):
 def histogram(body):
     """-> OrderedDict loop_key -> {depth, classes...}; loop_key = header label or 'straight'."""
     loops = OrderedDict()
-    cur = ("straight", 0)
+    cur, last_label = ("straight", 0), None
     hdr = re.compile(r"^(\.LBB\d+_\d+):")
     for l in body:
         m = hdr.match(l)
         if m:
-            label = m.group(1)[2:]
+            label = last_label = m.group(1)[2:]
             d = re.search(r"Loop Header: Depth=(\d+)", l)
             i = re.search(r"in Loop: Header=(BB\d+_\d+) Depth=(\d+)", l)
             if d:
@@ -111,6 +111,10 @@ def histogram(body):
                 cur = ("straight", 0)
             continue
         t = l.strip()
+        if t.startswith(";") and "Loop Header: Depth=" in l and last_label:       # header of a loop nested in others:
+            d = re.search(r"Loop Header: Depth=(\d+)", l)          # the label line names the parents
+            cur = (last_label, int(d.group(1)))
+            continue
         if l.startswith(";") and "in Loop: Header=" in l:          # "; %bb.N:  ; in Loop: Header=..."
             i = re.search(r"in Loop: Header=(BB\d+_\d+) Depth=(\d+)", l)
             cur = (i.group(1), int(i.group(2)))
