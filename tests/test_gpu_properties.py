@@ -419,6 +419,39 @@ def test_random_prescriptions_trace_bit_exact_against_the_oracle(oracle, seed, t
             assert np.array_equal(ray.obliq.cpu().numpy(), ref["obliq"])
 
 
+@pytest.mark.parametrize("seed", range(4))
+def test_long_trip_tables_periodic_exit_bit_exact_against_the_oracle(oracle, seed, tmp_path):
+    """Distant object points: the reference's Newton loop runs to its 10-trip cap on the first
+    surface (t ~ 1e3..2e4 mm cannot resolve |f| < 50e-6), which is where the kernels leave the
+    loop early once every ray of a wave is periodic.  The oracle runs every trip: positions,
+    directions, validity and the convergence masks (trip tables) must still be equal bit for bit."""
+    import json
+    from sdirt_amd import Lensgroup
+    from test_gpu_parity import rays_from_fixture
+    rng = np.random.default_rng(100 + seed)
+    data, state = _random_prescription(rng, n_elements=int(rng.integers(1, 4)))
+    path = tmp_path / "fuzz_far.json"
+    path.write_text(json.dumps(data))
+    K = len(data["surfaces"])
+    surf = oracle.surfaces_from_state(state, 0.589)
+    n = 8192
+    depth = -rng.uniform(800.0, 20000.0, n)
+    o = np.stack([rng.uniform(-0.15, 0.15, n) * -depth, rng.uniform(-0.15, 0.15, n) * -depth, depth], 1).astype(np.float32)
+    tgt = np.stack([rng.uniform(-4, 4, n), rng.uniform(-4, 4, n), np.zeros(n)], 1)
+    d = tgt - o.astype(np.float64)
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    ref = oracle.trace(surf, o, d, np.ones(n, np.float32))
+    assert max(ref["trips"]) > 4, "no long table: the periodic-exit loop would not run"
+    for precision in ("lean", "ieee"):
+        lens = Lensgroup(str(path), sensor_res=(512, 768), post_computation=False, device=DEV)
+        lens.precision = precision
+        ray, valid, _ = lens.trace(rays_from_fixture(o, d))
+        assert np.array_equal(lens.trips.cache[("trace", 0.589, 0, K, True, precision)], ref["trips"])
+        assert np.array_equal(ray.ra.cpu().numpy(), ref["ra"])
+        assert np.array_equal(ray.o.cpu().numpy(), ref["o"]), (seed, precision)
+        assert np.array_equal(ray.d.cpu().numpy(), ref["d"])
+
+
 @pytest.mark.parametrize("seed", range(8))
 def test_random_dual_pixel_parameters_splat_against_the_oracle(oracle, seed):
     """Fuzz of the DP model (monte_carlo.py:135-372): random microlens / stack geometry (h, f, w, r)
