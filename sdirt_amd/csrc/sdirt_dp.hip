@@ -173,8 +173,24 @@ __device__ __forceinline__ void store_ray(const sdirt_rays& R, int64_t i, const 
     if (R.obliq) R.obliq[i] = r.ob;
 }
 
+// *p |= m (p in LDS, m wave-uniform) by the first active lane of the wave.  Written out: the
+// compiler's rendering of `if (lane == first) atomicOr(p, m)` goes through its wave-level atomic
+// optimiser (mbcnt, two exec save/restore pairs, a readlane: ~20 instructions per surface).
+__device__ __forceinline__ void lds_or_first_lane(uint32_t* p, uint32_t m)
+{
+    const uint32_t addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)p;
+    uint64_t save, bit;
+    uint32_t idx;
+    asm volatile("s_ff1_i32_b64 %2, exec\n\t"
+                 "s_lshl_b64 %1, 1, %2\n\t"
+                 "s_and_saveexec_b64 %0, %1\n\t"
+                 "ds_or_b32 %3, %4\n\t"
+                 "s_mov_b64 exec, %0"
+                 : "=&s"(save), "=&s"(bit), "=&s"(idx) : "v"(addr), "v"(m) : "memory", "scc");
+}
+
 // Trace one ray through surfaces [first,last) in the travel direction.  The
-// per-wave convergence masks are OR-ed into lds_mask[k] by lane 0.
+// per-wave convergence masks are OR-ed into lds_mask[k] by the first active lane.
 template <bool FWD, class M = Ieee>
 __device__ __forceinline__ void trace_ray(const DevSurface* __restrict__ lens, int first, int last,
                                           const void* trip_words, Ray& r, uint32_t* lds_mask)
@@ -193,8 +209,7 @@ __device__ __forceinline__ void trace_ray(const DevSurface* __restrict__ lens, i
         s.a = cur.a; s.b = cur.b;
         const uint32_t m = surface_reaction<FWD, M>(s, lens + k, surf_trips(cur, k), r,
                                                     [&] { surf_issue<FWD>(nxt, lens + kn, trip_words, kn); });
-        if (lds_mask && m != 0u && ((int)__lane_id() == __builtin_ctzll(__ballot(1))))
-            atomicOr(&lds_mask[k], m);
+        if (lds_mask && m != 0u) lds_or_first_lane(&lds_mask[k], m);
         surf_wait(nxt);
         cur = nxt;
         k = kn;
