@@ -60,6 +60,7 @@ struct DevSurface {
 static_assert(sizeof(SurfHot) == 64 && sizeof(SurfPoly) == 64 && sizeof(DevSurface) == 128, "layout");
 
 constexpr uint32_t kFlagRefract = 4u, kFlagKgtM1 = 8u, kFlagCpos = 16u;
+constexpr uint32_t kFlagUnitK = 32u;      // 1 + k == 1.0f exactly (every sphere): (1 + k) * r2 is r2
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
@@ -86,6 +87,7 @@ struct Surf {
     __device__ __forceinline__ bool do_refract() const { return (a[0] & kFlagRefract) != 0u; }
     __device__ __forceinline__ bool k_gt_m1() const { return (a[0] & kFlagKgtM1) != 0u; }
     __device__ __forceinline__ bool c_pos() const { return (a[0] & kFlagCpos) != 0u; }
+    __device__ __forceinline__ bool unit_k() const { return (a[0] & kFlagUnitK) != 0u; }
     __device__ __forceinline__ float d() const { return __uint_as_float(a[1]); }
     __device__ __forceinline__ float c() const { return __uint_as_float(a[2]); }
     __device__ __forceinline__ float c2() const { return __uint_as_float(a[3]); }
@@ -343,20 +345,21 @@ struct ConicS {      // the same constants straight from SGPRs (cold paths)
 };
 __device__ __forceinline__ ConicS conic_s(const Surf& s) { return ConicS{s.c(), s.c2(), s.onepk(), s.d()}; }
 
-template <class M, bool INSIDE, class C>
+template <class M, bool INSIDE, class C, bool UNITK = false>
 __device__ __forceinline__ void sag_g_dgd(const C& k, const NoPoly&, int, float r2, float& g, float& dgd)
 {
-    const float a = (k.onepk * r2) * k.c2;
+    // UNITK: 1 + k is 1.0f, the product with it is the identity and is left out
+    const float a = UNITK ? r2 * k.c2 : (k.onepk * r2) * k.c2;
     const float sf = INSIDE ? M::sqrt_pos(1.0f - a) : M::sqrt(1.0f - a);
     const float onesf = 1.0f + sf;
     g = M::div(r2 * k.c, onesf);
     dgd = M::div((onesf + M::div(a * 0.5f, sf)) * k.c, onesf * onesf);   // a/2 == a*0.5 exactly
 }
 
-template <class M, bool INSIDE, class C>
+template <class M, bool INSIDE, class C, bool UNITK = false>
 __device__ __forceinline__ void sag_g_dgd(const C& k, const Poly& pol, int deg, float r2, float& g, float& dgd)
 {
-    sag_g_dgd<M, INSIDE>(k, NoPoly{}, 0, r2, g, dgd);
+    sag_g_dgd<M, INSIDE, C, UNITK>(k, NoPoly{}, 0, r2, g, dgd);
     dgd = dgd + pol.ai(0);
     g = g + pol.ai(0) * r2;
     float pw = r2;                        // r2 ** i
@@ -379,10 +382,16 @@ __device__ __forceinline__ void sag_g_dgd(const C& k, const Poly& pol, int deg, 
 // mask_out (wave-uniform, lives in SGPRs) gets bit j set when ANY active lane of
 // the wave had |f(t)| > 50e-6 in trip j -- the per-wave share of the reference's
 // batch-wide `.any()` loop condition (surfaces.py:547).
-template <class M, bool KGT, class P>
+template <class M, bool KGT, class P, bool UNITK = false>
 __device__ __forceinline__ bool newton_k(const Surf& s, const P& pol, const Ray& r, int trips, float& t_out,
                                          uint32_t& mask_out)
 {
+    using CV =
+#ifdef SDIRT_CONIC_SGPR
+        ConicS;
+#else
+        ConicV;
+#endif
     const bool adaptive = trips < 0;
     const int cap = adaptive ? -trips : trips;
     const float tol_loose = (float)50e-6, tol_tight = (float)10e-6, eps = (float)1e-9;
@@ -429,7 +438,7 @@ __device__ __forceinline__ bool newton_k(const Surf& s, const P& pol, const Ray&
         // (x*0)^2 + (y*0)^2 is 0 for every finite position
         const float r2 = (KGT ? rr < bound : rr > bound) ? rr : 0.0f;
         float g, dgd;
-        sag_g_dgd<M, KGT>(k, pol, deg, r2, g, dgd);
+        sag_g_dgd<M, KGT, CV, UNITK>(k, pol, deg, r2, g, dgd);
         const float ft = (g + k.d) - nz;
         const float dr2dt = 2.0f * (dd * t + dox);
         const float dfdt = dgd * dr2dt - r.dz;
@@ -488,7 +497,7 @@ __device__ __forceinline__ bool newton_k(const Surf& s, const P& pol, const Ray&
     const float tight = alive ? s.lim_tight() : -1.0f;
     const float r2 = rr < tight ? rr : 0.0f;
     float g, dgd;
-    sag_g_dgd<M, KGT>(k, pol, deg, r2, g, dgd);
+    sag_g_dgd<M, KGT, CV, UNITK>(k, pol, deg, r2, g, dgd);
     const float ft = (g + k.d) - nz;
     const float dr2dt = 2.0f * (dd * t + dox);
     const float dfdt = dgd * dr2dt - r.dz;
@@ -558,8 +567,13 @@ __device__ __forceinline__ uint32_t curved_reaction(const Surf& s, const P& pol,
     float t;
     // k > -1 (every sphere, ellipsoid, mild asphere) and k <= -1 differ only in the domain test
     // (surfaces.py:727-743); the branch is wave-uniform and taken once, outside the loop
-    const bool vn = s.k_gt_m1() ? newton_k<M, true>(s, pol, r, trips, t, mask)
-                                : newton_k<M, false>(s, pol, r, trips, t, mask);
+    // (and, for pure conics, a copy for 1 + k == 1: every sphere)
+    bool vn;
+    if (std::is_same<P, NoPoly>::value && s.unit_k())
+        vn = newton_k<M, true, P, true>(s, pol, r, trips, t, mask);
+    else
+        vn = s.k_gt_m1() ? newton_k<M, true>(s, pol, r, trips, t, mask)
+                         : newton_k<M, false>(s, pol, r, trips, t, mask);
     between();
     const float nx = r.ox + t * r.dx, ny = r.oy + t * r.dy, nz = r.oz + t * r.dz;
     bool v;

@@ -57,7 +57,7 @@ static DevSurface make_dev_surface(const sdirt_surface_desc& in)
     h.eta_b = (float)eta_b;  h.eta2_b = (float)(eta_b * eta_b);
     const bool do_refract = in.kind == SDIRT_PLANE ? (eta_f != 1.0) : true;
     h.flags = (uint32_t)in.kind | (do_refract ? kFlagRefract : 0u) | (in.k > -1.0f ? kFlagKgtM1 : 0u) |
-              (in.c > 0.0f ? kFlagCpos : 0u) | ((uint32_t)deg << 8);
+              (in.c > 0.0f ? kFlagCpos : 0u) | (h.onepk == 1.0f ? kFlagUnitK : 0u) | ((uint32_t)deg << 8);
     for (int i = 0; i < kMaxAi; ++i) {
         s.p.ai[i] = i < deg ? in.ai[i] : 0.0f;
         s.p.kai[i] = (float)(i + 1) * s.p.ai[i];
