@@ -1112,6 +1112,181 @@ k_local_psf_render_pipe(const float* __restrict__ img, const float* __restrict__
 #endif
 }
 
+// Six wave sums for the price of two.  A butterfly level that pairs lanes l and l^16 / l^32 is a
+// gfx950 half-exchange (v_permlane16_swap / v_permlane32_swap: the odd rows / the upper half of
+// one register trade places with the even rows / the lower half of another) plus ONE addition
+// for TWO vectors, whose sums end up in different rows of the result: after both levels
+// `q` holds, per 16-lane row, the partial sums of (a0, a1, a2, b0) and `s` those of (b1, b2, b1, b2);
+// four DPP additions inside the rows finish both.  19 vector instructions for six sums, against
+// 6 x (6 DPP additions + v_readlane).  Row r of q / s: every lane holds the total.
+__device__ __forceinline__ float swap16_add(float a, float b)
+{
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);   // rows: a(0+1) b(0+1) a(2+3) b(2+3)
+}
+__device__ __forceinline__ float swap32_add(float a, float b)
+{
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);   // lanes 0-31: a(lo+hi), 32-63: b(lo+hi)
+}
+__device__ __forceinline__ float row_sum(float v)
+{
+#define SDIRT_DPP_ADD(CTRL)                                                                     \
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false))
+    SDIRT_DPP_ADD(0xB1);      // quad_perm [1,0,3,2]
+    SDIRT_DPP_ADD(0x4E);      // quad_perm [2,3,0,1]
+    SDIRT_DPP_ADD(0x141);     // row_half_mirror
+    SDIRT_DPP_ADD(0x140);     // row_mirror
+#undef SDIRT_DPP_ADD
+    return v;
+}
+__device__ __forceinline__ void wave_sum6(const float (&a)[3], const float (&b)[3], float& q, float& s)
+{
+    const float p01 = swap16_add(a[0], a[1]), p23 = swap16_add(a[2], b[0]), p45 = swap16_add(b[1], b[2]);
+    q = row_sum(swap32_add(p01, p23));          // rows: a0 a1 a2 b0
+    s = row_sum(swap32_add(p45, p45));          // rows: b1 b2 b1 b2
+}
+
+// One wave per pixel, weights straight from HBM into registers (ks 21, RGB).
+// k_local_psf_render_pipe moved every weight through LDS (16-byte loads, a write, a read per
+// weight, two barriers per 8 pixels) and spent 165 instructions per pixel and wave.  Here lane l
+// loads the weights of ITS taps (f = 64 it + l: consecutive lanes, consecutive floats -- each load
+// instruction of a wave is one contiguous 256 bytes of the pixel's kernel) one pixel ahead of the
+// one being convolved; LDS holds only the image patch of the workgroup's CHUNK-pixel stretch of
+// the row ([KS][CHUNK + KS - 1] positions x 4 channel slots: one 8- or 16-byte read per tap gives
+// all channels), staged once: one barrier per workgroup, none around the weights.  The six sums
+// of a pixel are reduced together (wave_sum6) and stored by 4 + 2 lanes in two instructions.
+template <int C, bool HALF, int KS, int CHUNK>
+__global__ void __launch_bounds__(kBlock)
+#ifdef SDIRT_RENDER_WAVES
+__attribute__((amdgpu_waves_per_eu(SDIRT_RENDER_WAVES, SDIRT_RENDER_WAVES)))
+#endif
+k_local_psf_render_wave(const float* __restrict__ img, const float* __restrict__ psf, int H, int W,
+                        float* __restrict__ outl, float* __restrict__ outr)
+{
+    static_assert(C == 3, "row layout of wave_sum6");
+    constexpr int kk = KS * KS, pad = (KS - 1) / 2;
+    constexpr int PW = CHUNK + KS - 1;               // patch width
+    constexpr int NI = (kk + 63) / 64;               // taps per lane
+    constexpr int NPOS = KS * PW;                    // patch positions
+    constexpr int NQ = (NPOS + kBlock - 1) / kBlock;
+    constexpr int NW = kBlock / 64, PPW = CHUNK / NW;   // waves, pixels per wave
+    static_assert(PPW % 2 == 0, "the pixel loop is unrolled by two");
+    typedef typename std::conditional<HALF, _Float16, float>::type PatchT;
+    typedef PatchT pvec __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    pvec* patch = reinterpret_cast<pvec*>(lds_raw);  // [NPOS]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.y;
+    const int b = row / H, y = row - b * H;
+    const int HW = H * W;
+    const int x0 = blockIdx.x * CHUNK;
+    const float* __restrict__ wrow = psf + (int64_t)row * W * 2 * kk;      // this image row's kernels
+    const int ftail = min((NI - 1) * 64 + lane, kk - 1);
+    const bool tail_on = (NI - 1) * 64 + lane < kk;
+    auto load_w = [&](int x, float (&l)[NI], float (&r)[NI]) {
+        const float* __restrict__ k0 = wrow + (int64_t)min(x, W - 1) * 2 * kk + lane;
+#pragma unroll
+        for (int it = 0; it < NI; ++it) {
+            const int f = it + 1 < NI ? it * 64 : ftail - lane;
+#ifdef SDIRT_ABL_NOFETCH
+            l[it] = __int_as_float(0x3c000000 + f + x); r[it] = __int_as_float(0x3c100000 + f + x);   // ablation: no loads
+#else
+#ifdef SDIRT_RENDER_PLAIN_LOADS
+            l[it] = k0[f];
+            r[it] = k0[kk + f];
+#else
+            l[it] = __builtin_nontemporal_load(k0 + f);
+            r[it] = __builtin_nontemporal_load(k0 + kk + f);
+#endif
+#endif
+        }
+    };
+    float wa[NI], ra[NI], wb[NI], rb[NI];
+    load_w(x0 + wave, wa, ra);                       // in flight while the patch is staged
+    {
+        const float* __restrict__ img_b = img + (int64_t)b * C * HW;
+#pragma unroll
+        for (int u = 0; u < NQ; ++u) {
+            const int e = threadIdx.x + u * kBlock;
+            if (e < NPOS) {
+                const int r = e / PW, col = e - r * PW - pad;
+                const int o = min(max(y + r - pad, 0), H - 1) * W + min(max(x0 + col, 0), W - 1);
+                pvec v;
+#pragma unroll
+                for (int c = 0; c < C; ++c) v[c] = (PatchT)img_b[c * HW + o];
+                v[3] = (PatchT)0.0f;
+                patch[e] = v;
+            }
+        }
+    }
+    // tap f = 64 it + l of the kernel multiplies the neighbour at the flipped offset
+    // (render_psf.py:138): patch row KS-1-fi, patch column q + KS-1-fj.  The lanes past the last
+    // tap (448 - 441 at ks 21) read tap kk-1 and are zeroed.
+    int ptap[NI];
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+        const int f = min(it * 64 + lane, kk - 1);
+        const int fi = f / KS, fj = f - fi * KS;
+        ptap[it] = (KS - 1 - fi) * PW + (KS - 1 - fj);
+    }
+    // this lane's output slot: rows 0..2 of the reduced vector q are the L channels, row 3 is R
+    // channel 0; rows 0, 1 of s are R channels 1, 2
+    const int r16 = lane >> 4;
+    float* __restrict__ oq = (r16 < 3 ? outl + ((int64_t)(b * C + r16) * H + y) * W
+                                      : outr + ((int64_t)(b * C) * H + y) * W);
+    float* __restrict__ os = outr + ((int64_t)(b * C + 1 + (r16 & 1)) * H + y) * W;
+    const bool store_q = (lane & 15) == 0, store_s = (lane & 47) == 0;
+    __syncthreads();
+
+    auto pixel = [&](int x, const float (&wl)[NI], const float (&wr)[NI]) {
+        if (x >= W) return;
+#ifdef SDIRT_ABL_NOCOMPUTE
+        {   // ablation: consume the weights with one addition each, store one value
+            float t = 0.0f;
+#pragma unroll
+            for (int it = 0; it < NI; ++it) t += wl[it] + wr[it];
+            if (t == 12345.0f) oq[x] = t;
+            return;
+        }
+#endif
+        const pvec* pp = patch + (x - x0);
+        float accl[C], accr[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) { accl[c] = 0.0f; accr[c] = 0.0f; }
+#pragma unroll
+        for (int it = 0; it < NI; ++it) {
+            const bool on = it + 1 < NI || tail_on;
+            const float a = on ? wl[it] : 0.0f, bq = on ? wr[it] : 0.0f;
+            const pvec v = pp[ptap[it]];
+            if (HALF) {
+                const hpair wpair = half_pair(a, bq);
+#pragma unroll
+                for (int c = 0; c < C; ++c) mul_acc_half((_Float16)v[c], wpair, accl[c], accr[c]);
+            } else {
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    accl[c] += (float)v[c] * a;
+                    accr[c] += (float)v[c] * bq;
+                }
+            }
+        }
+        float q, s2;
+        wave_sum6(accl, accr, q, s2);
+        if (HALF) { q = round_half(q); s2 = round_half(s2); }
+        if (store_q) oq[x] = q;
+        if (store_s) os[x] = s2;
+    };
+#pragma unroll 1
+    for (int j = 0; j < PPW; j += 2) {
+        const int x = x0 + wave + j * NW;
+        load_w(x + NW, wb, rb);
+        pixel(x, wa, ra);
+        if (j + 2 < PPW) load_w(x + 2 * NW, wa, ra);
+        pixel(x + NW, wb, rb);
+    }
+}
+
 // PSFNet.pred (psfnet.py:317-336) + local_psf_render_fast (render_psf.py:120-155) in one pass
 // over the network's raw fp16 outputs: raw_l = net(x, y, z), raw_r = net(-x, y, z), both
 // [P, ks*ks].  Per pixel: L taps = raw_l / (sum(raw_l) + 1e-9), R taps = fliplr(raw_r) /
@@ -1908,6 +2083,11 @@ int sdirt_local_psf_render(const float* img, const float* psf, int32_t B, int32_
     const dim3 grid_p((unsigned)std::max(1, std::min(groups_p, std::max(gx, (groups_p + 11) / 12))), (unsigned)(B * H));
     const size_t lds_pipe = sizeof(float) * (((SDIRT_PIPE_PIX * 2 * 441 + 4 + 3) & ~3) + 3 * 21 * (SDIRT_PIPE_PIX + 20));
     const int64_t total_floats = P * 2 * ks * ks;
+    // wave-per-pixel kernel: one workgroup per 64-pixel (SDIRT_RENDER_CHUNK=128: 128-pixel) stretch of a row
+    static const int chunk_w = getenv("SDIRT_RENDER_CHUNK") ? atoi(getenv("SDIRT_RENDER_CHUNK")) : 64;
+    static const bool use_pipe = getenv("SDIRT_RENDER_PIPE") != nullptr;
+    const dim3 grid_w((unsigned)((W + chunk_w - 1) / chunk_w), (unsigned)(B * H));
+    auto lds_wave = [&](bool hf) { return (size_t)21 * (chunk_w + 20) * 4 * (hf ? 2 : 4); };
 #define SDIRT_RENDER_T(CC, HF, PP)                                                               \
     do {                                                                                         \
         if (lds_tile > 48 * 1024)                                                                \
@@ -1919,7 +2099,13 @@ int sdirt_local_psf_render(const float* img, const float* psf, int32_t B, int32_
 #define SDIRT_RENDER_H(CC, HF)                                                                   \
     do {                                                                                         \
         /* the reference's PSFNet kernel size (configs/dfdp_by_sdirt_rf50mm.yml: ks 21) on RGB */ \
-        if (pix == 8 && ks == 21 && CC == 3)                                                     \
+        if (pix == 8 && ks == 21 && CC == 3 && !use_pipe && chunk_w == 128)                      \
+            k_local_psf_render_wave<3, HF, 21, 128><<<grid_w, kBlock, lds_wave(HF), st>>>(       \
+                img, psf, H, W, out_l, out_r);                                                   \
+        else if (pix == 8 && ks == 21 && CC == 3 && !use_pipe)                                   \
+            k_local_psf_render_wave<3, HF, 21, 64><<<grid_w, kBlock, lds_wave(HF), st>>>(        \
+                img, psf, H, W, out_l, out_r);                                                   \
+        else if (pix == 8 && ks == 21 && CC == 3)                                                \
             k_local_psf_render_pipe<3, HF, 21, SDIRT_PIPE_PIX><<<grid_p, kBlock, lds_pipe, st>>>(\
                 img, psf, H, W, total_floats, out_l, out_r);                                     \
         else if (pix == 8) SDIRT_RENDER_T(CC, HF, 8);                                            \
