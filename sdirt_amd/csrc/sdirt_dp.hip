@@ -1539,6 +1539,126 @@ k_psfnet_render_pipe(const float* __restrict__ img, const _Float16* __restrict__
     }
 }
 
+// k_psfnet_render with the structure of k_local_psf_render_wave: one wave per pixel, lane l loads the
+// raw network outputs of ITS taps (left: f = 64 it + l; right: the fliplr'ed tap, psfnet.py:330 --
+// a permutation of the taps, so its values also make up the right kernel's sum) straight from HBM
+// one pixel ahead, the image patch of the workgroup's CHUNK pixels sits in LDS with the three
+// channels of a position in one 8-byte slot, both normalising sums are reduced together and the
+// six outputs with wave_sum6.  Results equal k_psfnet_render's up to the order of the fp32 sums.
+template <int C, int KS, int CHUNK>
+__global__ void __launch_bounds__(kBlock)
+#ifdef SDIRT_RENDER_WAVES
+__attribute__((amdgpu_waves_per_eu(SDIRT_RENDER_WAVES, SDIRT_RENDER_WAVES)))
+#endif
+k_psfnet_render_wave(const float* __restrict__ img, const _Float16* __restrict__ raw_l,
+                     const _Float16* __restrict__ raw_r, int H, int W,
+                     float* __restrict__ outl, float* __restrict__ outr)
+{
+    static_assert(C == 3, "row layout of wave_sum6");
+    constexpr int kk = KS * KS, pad = (KS - 1) / 2;
+    constexpr int PW = CHUNK + KS - 1;
+    constexpr int NI = (kk + 63) / 64;
+    constexpr int NPOS = KS * PW;
+    constexpr int NQ = (NPOS + kBlock - 1) / kBlock;
+    constexpr int NW = kBlock / 64, PPW = CHUNK / NW;
+    static_assert(PPW % 2 == 0, "the pixel loop is unrolled by two");
+    typedef _Float16 pvec __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    pvec* patch = reinterpret_cast<pvec*>(lds_raw);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.y;
+    const int b = row / H, y = row - b * H;
+    const int HW = H * W;
+    const int x0 = blockIdx.x * CHUNK;
+    const _Float16* __restrict__ lrow = raw_l + (int64_t)row * W * kk;
+    const _Float16* __restrict__ rrow = raw_r + (int64_t)row * W * kk;
+    int ptap[NI], fr[NI];
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+        const int f = min(it * 64 + lane, kk - 1);
+        const int fi = f / KS, fj = f - fi * KS;
+        ptap[it] = (KS - 1 - fi) * PW + (KS - 1 - fj);
+        fr[it] = fi * KS + (KS - 1 - fj);
+    }
+    const int ftail = min((NI - 1) * 64 + lane, kk - 1);
+    const bool tail_on = (NI - 1) * 64 + lane < kk;
+    auto load_w = [&](int x, _Float16 (&l)[NI], _Float16 (&r)[NI]) {
+        const int k0 = min(x, W - 1) * kk;             // a row's runs fit 32-bit offsets (checked by the host)
+#pragma unroll
+        for (int it = 0; it < NI; ++it) {
+            l[it] = __builtin_nontemporal_load(lrow + (k0 + (it + 1 < NI ? it * 64 + lane : ftail)));
+            r[it] = __builtin_nontemporal_load(rrow + (k0 + fr[it]));
+        }
+    };
+    _Float16 wa[NI], ra[NI], wb[NI], rb[NI];
+    load_w(x0 + wave, wa, ra);
+    {
+        const float* __restrict__ img_b = img + (int64_t)b * C * HW;
+#pragma unroll
+        for (int u = 0; u < NQ; ++u) {
+            const int e = threadIdx.x + u * kBlock;
+            if (e < NPOS) {
+                const int r = e / PW, col = e - r * PW - pad;
+                const int o = min(max(y + r - pad, 0), H - 1) * W + min(max(x0 + col, 0), W - 1);
+                pvec v;
+#pragma unroll
+                for (int c = 0; c < C; ++c) v[c] = (_Float16)img_b[c * HW + o];
+                v[3] = (_Float16)0.0f;
+                patch[e] = v;
+            }
+        }
+    }
+    const int r16 = lane >> 4;
+    float* __restrict__ oq = (r16 < 3 ? outl + ((int64_t)(b * C + r16) * H + y) * W
+                                      : outr + ((int64_t)(b * C) * H + y) * W);
+    float* __restrict__ os = outr + ((int64_t)(b * C + 1 + (r16 & 1)) * H + y) * W;
+    const bool store_q = (lane & 15) == 0, store_s = (lane & 47) == 0;
+    __syncthreads();
+
+    auto pixel = [&](int x, const _Float16 (&hl)[NI], const _Float16 (&hr)[NI]) {
+        if (x >= W) return;
+        const pvec* pp = patch + (x - x0);
+        float wl[NI], wr[NI], sl = 0.0f, sr = 0.0f;
+#pragma unroll
+        for (int it = 0; it < NI; ++it) {
+            const bool on = it + 1 < NI || tail_on;
+            wl[it] = on ? (float)hl[it] : 0.0f;
+            wr[it] = on ? (float)hr[it] : 0.0f;
+            sl += wl[it];
+            sr += wr[it];
+        }
+        // both sums at once: even rows of t end up with sum(sl), odd rows with sum(sr)
+        const float t = row_sum(swap32_add(swap16_add(sl, sr), swap16_add(sl, sr)));
+        const float tot_l = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t), 0));
+        const float tot_r = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t), 16));
+        // psf / (psf.sum() + 1e-9) in half precision (psfnet.py:333): the sum rounded to fp16
+        const float inv_l = sdirt::Lean::div(1.0f, round_half(tot_l) + 1e-9f);
+        const float inv_r = sdirt::Lean::div(1.0f, round_half(tot_r) + 1e-9f);
+        float accl[C], accr[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) { accl[c] = 0.0f; accr[c] = 0.0f; }
+#pragma unroll
+        for (int it = 0; it < NI; ++it) {
+            const hpair wpair = half_pair(wl[it] * inv_l, wr[it] * inv_r);
+            const pvec v = pp[ptap[it]];
+#pragma unroll
+            for (int c = 0; c < C; ++c) mul_acc_half(v[c], wpair, accl[c], accr[c]);
+        }
+        float q, s2;
+        wave_sum6(accl, accr, q, s2);
+        if (store_q) oq[x] = round_half(q);
+        if (store_s) os[x] = round_half(s2);
+    };
+#pragma unroll 1
+    for (int j = 0; j < PPW; j += 2) {
+        const int x = x0 + wave + j * NW;
+        load_w(x + NW, wb, rb);
+        pixel(x, wa, ra);
+        if (j + 2 < PPW) load_w(x + 2 * NW, wa, ra);
+        pixel(x + NW, wb, rb);
+    }
+}
+
 // ---------------------------------------------------------------------------
 // diagnostics: does the Lean math policy ever differ from IEEE?
 // ---------------------------------------------------------------------------
@@ -2147,6 +2267,7 @@ int sdirt_psfnet_render(const float* img, const void* raw_l, const void* raw_r, 
         return fail(SDIRT_ERR_UNSUPPORTED, "ks=%d: eight pixels' kernels exceed 64 KB of LDS", ks);
     const _Float16* rl = static_cast<const _Float16*>(raw_l);
     const _Float16* rr = static_cast<const _Float16*>(raw_r);
+    static const bool use_pipe = getenv("SDIRT_RENDER_PIPE") != nullptr;
 #define SDIRT_PN(CC, PP, KK)                                                                     \
     do {                                                                                         \
         const size_t lds = per_pixel * PP;                                                       \
@@ -2159,7 +2280,10 @@ int sdirt_psfnet_render(const float* img, const void* raw_l, const void* raw_r, 
     } while (0)
 #define SDIRT_PN_C(CC)                                                                           \
     do {                                                                                         \
-        if (ks == 21 && CC == 3 && (int64_t)3 * H * W < (1ll << 30) && (int64_t)B * H < 65536) { \
+        if (ks == 21 && CC == 3 && (int64_t)3 * H * W < (1ll << 30) && (int64_t)B * H < 65536 && !use_pipe) { \
+            k_psfnet_render_wave<3, 21, 64><<<dim3((unsigned)((W + 63) / 64), (unsigned)(B * H)), kBlock, \
+                                              (size_t)21 * 84 * 8, st>>>(img, rl, rr, H, W, out_l, out_r); \
+        } else if (ks == 21 && CC == 3 && (int64_t)3 * H * W < (1ll << 30) && (int64_t)B * H < 65536) { \
             const int groups = (W + 7) / 8;                                                      \
             const int gx = std::max(1, std::min(groups, std::max((int)((256 * 16 + (int64_t)B * H - 1) / ((int64_t)B * H)), (groups + 11) / 12))); \
             const size_t lds = sizeof(_Float16) * (2 * ((8 * 441 + 8 + 7) & ~7) + 3 * 21 * 28);  \
