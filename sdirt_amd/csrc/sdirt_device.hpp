@@ -420,16 +420,18 @@ __device__ __forceinline__ bool newton_k(const Surf& s, const P& pol, const Ray&
     uint32_t rmask = 0;
     const uint32_t amask = adaptive ? ~0u : 0u;
     int left = cap;
-    // Exact early exit.  A trip maps t to F(t) and nothing else changes, so once t[n+1] == t[n-1]
-    // bit for bit the sequence is periodic (a fixed point, or the two-value flip of a last bit)
-    // and the remaining trips can be written down instead of run: with `r` of them left the final
-    // t is t[n+1] (r even) or t[n] (r odd), and the wave's open flags repeat with period two.
+    // Exact early exit.  A trip maps t to F(t) and nothing else changes, so once t[n+1] == t[n]
+    // (a fixed point) or t[n+1] == t[n-1] (the two-value flip of a last bit), bit for bit, the
+    // sequence is periodic and the remaining trips can be written down instead of run: with `r`
+    // of them left the final t is t[n+1] (r even) or t[n] (r odd), and the wave's open flags
+    // repeat with period two.
     // When EVERY ray of the wave is there, the wave leaves the loop.  (On the first surface the
     // reference runs to its 10-trip cap for distant objects -- t ~ 2e4 mm resolves the surface to
     // 1e-3 mm only, |f| never gets below 50e-6 -- while every wave is periodic after 2 to 4.)
     uint32_t tp = 0xffffffffu;            // t two trips back: none yet (no trip produces this NaN)
     float t_odd = t;
     int skipped = 0;
+    unsigned long long open_cur = 0ull, open_prev = 0ull, fixed = 0ull;   // lane masks of the last trips
     auto trip = [&](auto periodic_exit) __attribute__((always_inline)) {
         left -= 1;
         const float nx = r.ox + r.dx * t, ny = r.oy + r.dy * t, nz = r.oz + r.dz * t;
@@ -446,16 +448,20 @@ __device__ __forceinline__ bool newton_k(const Surf& s, const P& pol, const Ray&
         const float tn = t - clamp_sym(M::div(ft, dfdt + eps), kNewtonStepBound);
         uint32_t tmp;
         if (decltype(periodic_exit)::value) {
-            asm volatile("v_cmp_eq_u32 vcc, %6, %7\n\t"
-                         "s_cmp_lg_u64 %4, 0\n\t"             // SCC = open
-                         "s_cselect_b32 %3, 0, %5\n\t"
+            open_prev = open_cur;
+            open_cur = open;
+            asm volatile("v_cmp_eq_u32 vcc, %7, %8\n\t"          // t[n+1] == t[n-1]: period two
+                         "v_cmp_eq_u32_e64 %4, %7, %9\n\t"       // t[n+1] == t[n]:   fixed point
+                         "s_cmp_lg_u64 %5, 0\n\t"                // SCC = open
+                         "s_cselect_b32 %3, 0, %6\n\t"
                          "s_addc_u32 %0, %0, %0\n\t"
                          "s_andn2_b32 %1, %1, %3\n\t"
-                         "s_cmp_eq_u64 vcc, exec\n\t"         // SCC = every ray of the wave is periodic
+                         "s_or_b64 vcc, vcc, %4\n\t"
+                         "s_cmp_eq_u64 vcc, exec\n\t"            // SCC = every ray of the wave is periodic
                          "s_cselect_b32 %2, %1, %2\n\t"
                          "s_cselect_b32 %1, 0, %1"
-                         : "+s"(rmask), "+s"(left), "+s"(skipped), "=&s"(tmp)
-                         : "s"(open), "s"(amask), "v"(tn), "v"(tp) : "scc", "vcc");
+                         : "+s"(rmask), "+s"(left), "+s"(skipped), "=&s"(tmp), "=&s"(fixed)
+                         : "s"(open), "s"(amask), "v"(tn), "v"(tp), "v"(t) : "scc", "vcc");
             tp = __float_as_uint(t);
             t_odd = t;
         } else {
@@ -478,8 +484,12 @@ __device__ __forceinline__ bool newton_k(const Surf& s, const P& pol, const Ray&
         while (left > 0) trip(std::false_type{});
     }
     if (skipped > 0) {
-        // the open flags of the skipped trips: ...ABAB with A = the flag before last, B = the last
-        rmask = (rmask << skipped) | (((rmask & 3u) * 0x5555u) >> (16 - skipped));
+        // the open flags of the skipped trips alternate A, B, A, ...: B = the last flag (the state
+        // t[n]); A belongs to the state t[n+1], which a fixed-point ray shares with t[n] and a
+        // period-two ray with t[n-1]
+        const bool a_open = ((open_cur & fixed) | (open_prev & ~fixed)) != 0ull;
+        const uint32_t pat = (a_open ? 0xAAAAu : 0u) | ((rmask & 1u) ? 0x5555u : 0u);
+        rmask = (rmask << skipped) | (pat >> (16 - skipped));
         t = (skipped & 1) ? t_odd : t;
     }
     // trip j (0-based) -> bit j + 1.  n trips ran: cap, or in adaptive mode up to and including
