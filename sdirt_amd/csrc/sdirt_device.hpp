@@ -473,7 +473,7 @@ __device__ __forceinline__ bool newton_k(const Surf& s, const P& pol, const Ray&
         }
         t = tn;
     };
-    // the periodicity test costs three vector and four scalar instructions per trip: it is run
+    // the periodicity test costs four vector and five scalar instructions per trip: it is run
     // where it can pay, on tables longer than kPeriodicFrom trips (a wave-uniform choice of loop)
 #ifndef SDIRT_NO_PERIODIC_EXIT
     if (cap > kPeriodicFrom) {
