@@ -438,8 +438,11 @@ def main():
                          "kernel": "k_psf_lr<R,small-r,Lean,CENTER> (chief-ray pass + primary pass "
                                    "of a point in one workgroup)",
                          "algorithmic_bytes_per_launch": alg_bytes, "valu_issue": valu,
-                         "note": "scalar-per-ray fp32 math: the kernel is VALU-bound by "
-                                 "construction (~6.4 k VALU instr/ray vs 8.25 B/ray), DESIGN.md §3"},
+                         "note": "scalar-per-ray fp32 math: the kernel is bound by vector-instruction "
+                                 "issue by construction (%s VALU instr per traced ray vs %.2f "
+                                 "algorithmic bytes), DESIGN.md §3"
+                                 % ("%.0f" % (valu["wave_instructions_per_launch"] * 64 / (n_local * (SPP + 2048)))
+                                    if valu else "~5 k", alg_bytes / (n_local * (SPP + 2048)))},
         }
         if dt_ng is not None:
             res["value_no_gather"] = rays / dt_ng
