@@ -398,7 +398,11 @@ int sdirt_psfnet_mlp(const void* packed, const int32_t* widths, int32_t n_layers
     const float* b = reinterpret_cast<const float*>(static_cast<const char*>(packed) +
                                                     weights_bytes(widths, n_layers));
     const size_t lds = sizeof(_Float16) * kRows * kXStride;           // 133,120 B
-    auto kern = k_psfnet_mlp<6, 2>;      // 6 weight fragments, 2 sets of X fragments in flight
+#ifndef SDIRT_MLP_AD
+#define SDIRT_MLP_AD 6
+#define SDIRT_MLP_BD 2
+#endif
+    auto kern = k_psfnet_mlp<SDIRT_MLP_AD, SDIRT_MLP_BD>;   // 6 weight fragments, 2 sets of X fragments in flight
     HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int dev = 0, cus = 256;
     HIP_TRY(hipGetDevice(&dev));
