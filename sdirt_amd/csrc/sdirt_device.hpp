@@ -324,7 +324,7 @@ __device__ __forceinline__ void normalize3(float& x, float& y, float& z)
 // fp64, rounded once per term) -- the parity oracle evaluates the same expression.
 // the conic's constants as the Newton loop holds them: in VGPRs.  A vector instruction with an
 // SGPR source operand issues at 0.55x the rate of one with VGPR / inline-constant sources on
-// gfx950 (tools/newton_bench.hip: 2.65 vs 1.47 cycles per SIMD at 8 waves); six per trip against
+// gfx950 (tools/form_bench.hip: 4.2 vs 2.25 cycles per SIMD at 8 waves); six per trip against
 // four v_mov per surface.  (End to end the two forms time the same within run-to-run noise:
 // profiles/r02 kbench logs; SDIRT_CONIC_SGPR selects the SGPR form.)
 struct ConicV {

@@ -18,9 +18,10 @@ comments ("=>This Loop Header: Depth=N" / "in Loop: Header=BBx_y Depth=N") and c
   salu, smem (s_load), s_nop, s_waitcnt, branch, vmem, lds
 
 `simd_cyc` prices one pass through the block with the per-SIMD costs MEASURED on gfx950 at 8 waves
-per SIMD by tools/newton_bench.hip (profiles/r02/newton_bench.txt): valu 1.47, valu_s 2.65,
-cndmask_vcc 1.7, valu_trans 4.6, valu_f64 2.7, lane 2.65, salu 1.2, s_nop 0.9, branch 2, smem 1.2,
-s_waitcnt 1, vmem / lds 2 -- an estimate of SIMD issue time, not a latency.  The Newton loops are
+per SIMD by tools/form_bench.hip (profiles/r02/form_bench.txt): valu 2.25, valu_s / valu_f64 / lane 4.2,
+cndmask_vcc 2.25, valu_trans 8.2, salu / branch / smem / s_waitcnt 2.3, s_nop 1, vmem / lds 2.3 -- an UPPER
+estimate of SIMD issue time (in the product the half- and quarter-rate forms hide behind the other
+waves: 2.24 cycles per instruction of any kind), not a latency.  The Newton loops are
 the innermost loops of the surface loop; their rows are what VERDICT r01 item 3 asks to be tracked.
 """
 import argparse
@@ -33,8 +34,8 @@ TRANS = re.compile(r"^v_(rcp|rsq|sqrt|sin|cos|exp|log)_(f32|f16|legacy)")
 F64 = re.compile(r"^v_\w+_f64|^v_cvt_f64|^v_cvt_\w+_f64")
 
 
-COST = dict(valu=1.47, valu_s=2.65, cndmask_vcc=1.7, valu_trans=4.6, valu_f64=2.7, lane=2.65, salu=1.2,
-            smem=1.2, s_nop=0.9, s_waitcnt=1.0, branch=2.0, vmem=2.0, lds=2.0, barrier=2.0, other=1.0)
+COST = dict(valu=2.25, valu_s=4.2, cndmask_vcc=2.25, valu_trans=8.2, valu_f64=4.2, lane=4.2, salu=2.3,
+            smem=2.3, s_nop=1.0, s_waitcnt=2.3, branch=2.3, vmem=2.3, lds=2.3, barrier=2.3, other=2.3)
 SREG = re.compile(r"(?<![\w.])(s\d+|s\[\d+:\d+\]|vcc|exec)\b")
 
 

@@ -12,6 +12,15 @@
 #define P4 "v_mul_f32 %0, %0, %1\n\tv_add_f32 %0, %0, %2\n\tv_fma_f32 %0, %0, %1, %2\n\tv_mul_f32 %0, %0, %1\n\t"
 #define P16 P4 P4 P4 P4
 #define CMPSEL "v_cmp_lt_f32 vcc, %0, %1\n\ts_nop 1\n\tv_cndmask_b32 %0, %0, %2, vcc\n\t"
+// the same chain with every operation spelled as v_fma_f32: a*b = fma(a, b, -0), a+b = fma(a, 1, b)
+#define F4 "v_fma_f32 %0, %0, %1, %3\n\tv_fma_f32 %0, %0, 1.0, %2\n\tv_fma_f32 %0, %0, %1, %2\n\tv_fma_f32 %0, %0, %1, %3\n\t"
+#define F16 F4 F4 F4 F4
+#define M4 "v_mul_f32 %0, %0, %1\n\tv_mul_f32 %0, %0, %1\n\tv_mul_f32 %0, %0, %1\n\tv_mul_f32 %0, %0, %1\n\t"
+#define M16 M4 M4 M4 M4
+#define A4 "v_add_f32 %0, %0, %2\n\tv_add_f32 %0, %0, %2\n\tv_add_f32 %0, %0, %2\n\tv_add_f32 %0, %0, %2\n\t"
+#define A16 A4 A4 A4 A4
+#define MA4 "v_mul_f32 %0, %0, %1\n\tv_add_f32 %0, %0, %2\n\tv_mul_f32 %0, %0, %1\n\tv_add_f32 %0, %0, %2\n\t"
+#define MA16 MA4 MA4 MA4 MA4
 #define P14 P4 P4 P4 "v_mul_f32 %0, %0, %1\n\tv_add_f32 %0, %0, %2\n\t"
 #define P15 P4 P4 P4 "v_mul_f32 %0, %0, %1\n\tv_add_f32 %0, %0, %2\n\tv_fma_f32 %0, %0, %1, %2\n\t"
 
@@ -33,6 +42,10 @@ __global__ void __launch_bounds__(256) k_mix(int reps, float sc, float* sink, un
         if (KIND == 5) asm volatile(P4 P4 "v_rcp_f32 %0, %0\n\t" P4 CMPSEL "v_mul_f32 %0, %3, %0\n\t" P4 "s_add_u32 s40, s40, 1\n\t"
                                     P4 P4 "v_rcp_f32 %0, %0\n\t" P4 CMPSEL "v_mul_f32 %0, %3, %0\n\t" P4 "s_add_u32 s40, s40, 1\n\t"
                                     : "+v"(a) : "v"(c0), "v"(c1), "s"(sc) : "vcc", "s40", "scc");
+        if (KIND == 6) asm volatile(F16 F16 F16 F16 : "+v"(a) : "v"(c0), "v"(c1), "v"(-0.0f));
+        if (KIND == 7) asm volatile(M16 M16 M16 M16 : "+v"(a) : "v"(c0), "v"(c1));
+        if (KIND == 8) asm volatile(A16 A16 A16 A16 : "+v"(a) : "v"(c0), "v"(c1));
+        if (KIND == 9) asm volatile(MA16 MA16 MA16 MA16 : "+v"(a) : "v"(c0), "v"(c1));
     }
     const unsigned long long t1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
     if (threadIdx.x == 0 && blockIdx.x == gridDim.x / 2) { out[0] = t1 - t0; out[1] = r1 - r0; }
@@ -45,10 +58,12 @@ int main()
     CHECK(hipMalloc(&sink, sizeof(float) * 2048 * 256)); CHECK(hipMalloc(&d, 16));
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     const char* names[] = {"64 plain (mul/add/fma chain)", "56 plain + 4 x (v_cmp, s_nop 1, v_cndmask)", "60 plain + 4 SGPR-operand v_mul",
-                           "60 plain + 4 v_rcp_f32", "64 plain + 4 s_add_u32", "40 plain + 2 rcp + 2 cmp/sel + 2 sgpr-mul + 2 salu (a ray tracer's mix)"};
-    const int ninstr[] = {64, 64, 64, 64, 68, 52};
+                           "60 plain + 4 v_rcp_f32", "64 plain + 4 s_add_u32", "40 plain + 2 rcp + 2 cmp/sel + 2 sgpr-mul + 2 salu (a ray tracer's mix)",
+                           "the 64-instruction chain of line 1 with every operation spelled v_fma_f32", "64 dependent v_mul_f32", "64 dependent v_add_f32",
+                           "64 dependent, v_mul_f32 / v_add_f32 alternating"};
+    const int ninstr[] = {64, 64, 64, 64, 68, 52, 64, 64, 64, 64};
     const int reps = 60000;
-    for (int kind = 0; kind < 6; ++kind) {
+    for (int kind = 0; kind < 10; ++kind) {
         float ms = 0;
         for (int pass = 0; pass < 2; ++pass) {
             CHECK(hipEventRecord(e0));
@@ -59,6 +74,10 @@ int main()
             case 3: k_mix<3><<<2048, 256>>>(reps, 0.9999f, sink, d); break;
             case 4: k_mix<4><<<2048, 256>>>(reps, 0.9999f, sink, d); break;
             case 5: k_mix<5><<<2048, 256>>>(reps, 0.9999f, sink, d); break;
+            case 6: k_mix<6><<<2048, 256>>>(reps, 0.9999f, sink, d); break;
+            case 7: k_mix<7><<<2048, 256>>>(reps, 0.9999f, sink, d); break;
+            case 8: k_mix<8><<<2048, 256>>>(reps, 0.9999f, sink, d); break;
+            case 9: k_mix<9><<<2048, 256>>>(reps, 0.9999f, sink, d); break;
             }
             CHECK(hipEventRecord(e1)); CHECK(hipDeviceSynchronize()); CHECK(hipEventElapsedTime(&ms, e0, e1));
         }
