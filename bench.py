@@ -284,7 +284,7 @@ def main():
     step_no = [0]
     # output buffers are owned by the caller and re-used (the previous steps' PSFs may still be
     # feeding the all-gather / the consumer while the next step renders)
-    DEPTH = 3        # calls kept in flight (kernel enqueued, Newton trip check pending)
+    DEPTH = 8        # calls kept in flight (kernel enqueued, Newton trip check pending): ~80 ms of queued work
     out_bufs = [tuple(torch.empty((n_local, KS, KS), dtype=torch.float32, device=device)
                       for _ in range(2)) for _ in range(DEPTH + 1)]
 
@@ -404,7 +404,15 @@ def main():
                 # wave64 instruction per 2 cycles per SIMD (1024 SIMDs, 2.4 GHz); quarter-rate
                 # instructions (v_rcp / v_sqrt, ~6 % of the mix) make the reachable figure lower.
                 peak = 1024 * 2.4e9 / 2
+                n_all = n_instr + (counters.get("salu_wave_instructions_per_launch") or 0) \
+                    + (counters.get("smem_instructions_per_launch") or 0)
+                clk = counters.get("shader_clock_ghz") or 2.38
                 valu = {"wave_instructions_per_launch": n_instr,
+                        # every instruction, scalar ones included, takes an issue slot of its SIMD; a plain
+                        # fp32 vector instruction alone issues at 2.25 cycles per SIMD (tools/form_bench.hip)
+                        "all_instructions_per_launch": n_all,
+                        "cycles_per_instruction_per_simd": k_ms[dom] * 1e-3 * clk * 1e9 * 1024 / n_all,
+                        "plain_fp32_cycles_per_instruction": 2.25,
                         "achieved_per_s": n_instr / (k_ms[dom] * 1e-3), "peak_per_s": peak,
                         "frac": n_instr / (k_ms[dom] * 1e-3) / peak,
                         "source": {"kind": "carried: SQ_INSTS_VALU of a separate rocprofv3 --pmc run "
