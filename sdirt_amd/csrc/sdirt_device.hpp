@@ -99,6 +99,7 @@ struct Surf {
     __device__ __forceinline__ float d_plus_R() const { return __uint_as_float(b[0]); }
     __device__ __forceinline__ float eta() const { return __uint_as_float(b[1]); }
     __device__ __forceinline__ float eta2() const { return __uint_as_float(b[2]); }
+    __device__ __forceinline__ struct Poly poly(const DevSurface* blk) const;   // the asphere's polynomial block
 };
 
 // One surface's constants in flight: the two loads of its block plus the dword of the launch's
@@ -145,6 +146,12 @@ struct Poly {
     __device__ __forceinline__ float kai(int i) const { return __uint_as_float(w[8 + i]); }
 };
 struct NoPoly {};
+__device__ __forceinline__ Poly Surf::poly(const DevSurface* blk) const
+{
+    Poly p;
+    p.w = sload_block(&blk->p);
+    return p;
+}
 
 struct DevDpParams {
     float h, f, w, r;    // fp32 of the python floats        monte_carlo.py:157-164
@@ -336,14 +343,16 @@ __device__ __forceinline__ float to_vgpr(float s)
     asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(s));
     return v;
 }
-__device__ __forceinline__ ConicV conic_v(const Surf& s)
+template <class S>
+__device__ __forceinline__ ConicV conic_v(const S& s)
 {
     return ConicV{to_vgpr(s.c()), to_vgpr(s.c2()), to_vgpr(s.onepk()), to_vgpr(s.d())};
 }
 struct ConicS {      // the same constants straight from SGPRs (cold paths)
     float c, c2, onepk, d;
 };
-__device__ __forceinline__ ConicS conic_s(const Surf& s) { return ConicS{s.c(), s.c2(), s.onepk(), s.d()}; }
+template <class S>
+__device__ __forceinline__ ConicS conic_s(const S& s) { return ConicS{s.c(), s.c2(), s.onepk(), s.d()}; }
 
 template <class M, bool INSIDE, class C, bool UNITK = false>
 __device__ __forceinline__ void sag_g_dgd(const C& k, const NoPoly&, int, float r2, float& g, float& dgd)
@@ -356,8 +365,8 @@ __device__ __forceinline__ void sag_g_dgd(const C& k, const NoPoly&, int, float 
     dgd = M::div((onesf + M::div(a * 0.5f, sf)) * k.c, onesf * onesf);   // a/2 == a*0.5 exactly
 }
 
-template <class M, bool INSIDE, class C, bool UNITK = false>
-__device__ __forceinline__ void sag_g_dgd(const C& k, const Poly& pol, int deg, float r2, float& g, float& dgd)
+template <class M, bool INSIDE, class C, bool UNITK = false, class P = Poly>
+__device__ __forceinline__ void sag_g_dgd(const C& k, const P& pol, int deg, float r2, float& g, float& dgd)
 {
     sag_g_dgd<M, INSIDE, C, UNITK>(k, NoPoly{}, 0, r2, g, dgd);
     dgd = dgd + pol.ai(0);
@@ -382,8 +391,8 @@ __device__ __forceinline__ void sag_g_dgd(const C& k, const Poly& pol, int deg, 
 // mask_out (wave-uniform, lives in SGPRs) gets bit j set when ANY active lane of
 // the wave had |f(t)| > 50e-6 in trip j -- the per-wave share of the reference's
 // batch-wide `.any()` loop condition (surfaces.py:547).
-template <class M, bool KGT, class P, bool UNITK = false>
-__device__ __forceinline__ bool newton_k(const Surf& s, const P& pol, const Ray& r, int trips, float& t_out,
+template <class M, bool KGT, class P, bool UNITK = false, class S = Surf>
+__device__ __forceinline__ bool newton_k(const S& s, const P& pol, const Ray& r, int trips, float& t_out,
                                          uint32_t& mask_out)
 {
     using CV =
@@ -524,11 +533,11 @@ __device__ __forceinline__ bool newton_k(const Surf& s, const P& pol, const Ray&
 
 // surfaces.py:633-679 with _normal (:589-630).  FWD: rays travel +z (n negated,
 // eta = n1/n2); !FWD: backward tracing.
-template <bool FWD, class M, class P>
-__device__ __forceinline__ void refract(const Surf& s, const P& pol, Ray& r)
+template <bool FWD, class M, class P, class S>
+__device__ __forceinline__ void refract(const S& s, const P& pol, Ray& r)
 {
     float nx, ny, nz;
-    if (std::is_same<P, Poly>::value) {
+    if (!std::is_same<P, NoPoly>::value) {
         const float vf = r.ra > 0.0f ? 1.0f : 0.0f;
         const float xv = r.ox * vf, yv = r.oy * vf;
         float g, ds;
@@ -570,8 +579,8 @@ __device__ __forceinline__ void refract(const Surf& s, const P& pol, Ray& r)
 
 // Curved surface: Newton intersection, validity, refraction (surfaces.py:456-520).  `between` runs
 // after the intersection and before the refraction (the trace loop's prefetch of the next surface).
-template <bool FWD, class M, class P, class F>
-__device__ __forceinline__ uint32_t curved_reaction(const Surf& s, const P& pol, Ray& r, int trips, F between)
+template <bool FWD, class M, class P, class F, class S>
+__device__ __forceinline__ uint32_t curved_reaction(const S& s, const P& pol, Ray& r, int trips, F between)
 {
     uint32_t mask = 0;
     float t;
@@ -600,8 +609,8 @@ __device__ __forceinline__ uint32_t curved_reaction(const Surf& s, const P& pol,
 
 // Aspheric.ray_reaction, surfaces.py:391-520, on surface `blk` whose constants `s` are already in
 // registers.  Returns the Newton convergence mask of this wave on this surface (0 for planes).
-template <bool FWD, class M, class F>
-__device__ __forceinline__ uint32_t surface_reaction(const Surf& s, const DevSurface* __restrict__ blk,
+template <bool FWD, class M, class F, class S>
+__device__ __forceinline__ uint32_t surface_reaction(const S& s, const DevSurface* __restrict__ blk,
                                                      int trips, Ray& r, F between)
 {
     if (s.kind() == 0) {
@@ -614,11 +623,8 @@ __device__ __forceinline__ uint32_t surface_reaction(const Surf& s, const DevSur
         if (s.do_refract()) refract<FWD, M>(s, NoPoly{}, r);
         return 0;
     }
-    if (s.ai_degree() > 0) {                      // wave-uniform: the polynomial block is fetched
-        Poly pol;                                 // (one more round trip) on aspheres only
-        pol.w = sload_block(&blk->p);
-        return curved_reaction<FWD, M>(s, pol, r, trips, between);
-    }
+    if (s.ai_degree() > 0)                        // wave-uniform: the polynomial block is fetched
+        return curved_reaction<FWD, M>(s, s.poly(blk), r, trips, between);   // (one more round trip) on aspheres only
     return curved_reaction<FWD, M>(s, NoPoly{}, r, trips, between);
 }
 

@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <string>
 #include <vector>
 
 #include "../../include/sdirt_dp.h"
@@ -215,6 +216,10 @@ __device__ __forceinline__ void trace_ray(const DevSurface* __restrict__ lens, i
         k = kn;
     }
 }
+
+#ifdef SDIRT_SPEC_HEADER
+#include SDIRT_SPEC_HEADER        // per-prescription specialisation (tools/spec_build.py): SpecA*/SpecC* and trace_spec
+#endif
 
 // byte `off` of this kernel's argument segment
 __device__ __forceinline__ const void* kernarg_at(int off)
@@ -527,6 +532,10 @@ k_psf_lr(SplatBlock sb /* kernarg offset 0 */, TripSet trips /* 64 */, TripSet t
     constexpr int kTripsAt = 64, kTripsCAt = 64 + 64 * SDIRT_MAX_WAVELENGTHS;
     x2 += (int64_t)w * S; y2 += (int64_t)w * S;
     if (conv_mask) conv_mask += w * SDIRT_MAX_SURFACES;
+#ifdef SDIRT_SPEC_HEADER
+    const u32x16 spec_tw = sload_block(kernarg_at(kTripsAt + 64 * w));       // both trip tables, once per workgroup
+    const u32x16 spec_tw_c = sload_block(kernarg_at(kTripsCAt + 64 * w));
+#endif
     if (CENTER) {
         ca.xc += (int64_t)w * ca.Sc; ca.yc += (int64_t)w * ca.Sc;
         ca.center_out += (int64_t)w * N * 2;
@@ -551,8 +560,12 @@ k_psf_lr(SplatBlock sb /* kernarg offset 0 */, TripSet trips /* 64 */, TripSet t
         int any = 0;
         for (int s = threadIdx.x; s < ca.Sc; s += blockDim.x) {
             Ray r = make_ray<HotMath>(px, py, pzo, ca.xc[s], ca.yc[s], pz);
+#ifdef SDIRT_SPEC_HEADER
+            trace_spec<true, HotMath>(spec_tw_c, r, ca.conv_mask_c ? lds_mask : nullptr);
+#else
             trace_ray<true, HotMath>(ca.lens_c, 0, K, kernarg_at(kTripsCAt + 64 * w), r,
                                      ca.conv_mask_c ? lds_mask : nullptr);
+#endif
             propagate_to<HotMath>(r, zs);
             sx += (double)(r.ox * r.ra);
             sy += (double)(r.oy * r.ra);
@@ -625,7 +638,11 @@ k_psf_lr(SplatBlock sb /* kernarg offset 0 */, TripSet trips /* 64 */, TripSet t
     };
     for (int s = j * chunk + threadIdx.x; s < s_end; s += blockDim.x) {
         Ray r = make_ray<HotMath>(px, py, pzo, x2[s], y2[s], pz);
+#ifdef SDIRT_SPEC_HEADER
+        trace_spec<false, HotMath>(spec_tw, r, conv_mask ? lds_mask : nullptr);
+#else
         trace_ray<true, HotMath>(lens, 0, K, kernarg_at(kTripsAt + 64 * w), r, conv_mask ? lds_mask : nullptr);
+#endif
         propagate_to<HotMath>(r, zs);
         splat(r.ox, r.oy, r.dx, r.dz, r.ra);
     }
@@ -1796,6 +1813,78 @@ void sdirt_lens_destroy(sdirt_lens* lens)
 }
 
 int32_t sdirt_lens_num_surfaces(const sdirt_lens* lens) { return lens ? lens->n_surfaces : 0; }
+
+// Source of the per-prescription specialisation of the fused kernel: the constants of the two
+// device tables (primary wavelength, chief-ray wavelength) as literals, one accessor type per
+// surface with the interface of sdirt::Surf, and trace_spec<CHIEF>() = the surface loop unrolled.
+// The text is compiled by tools/spec_build.py (-DSDIRT_SPEC_HEADER=...) into a library whose
+// fused kernel is valid for THIS prescription only.  Returns the length of the text (written if
+// it fits `cap`).
+static void emit_surface(std::string& o, const char* tag, int k, const DevSurface& d)
+{
+    char b[256];
+    auto u = [](float f) { uint32_t v; std::memcpy(&v, &f, 4); return v; };
+    const SurfHot& h = d.h;
+    const int deg = (int)((h.flags >> 8) & 15u);
+    snprintf(b, sizeof b, "struct Spec%sP%d {\n", tag, k); o += b;
+    for (const char* nm : {"ai", "kai"}) {
+        snprintf(b, sizeof b, "    __device__ __forceinline__ float %s(int i) const {\n        switch (i) {\n", nm); o += b;
+        for (int i = 0; i < kMaxAi; ++i) {
+            snprintf(b, sizeof b, "        case %d: return __uint_as_float(0x%08xu);\n", i,
+                     u(nm[0] == 'a' ? d.p.ai[i] : d.p.kai[i]));
+            o += b;
+        }
+        o += "        default: return 0.0f;\n        }\n    }\n";
+    }
+    o += "};\n";
+    snprintf(b, sizeof b, "struct Spec%sS%d {\n    static constexpr uint32_t kF = 0x%xu;\n", tag, k, h.flags); o += b;
+    o += "    __device__ __forceinline__ int kind() const { return (int)(kF & 3u); }\n"
+         "    __device__ __forceinline__ int ai_degree() const { return (int)((kF >> 8) & 15u); }\n"
+         "    __device__ __forceinline__ bool do_refract() const { return (kF & kFlagRefract) != 0u; }\n"
+         "    __device__ __forceinline__ bool k_gt_m1() const { return (kF & kFlagKgtM1) != 0u; }\n"
+         "    __device__ __forceinline__ bool c_pos() const { return (kF & kFlagCpos) != 0u; }\n"
+         "    __device__ __forceinline__ bool unit_k() const { return (kF & kFlagUnitK) != 0u; }\n";
+    const struct { const char* n; float v; } f[] = {
+        {"d", h.d}, {"c", h.c}, {"c2", h.c2}, {"onepk", h.onepk}, {"lim_loose", h.lim_loose}, {"r2_lim", h.r2_lim},
+        {"lim_tight", h.lim_tight}, {"r_lim", h.lim_tight}, {"d_plus_R", h.d_plus_R}, {"eta", h.eta_f}, {"eta2", h.eta2_f}};
+    for (const auto& e : f) {
+        snprintf(b, sizeof b, "    __device__ __forceinline__ float %s() const { return __uint_as_float(0x%08xu); }\n", e.n, u(e.v));
+        o += b;
+    }
+    snprintf(b, sizeof b, "    __device__ __forceinline__ Spec%sP%d poly(const DevSurface*) const { return Spec%sP%d{}; }\n};\n",
+             tag, k, tag, k);
+    o += b;
+    (void)deg;
+}
+
+int64_t sdirt_emit_spec(const sdirt_surface_desc* primary, const sdirt_surface_desc* center, int32_t K, char* out,
+                        int64_t cap)
+{
+    if (!primary || !center || K < 1 || K > SDIRT_MAX_SURFACES) return -1;
+    struct { std::vector<DevSurface> host; } l_, c_;
+    for (int k = 0; k < K; ++k) { l_.host.push_back(make_dev_surface(primary[k])); c_.host.push_back(make_dev_surface(center[k])); }
+    const auto *lens = &l_, *lens_center = &c_;
+    std::string o = "// generated by sdirt_lens_emit_spec: do not edit\nnamespace sdirt {\n";
+    for (int k = 0; k < K; ++k) emit_surface(o, "A", k, lens->host[k]);
+    for (int k = 0; k < K; ++k) emit_surface(o, "C", k, lens_center->host[k]);
+    o += "constexpr int kSpecSurfaces = " + std::to_string(K) + ";\n"
+         "// the surface loop of trace_ray, unrolled: tw = the launch's trip table (one signed byte per surface)\n"
+         "template <bool CHIEF, class M>\n"
+         "__device__ __forceinline__ void trace_spec(const u32x16& tw, Ray& r, uint32_t* lds_mask)\n{\n"
+         "    uint32_t m;\n";
+    char b[512];
+    for (int k = 0; k < K; ++k) {
+        snprintf(b, sizeof b,
+                 "    if (CHIEF) m = surface_reaction<true, M>(SpecCS%d{}, nullptr, (int)(int8_t)(tw[%d] >> %d), r, [] {});\n"
+                 "    else m = surface_reaction<true, M>(SpecAS%d{}, nullptr, (int)(int8_t)(tw[%d] >> %d), r, [] {});\n"
+                 "    if (lds_mask && m != 0u) ::lds_or_first_lane(&lds_mask[%d], m);\n",
+                 k, k >> 2, (k & 3) * 8, k, k >> 2, (k & 3) * 8, k);
+        o += b;
+    }
+    o += "}\n}  // namespace sdirt\n";
+    if (out && (int64_t)o.size() + 1 <= cap) std::memcpy(out, o.c_str(), o.size() + 1);
+    return (int64_t)o.size() + 1;
+}
 
 int sdirt_points_to_object(const float* points, int64_t N, double tan_hfov, double r_last,
                            double sensor_w, double sensor_h, float* point_obj, void* stream)
