@@ -408,10 +408,10 @@ def main():
                     + (counters.get("smem_instructions_per_launch") or 0)
                 clk = counters.get("shader_clock_ghz") or 2.38
                 valu = {"wave_instructions_per_launch": n_instr,
-                        # every instruction, scalar ones included, takes an issue slot of its SIMD; a plain
-                        # fp32 vector instruction alone issues at 2.25 cycles per SIMD (tools/form_bench.hip)
+                        # SIMD cycles per VECTOR instruction; a plain fp32 one costs 2.25, compares / SGPR-operand
+                        # forms 4.2, v_rcp 8-13 (tools/form_bench.hip); scalar instructions run beside them
                         "all_instructions_per_launch": n_all,
-                        "cycles_per_instruction_per_simd": k_ms[dom] * 1e-3 * clk * 1e9 * 1024 / n_all,
+                        "cycles_per_vector_instruction_per_simd": k_ms[dom] * 1e-3 * clk * 1e9 * 1024 / n_instr,
                         "plain_fp32_cycles_per_instruction": 2.25,
                         "achieved_per_s": n_instr / (k_ms[dom] * 1e-3), "peak_per_s": peak,
                         "frac": n_instr / (k_ms[dom] * 1e-3) / peak,
