@@ -118,6 +118,15 @@ int sdirt_lens_create(const sdirt_surface_desc* surfaces /*host*/, int32_t n_sur
 void sdirt_lens_destroy(sdirt_lens* lens);
 int32_t sdirt_lens_num_surfaces(const sdirt_lens* lens);
 
+/* EXPERIMENTAL (tools/spec_build.py): C++ source of the fused kernel's trace
+ * specialised for one prescription -- the constants of the two tables (primary wavelength /
+ * chief-ray wavelength, K surfaces each) as literals, the surface loop unrolled.  Host only, no
+ * device needed.  Returns the length of the text including its terminating NUL (written to
+ * `out` if cap is large enough), or -1 for bad arguments. */
+int64_t sdirt_emit_spec(const sdirt_surface_desc* primary /*host [K]*/,
+                        const sdirt_surface_desc* center /*host [K]*/, int32_t n_surfaces,
+                        char* out, int64_t cap);
+
 /* ---- staged path (same decomposition as the reference) ------------------ */
 
 /* Lensgroup.psf_diff, deeplens/optics.py:956-960 + calc_scale_pinhole :1302-1306:

@@ -34,9 +34,7 @@ def main():
     arr_t = _lib.SurfaceDesc * K
     prim = arr_t(*[s.desc(args.wvln) for s in lens.surfaces])
     cen = arr_t(*[s.desc(DEFAULT_WAVE) for s in lens.surfaces])
-    h = C.CDLL(_lib.LIB_PATH)
-    h.sdirt_emit_spec.restype = C.c_int64
-    h.sdirt_emit_spec.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_char_p, C.c_int64]
+    h = _lib.lib()
     n = h.sdirt_emit_spec(prim, cen, K, None, 0)
     assert n > 0, n
     buf = C.create_string_buffer(n)
