@@ -337,7 +337,7 @@ def main():
             ready = torch.cuda.Event()
             ready.record(torch.cuda.current_stream(device))
         in_flight.append((pend, out, slot, ready))
-        settle(keep=1 if gather else DEPTH)
+        settle(keep=3 if gather else DEPTH)   # gathers trail by three steps: a host hiccup on one rank stalls nobody
         return out
 
     def fence():
