@@ -132,6 +132,38 @@ def main():
           " max |dcentre| %.2e" % np.abs(c["center"] - d["center"]).max())
     gg.save(os.path.abspath(args.out), "f14_rf50_mini_c2_rays", d)
 
+    # F20 = the same hand-off on rf35mm (21 surfaces, stop at index 7, an even asphere): 12 of the
+    # 27 points, 4096 spp, ks 65, with the correctly-rounded-math re-run
+    rf35 = gg.build_lens("rf35mm")
+    with open(os.path.join(args.out, "lens_state_rf35mm.json")) as f:
+        st35 = json.load(f)
+    assert st35["d_sensor"] == float(rf35.d_sensor) and st35["hfov"] == float(rf35.hfov)
+
+    def frozen35(M=32, entrance=True, shrink_pupil=False):
+        z, r = (st35["pupil_z"], st35["pupil_r"]) if entrance else (st35["exit_pupil_z"], st35["exit_pupil_r"])
+        return z, (r * 0.25 if shrink_pupil else r)
+    rf35.entrance_pupil = frozen35
+    pts35 = f8["points"][::2][:12].tolist()
+
+    def case35():
+        d_ = gg.run_psf_case(rf35, pts35, ks=65, spp=4096, wvln=0.589, seed=20,
+                             param_list=gg.DP_DEFAULT + ["l"], full=True)
+        return dict(points=d_["points"], point_obj=d_["ray_o0"][0], ray_d0=d_["ray_d0"], cen_d0=d_["cen_d0"],
+                    trips=d_["trips"], trips_center=d_["trips_center"], center=d_["center"], psf=d_["psf"],
+                    grid_r=d_["grid_r"], ks=d_["ks"], spp=d_["spp"], seed=d_["seed"])
+    d35 = gg.twice(case35)
+
+    def case35_cr():
+        with CorrectlyRoundedInsideTraceAndSplat():
+            return case35()
+    c35 = gg.twice(case35_cr)
+    assert np.array_equal(c35["ray_d0"], d35["ray_d0"])
+    for k in ("trips", "trips_center", "center", "psf", "grid_r"):
+        d35[k + "_cr"] = c35[k]
+    print("rf35mm, plain vs correctly-rounded-math reference: trips equal", np.array_equal(c35["trips"], d35["trips"]),
+          " max |dPSF_L| %.2e" % np.abs(c35["psf"] - d35["psf"]).max())
+    gg.save(os.path.abspath(args.out), "f20_rf35_handoff_rays", d35)
+
     # F15 = forward_integral WITHOUT a reference centre (pointc_ref=None -> the RMS centre of the
     # rays themselves, monte_carlo.py:27-31) on synthetic sensor-plane rays, both DP outputs
     def rms_centre():

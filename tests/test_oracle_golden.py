@@ -203,8 +203,11 @@ def test_torch_port_follows_the_reference(oracle, lens_name, fx):
     assert np.abs(L2.numpy() - lo).max() < 3e-3 and np.abs(R2.numpy() - ro).max() < 3e-3
 
 
-def _f14_oracle(oracle, centre_key):
-    st, g = load_state("rf50mm"), load_golden("f14_rf50_mini_c2_rays")
+HANDOFF = {"rf50mm": "f14_rf50_mini_c2_rays", "rf35mm": "f20_rf35_handoff_rays"}
+
+
+def _f14_oracle(oracle, centre_key, lens="rf50mm"):
+    st, g = load_state(lens), load_golden(HANDOFF[lens])
     ks = int(g["ks"])
     S, N = g["ray_d0"].shape[:2]
     surf = oracle.surfaces_from_state(st, 0.589)
@@ -216,23 +219,24 @@ def _f14_oracle(oracle, centre_key):
     return g, oracle.psf_normalize(lg), oracle.psf_normalize(rg)
 
 
-def test_ray_handoff_against_the_reference_with_correctly_rounded_math(oracle):
-    """Fixture F14: the reference's own post-normalise rays of the 3x3x3 / 4096 spp / ks 65 volume go
+@pytest.mark.parametrize("lens", ["rf50mm", "rf35mm"])
+def test_ray_handoff_against_the_reference_with_correctly_rounded_math(oracle, lens):
+    """Fixtures F14 (rf50mm) and F20 (rf35mm: 21 surfaces, an even asphere; 12 points): the reference's own post-normalise rays of the 3x3x3 / 4096 spp / ks 65 volume go
     in; trace -> propagate -> splat -> normalise is the oracle's.
 
     Against the reference as it runs (MKL VML sqrt / acos / sin, < 1 ulp but not correctly
     rounded): 2.9e-5 of the PSF peak.  Against the SAME reference code with those functions
     correctly rounded (`*_cr`, oracle/gen_golden_handoff.py): 2.4e-7 -- the whole distance is the
     math library's last bit, which also moves the reference away from ITSELF by 2.9e-5."""
-    g, L, R = _f14_oracle(oracle, "center_cr")
+    g, L, R = _f14_oracle(oracle, "center_cr", lens)
     assert np.abs(L - g["psf_cr"]).max() <= 1e-6
     assert np.abs(R - oracle.psf_normalize(g["grid_r_cr"])).max() <= 1e-6
-    g, L, R = _f14_oracle(oracle, "center")
+    g, L, R = _f14_oracle(oracle, "center", lens)
     d_plain = np.abs(L - g["psf"]).max()
     d_self = np.abs(g["psf_cr"] - g["psf"]).max()
     assert d_plain <= 4e-5 and d_plain <= 1.05 * d_self            # no farther than the reference from itself
     # chief-ray pass from the reference's own chief rays
-    st = load_state("rf50mm")
+    st = load_state(lens)
     Sc, N = g["cen_d0"].shape[:2]
     oc = np.broadcast_to(g["point_obj"][None], (Sc, N, 3)).copy()
     out = oracle.trace(oracle.surfaces_from_state(st, 0.589), oc, g["cen_d0"], np.ones((Sc, N), np.float32))
