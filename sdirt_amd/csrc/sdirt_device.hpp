@@ -26,14 +26,15 @@ constexpr float kNewtonStepBound = 5.0f;   // deeplens/surfaces.py:29
 
 // ---------------------------------------------------------------------------
 // Per-surface constants in device memory: two 64-byte blocks per surface, laid out for the
-// scalar unit.  A wave reads block `h` with ONE s_load_dwordx16 per surface (into 16 SGPRs:
-// no VGPRs, no LDS bandwidth) and block `p` with one more on aspheres only.  Every field the
+// scalar unit.  A wave reads the 12 dwords of block `h` it needs with one scalar round trip per
+// surface (Surf / surf_issue below: into SGPRs, no VGPRs, no LDS bandwidth) and block `p` with one
+// more on aspheres only.  Every field the
 // reference obtains by rounding a Python/numpy float64 to fp32 at the point of use is rounded on
 // the host, once, in sdirt_lens_create (sdirt_dp.hip: make_dev_surface).
 // ---------------------------------------------------------------------------
 struct alignas(64) SurfHot {
     uint32_t flags;      // bits 0-1 kind (0 plane, 1 sphere, 2 asphere) | 2 do_refract (plane: eta != 1,
-                         // surfaces.py:450) | 3 k > -1 (:727,738) | 4 c > 0 | 8-11 ai_degree
+                         // surfaces.py:450) | 3 k > -1 (:727,738) | 4 c > 0 | 5 1 + k == 1 | 8-11 ai_degree
     float d, c;
     float c2;            // c*c (fp32)
     float onepk;         // 1 + k
