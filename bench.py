@@ -50,21 +50,34 @@ WORKLOADS = {
     "c2": dict(lens="rf50mm", ks=65, spp=4096, grid_z=16, sensor_z=62.25,
                desc="rf50mm 32x32x{gz} (x,y,z) PSF volume"),
     "c3": dict(lens="rf50mm", ks=21, spp=8192, grid_z=64, sensor_z=62.25,
-               desc="rf50mm dense PSFNet grid 32x32x{gz} (8 shards of 8192 points on a node)"),
+               desc="rf50mm dense PSFNet grid 32x32x{gz}, Gaussian-warped depth planes around the 1 m "
+                    "focal plane (psfnet.py:229-232) (8 shards of 8192 points on a node)"),
     "c4": dict(lens="rf35mm", ks=65, spp=4096, grid_z=16, sensor_z=80.447,
                desc="rf35mm (21 surfaces) 32x32x{gz} PSF volume"),
 }
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s HBM3E
 
 
-def volume_points(world):
-    """The reference's test grid (psfnet.py:220-226) x depths z2depth(linspace(0,1))
-    (psfnet.py:36-37,724-726): [32*32*16*world, 3], z-major so that a rank's
-    contiguous shard is a slab of depth planes."""
+FOC_Z_RF50 = (-1000.0 + 62.25 - (-200.0)) / (-20000.0 - (-200.0))   # psfnet.py:50-51, foc_z_arr[1]
+
+
+def volume_points(world, workload="c2"):
+    """The reference's test grid (psfnet.py:220-226) x depths z2depth(z) (psfnet.py:36-37,
+    724-726): [32*32*GRID_Z*world, 3], z-major so that a rank's contiguous shard is a slab of
+    depth planes.  c2 / c4: z = linspace(0, 1).  c3 (the PSFNet evaluation grid): the
+    reference's Gaussian-warped spacing around the focal plane (psfnet.py:229-232,
+    foc_z = foc_z_arr[1]) -- planes crowd around 1 m, where the PSF changes fastest."""
     g = GRID_XY
+    nz = (8 if workload == "c3" else WORKLOADS[workload]["grid_z"]) * world
     x, y = torch.meshgrid(torch.linspace(-1 + 1 / (2 * g), 1 - 1 / (2 * g), g),
                           torch.linspace(1 - 1 / (2 * g), -1 + 1 / (2 * g), g), indexing="xy")
-    z = torch.linspace(0, 1, GRID_Z * world)
+    if workload == "c3":
+        z_gauss = torch.linspace(-3, 3, nz)
+        z = torch.zeros_like(z_gauss)
+        z[z_gauss > 0] = (1 - FOC_Z_RF50) * z_gauss[z_gauss > 0] / 3 + FOC_Z_RF50
+        z[z_gauss < 0] = FOC_Z_RF50 * z_gauss[z_gauss < 0] / 3 + FOC_Z_RF50
+    else:
+        z = torch.linspace(0, 1, nz)
     depth = z * (-20000.0 - (-200.0)) + (-200.0)
     pts = torch.stack([x.reshape(1, -1).expand(len(z), -1), y.reshape(1, -1).expand(len(z), -1),
                        depth.reshape(-1, 1).expand(-1, g * g)], dim=-1)
@@ -263,7 +276,7 @@ def main():
 
     from sdirt_amd import dist as sd
     lens = build_lens(device, wl["lens"], wl["sensor_z"])
-    points_all = volume_points(world)
+    points_all = volume_points(world, args.workload)
     n_total = points_all.shape[0]
     a, b = sd.shard_bounds(n_total, world)[rank]
     points_local = points_all[a:b].to(device)

@@ -101,6 +101,13 @@ typedef struct sdirt_dp_params {
  * instead of inf, denormal operands are not handled.  No valid ray produces such operands.
  * This flag selects the compiler's full-range IEEE sequences instead (~1.26x slower). */
 #define SDIRT_PSF_STRICT_IEEE 4u
+/* sdirt_trace only: read every surface's constants with a plain load-and-wait at the top of the
+ * surface instead of the hand-scheduled prefetch one surface ahead (sdirt_device.hpp: surf_issue /
+ * surf_wait).  Same arithmetic, hence bit-identical rays: the binding traces a probe bundle both
+ * ways when it first uploads a prescription and refuses to go on if they differ (a miscompiled
+ * prefetch would trace with stale constants -- the build-time ISA check is the first guard,
+ * this is the second). */
+#define SDIRT_TRACE_NO_PREFETCH 8u
 
 /* ---- library ------------------------------------------------------------ */
 int sdirt_abi_version(void);
@@ -117,15 +124,6 @@ int sdirt_lens_create(const sdirt_surface_desc* surfaces /*host*/, int32_t n_sur
                       sdirt_lens** out_lens);
 void sdirt_lens_destroy(sdirt_lens* lens);
 int32_t sdirt_lens_num_surfaces(const sdirt_lens* lens);
-
-/* EXPERIMENTAL (tools/spec_build.py): C++ source of the fused kernel's trace
- * specialised for one prescription -- the constants of the two tables (primary wavelength /
- * chief-ray wavelength, K surfaces each) as literals, the surface loop unrolled.  Host only, no
- * device needed.  Returns the length of the text including its terminating NUL (written to
- * `out` if cap is large enough), or -1 for bad arguments. */
-int64_t sdirt_emit_spec(const sdirt_surface_desc* primary /*host [K]*/,
-                        const sdirt_surface_desc* center /*host [K]*/, int32_t n_surfaces,
-                        char* out, int64_t cap);
 
 /* ---- staged path (same decomposition as the reference) ------------------ */
 
@@ -179,8 +177,8 @@ int sdirt_rays_to_aos(sdirt_rays rays, int64_t n_rays, float* o /*dev [M,3] or N
  * wave instead of per batch; no host check is needed, results differ from the batch-exact ones
  * in the low-order bits of t (PSFs to ~1e-5 of their peak). */
 int sdirt_trace(const sdirt_lens* lens, int32_t first, int32_t last, int32_t backward,
-                const int32_t* trips /*host [K]*/, uint32_t flags /*SDIRT_PSF_STRICT_IEEE or 0*/,
-                sdirt_rays rays, int64_t n_rays, uint32_t* conv_mask /*dev [K] or NULL*/,
+                const int32_t* trips /*host [K]*/,
+                uint32_t flags /*SDIRT_PSF_STRICT_IEEE | SDIRT_TRACE_NO_PREFETCH or 0*/, sdirt_rays rays, int64_t n_rays, uint32_t* conv_mask /*dev [K] or NULL*/,
                 void* stream);
 
 /* Ray.propagate_to, deeplens/basics.py:256-264. */

@@ -176,21 +176,28 @@ def psf_normalize(psf):
 
 
 def psf(state, points, x2, y2, xc, yc, ks, wvln=0.589, dp=None, normalize=True,
-        center_wvln=0.589):
-    """End-to-end psf_diff on explicit pupil samples -> (L, R, centre, ok)."""
+        center_wvln=0.589, return_trips=False):
+    """End-to-end psf_diff on explicit pupil samples -> (L, R, centre, ok); with return_trips
+    also the batch-global Newton trip tables (primary, chief-ray) the reference's loop
+    (surfaces.py:547) runs on this batch."""
     surf = surfaces_from_state(state, wvln)
     surf_c = surfaces_from_state(state, center_wvln)
     po = points_to_object(points, state)
     x2, y2, xc, yc = _f32(x2), _f32(y2), _f32(xc), _f32(yc)
-    N = len(po)
+    N, K = len(po), len(surf)
     cen = np.empty((N, 2), np.float32)
     lg = np.empty((N, ks, ks), np.float32); rg = np.empty((N, ks, ks), np.float32)
-    lib().or_psf.restype = C.c_int
-    ok = lib().or_psf(surf, surf_c, C.c_int(len(surf)), _fp(po), C.c_int64(N), _fp(x2), _fp(y2),
-                      C.c_int64(len(x2)), _fp(xc), _fp(yc), C.c_int64(len(xc)),
-                      C.c_double(state["pupil_z"]), C.c_double(state["d_sensor"]),
-                      C.c_double(state["pixel_size"]), C.c_int(ks), _dp(dp),
-                      C.c_int(1 if normalize else 0), _fp(cen), _fp(lg), _fp(rg))
+    tp, tc = np.zeros(K, np.int32), np.zeros(K, np.int32)
+    i32 = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
+    lib().or_psf_trips.restype = C.c_int
+    ok = lib().or_psf_trips(surf, surf_c, C.c_int(K), _fp(po), C.c_int64(N), _fp(x2), _fp(y2),
+                            C.c_int64(len(x2)), _fp(xc), _fp(yc), C.c_int64(len(xc)),
+                            C.c_double(state["pupil_z"]), C.c_double(state["d_sensor"]),
+                            C.c_double(state["pixel_size"]), C.c_int(ks), _dp(dp),
+                            C.c_int(1 if normalize else 0), _fp(cen), _fp(lg), _fp(rg),
+                            i32(tp), i32(tc))
+    if return_trips:
+        return lg, rg, cen, bool(ok), tp, tc
     return lg, rg, cen, bool(ok)
 
 

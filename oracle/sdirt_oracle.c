@@ -630,10 +630,11 @@ void or_psf_normalize(int64_t N, int ks, float* psf)
  * [N][ks][ks] and the centres [N][2].  surf_c: surface table at the centre
  * wavelength (optics.py:900 always uses DEFAULT_WAVE).  Returns 0 on the
  * reference's 'No sampled rays is valid.' assertion. */
-int or_psf(const or_surface* surf, const or_surface* surf_c, int K, const float* point_obj,
-           int64_t N, const float* x2, const float* y2, int64_t S, const float* xc,
-           const float* yc, int64_t Sc, double pupil_z, double d_sensor, double ps, int ks,
-           const double* dp, int normalize, float* center, float* l_grid, float* r_grid)
+int or_psf_trips(const or_surface* surf, const or_surface* surf_c, int K, const float* point_obj,
+                 int64_t N, const float* x2, const float* y2, int64_t S, const float* xc,
+                 const float* yc, int64_t Sc, double pupil_z, double d_sensor, double ps, int ks,
+                 const double* dp, int normalize, float* center, float* l_grid, float* r_grid,
+                 int32_t* trips_primary, int32_t* trips_center)
 {
     int64_t Mm = S > Sc ? S : Sc;
     Mm *= N;
@@ -641,12 +642,16 @@ int or_psf(const or_surface* surf, const or_surface* surf_c, int K, const float*
     float* d = (float*)malloc(sizeof(float) * Mm * 3);
     float* ra = (float*)malloc(sizeof(float) * Mm);
     float* ob = (float*)malloc(sizeof(float) * Mm);
+    /* trips_*: [K] out, the batch-global Newton trip counts the reference's loop runs on THIS
+     * batch (surfaces.py:547) -- what a speculate-and-verify implementation must land on */
+    if (trips_center) for (int k = 0; k < K; ++k) trips_center[k] = -1;
+    if (trips_primary) for (int k = 0; k < K; ++k) trips_primary[k] = -1;
     or_sample_rays(point_obj, N, xc, yc, Sc, pupil_z, o, d, ra, ob);
-    or_trace(surf_c, 0, K, Sc * N, o, d, ra, ob, NULL, NULL, NULL, NULL);
+    or_trace(surf_c, 0, K, Sc * N, o, d, ra, ob, trips_center, NULL, NULL, NULL);
     or_propagate_to(d_sensor, Sc * N, o, d);
     int ok = or_center_from_rays(Sc, N, o, ra, center);
     or_sample_rays(point_obj, N, x2, y2, S, pupil_z, o, d, ra, ob);
-    or_trace(surf, 0, K, S * N, o, d, ra, ob, NULL, NULL, NULL, NULL);
+    or_trace(surf, 0, K, S * N, o, d, ra, ob, trips_primary, NULL, NULL, NULL);
     or_propagate_to(d_sensor, S * N, o, d);
     or_forward_integral(S, N, o, d, ra, ps, ks, center, dp, l_grid, r_grid);
     if (normalize) {
@@ -655,6 +660,15 @@ int or_psf(const or_surface* surf, const or_surface* surf_c, int K, const float*
     }
     free(o); free(d); free(ra); free(ob);
     return ok;
+}
+
+int or_psf(const or_surface* surf, const or_surface* surf_c, int K, const float* point_obj,
+           int64_t N, const float* x2, const float* y2, int64_t S, const float* xc,
+           const float* yc, int64_t Sc, double pupil_z, double d_sensor, double ps, int ks,
+           const double* dp, int normalize, float* center, float* l_grid, float* r_grid)
+{
+    return or_psf_trips(surf, surf_c, K, point_obj, N, x2, y2, S, xc, yc, Sc, pupil_z, d_sensor, ps,
+                        ks, dp, normalize, center, l_grid, r_grid, NULL, NULL);
 }
 
 int or_num_threads(void)

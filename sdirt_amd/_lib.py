@@ -18,6 +18,7 @@ MAX_KS = 141
 MAX_WAVELENGTHS = 3
 PSF_NORMALIZE = 1
 PSF_STRICT_IEEE = 4
+TRACE_NO_PREFETCH = 8
 
 KIND_PLANE, KIND_SPHERE, KIND_ASPHERE = 0, 1, 2
 
@@ -53,7 +54,6 @@ SIGNATURES = {
     "sdirt_lens_create": (C.c_int, [C.POINTER(SurfaceDesc), _I32, C.POINTER(_P)]),
     "sdirt_lens_destroy": (None, [_P]),
     "sdirt_lens_num_surfaces": (_I32, [_P]),
-    "sdirt_emit_spec": (_I64, [_P, _P, _I32, C.c_char_p, _I64]),
     "sdirt_points_to_object": (C.c_int, [_P, _I64, _D, _D, _D, _D, _P, _P]),
     "sdirt_pupil_samples": (C.c_int, [_P, _P, _I64, _D, _P, _P, _P]),
     "sdirt_sample_rays": (C.c_int, [_P, _I64, _P, _P, _I64, _D, Rays, _P]),

@@ -240,15 +240,11 @@ struct Lean {
     }
     static __device__ __forceinline__ float sqrt_pos(float x)
     {
-#ifdef SDIRT_NO_RSQ_SQRT
-        return sqrt(x);
-#else
         const float r = __builtin_amdgcn_rsqf(x);
         const float s = x * r;
         const float h = 0.5f * r;
         const float d = __builtin_fmaf(-s, s, x);            // exact residual of the 1-ulp estimate
         return __builtin_fmaf(d, h, s);
-#endif
     }
     // div() in two halves: div(a, b) == div_y(a, b, recip(b)).  (The seed must be v_rcp_f32(b):
     // seeding the Newton step from a related quantity instead -- the square root's own
@@ -397,19 +393,11 @@ __device__ __forceinline__ bool newton_k(const S& s, const P& pol, const Ray& r,
                                          uint32_t& mask_out)
 {
     using CV =
-#ifdef SDIRT_CONIC_SGPR
-        ConicS;
-#else
         ConicV;
-#endif
     const bool adaptive = trips < 0;
     const int cap = adaptive ? -trips : trips;
     const float tol_loose = (float)50e-6, tol_tight = (float)10e-6, eps = (float)1e-9;
-#ifdef SDIRT_CONIC_SGPR
-    const ConicS k = conic_s(s);
-#else
     const ConicV k = conic_v(s);
-#endif
     const int deg = s.ai_degree();
     const float t0 = M::div(k.d - r.oz, r.dz);
     const float dd = r.dx * r.dx + r.dy * r.dy;
@@ -485,11 +473,9 @@ __device__ __forceinline__ bool newton_k(const S& s, const P& pol, const Ray& r,
     };
     // the periodicity test costs four vector and five scalar instructions per trip: it is run
     // where it can pay, on tables longer than kPeriodicFrom trips (a wave-uniform choice of loop)
-#ifndef SDIRT_NO_PERIODIC_EXIT
     if (cap > kPeriodicFrom) {
         while (left > 0) trip(std::true_type{});
     } else
-#endif
     {
         while (left > 0) trip(std::false_type{});
     }

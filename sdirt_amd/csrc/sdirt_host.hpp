@@ -6,7 +6,11 @@
 #include <cstdarg>
 #include <cstdio>
 
+#include <cstdint>
+#include <vector>
+
 #include "../../include/sdirt_dp.h"
+#include "sdirt_device.hpp"
 
 inline thread_local char g_err[512] = "";
 
@@ -37,3 +41,61 @@ inline int fail(int code, const char* fmt, ...)
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+
+// A prescription at one wavelength: the device table the kernels read and its host mirror.
+struct sdirt_lens {
+    int32_t n_surfaces;
+    sdirt::DevSurface* dev;               // device table [n_surfaces]
+    std::vector<sdirt::DevSurface> host;  // host mirror
+};
+
+// Newton trip counts of one launch, one signed byte per surface, passed by value at a FIXED
+// offset of the kernel-argument segment; the kernels read the dword of surface k from there
+// with a scalar load that shares the round trip of the surface's constant block (a byte-indexed
+// by-value table made the compiler issue a vector load and wait for it once per surface).
+struct alignas(64) TripTable {
+    uint32_t w[SDIRT_MAX_SURFACES / 4];
+};
+static_assert(sizeof(TripTable) == 64, "layout");
+
+inline int make_trips(const sdirt_lens* lens, const int32_t* trips, TripTable& tt)
+{
+    for (int k = 0; k < SDIRT_MAX_SURFACES / 4; ++k) tt.w[k] = 0;
+    for (int k = 0; k < lens->n_surfaces; ++k) {
+        int v = trips ? trips[k] : SDIRT_NEWTON_MAXITER;
+        if (v < -SDIRT_NEWTON_MAXITER || v > SDIRT_NEWTON_MAXITER)
+            return fail(SDIRT_ERR_INVALID_ARGUMENT, "trips[%d]=%d outside [-%d,%d]", k, v,
+                        SDIRT_NEWTON_MAXITER, SDIRT_NEWTON_MAXITER);
+        tt.w[k >> 2] |= (uint32_t)(uint8_t)(int8_t)v << ((k & 3) * 8);
+    }
+    return SDIRT_OK;
+}
+
+constexpr int kBlock = 256;
+// Workgroup size of the two fused kernels.  512 threads = 8 waves share one pair of
+// L/R tiles (33.8 KB at ks 65): 4 workgroups = 32 waves per CU = 8 per SIMD; both
+// kernels need <= 43 VGPRs.  Measured on config 2: k_psf_lr 12.69 ms at 256 threads
+// (LDS-limited to 4 waves/SIMD), 11.76 ms at 512, 15.7 ms at 1024.
+constexpr int kFused = 512;
+
+inline int grid_for(int64_t work, int block, int cap = 256 * 16)
+{
+    int64_t g = (work + block - 1) / block;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+inline int check_rays(const sdirt_rays& R)
+{
+    if (!R.ox || !R.oy || !R.oz || !R.dx || !R.dy || !R.dz || !R.ra)
+        return fail(SDIRT_ERR_INVALID_ARGUMENT, "sdirt_rays has a null array");
+    return SDIRT_OK;
+}
+
+inline int check_ks(int ks)
+{
+    if (ks < 2 || ks > SDIRT_MAX_KS)
+        return fail(SDIRT_ERR_INVALID_ARGUMENT, "ks=%d outside [2,%d]", ks, SDIRT_MAX_KS);
+    return SDIRT_OK;
+}

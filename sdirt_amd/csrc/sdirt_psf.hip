@@ -1,0 +1,616 @@
+// sdirt_psf.hip -- the PSF kernels of libsdirt_dp.so (MI355X / gfx950 only): forward_integral on
+// staged rays, max-normalisation, the fused chief-ray centre, and k_psf_lr = [chief-ray pass ->]
+// sample -> trace -> propagate -> window -> dual-pixel weights -> LDS splat -> normalise -> store
+// (deeplens/optics.py:889-996, deeplens/monte_carlo.py:9-372).  See include/sdirt_dp.h for the
+// ABI and DESIGN.md for the data layout and the roofline of each kernel.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <type_traits>
+#include <vector>
+
+#include "../../include/sdirt_dp.h"
+#include "sdirt_trace.hpp"
+
+using namespace sdirt;
+
+static DevDpParams make_dp(const sdirt_dp_params* dp)
+{
+    DevDpParams p;
+    const double h = dp ? dp->h : 0.78, f = dp ? dp->f : 1.44, w = dp ? dp->w : 0.3,
+                 r = dp ? dp->r : 0.5;
+    p.h = (float)h; p.f = (float)f; p.w = (float)w; p.r = (float)r;
+    p.fmh = (float)(f - h);
+    p.rr = p.r * p.r;
+    p.big = r > 0.5;
+    p.have_r = dp != nullptr;
+    int ex = 0;
+    p.r_pow2 = std::frexp(p.r, &ex) == 0.5f;
+    p.inv_r = 1.0f / p.r;
+    p.tr = std::asin((1.0f / p.r) * 0.5f);
+    p.tl = (float)3.141592653589793 - p.tr;
+    return p;
+}
+
+static SplatGeom make_geom(double ps, int ks)
+{
+    SplatGeom g;
+    const double hi = (ks / 2.0 - 0.5) * ps, lo = (-ks / 2.0 + 0.5) * ps;
+    g.lim = (float)(hi - 0.01 * ps);
+    g.x_min = (float)lo;
+    g.y_max = (float)hi;
+    g.dx_rng = (float)(hi - lo);
+    g.dy_rng = (float)(lo - hi);
+    g.ksm1 = (float)(ks - 1);
+    g.ks = ks;
+    return g;
+}
+
+// Everything the splat of one ray needs (window geometry + dual-pixel parameters), as ONE
+// 64-byte block at offset 0 of k_psf_lr's kernel-argument segment: the kernel fetches it with one
+// scalar load per RAY, right before the splat, instead of keeping ~20 SGPRs alive through the
+// trace (where round 1's build parked them in VGPR lanes: v_writelane / v_readlane traffic).
+struct alignas(64) SplatBlock {
+    float lim, x_min, y_max, dx_rng, dy_rng, ksm1;
+    int32_t ks;
+    float h, f, w, r, fmh, rr, inv_r;
+    int32_t r_pow2;
+    int32_t pad;
+};
+static_assert(sizeof(SplatBlock) == 64, "layout");
+
+static SplatBlock make_splat_block(const SplatGeom& g, const DevDpParams& p)
+{
+    SplatBlock b;
+    b.lim = g.lim; b.x_min = g.x_min; b.y_max = g.y_max; b.dx_rng = g.dx_rng; b.dy_rng = g.dy_rng;
+    b.ksm1 = g.ksm1; b.ks = g.ks;
+    b.h = p.h; b.f = p.f; b.w = p.w; b.r = p.r; b.fmh = p.fmh; b.rr = p.rr; b.inv_r = p.inv_r;
+    b.r_pow2 = p.r_pow2; b.pad = 0;
+    return b;
+}
+
+// forward_integral on SoA [S,N] rays: one thread per ray (coalesced reads),
+// contributions added to the pre-zeroed [N,ks,ks] grids with global float
+// atomics -- consecutive lanes are consecutive POINTS, so the 64 atomics of a
+// wave instruction go to 64 different tiles.
+__global__ void __launch_bounds__(kBlock)
+k_forward_integral(sdirt_rays R, int64_t S, int64_t N, SplatGeom gm, DevDpParams dp,
+                   const float* __restrict__ center, float* __restrict__ lg,
+                   float* __restrict__ rg)
+{
+    const int64_t M = S * N;
+    const int64_t tile = (int64_t)gm.ks * gm.ks;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t n = i % N;
+        SplatTaps tp;
+        if (!splat_taps(gm, R.ox[i], R.oy[i], center[2 * n], center[2 * n + 1], R.ra[i], tp))
+            continue;
+        const float x_tan = (-R.dx[i]) / R.dz[i];    // monte_carlo.py:48
+        float sl, sr;
+        if (dp.big) dp_weights_big(dp, x_tan, sl, sr);
+        else dp_weights_small(dp, x_tan, sl, sr);
+        float* L = lg + n * tile;
+        atomicAdd(L + tp.i_tl, tp.w_tl * sl);
+        atomicAdd(L + tp.i_tr, tp.w_tr * sl);
+        atomicAdd(L + tp.i_bl, tp.w_bl * sl);
+        atomicAdd(L + tp.i_br, tp.w_br * sl);
+        if (rg && dp.have_r) {
+            float* Rr = rg + n * tile;
+            atomicAdd(Rr + tp.i_tl, tp.w_tl * sr);
+            atomicAdd(Rr + tp.i_tr, tp.w_tr * sr);
+            atomicAdd(Rr + tp.i_bl, tp.w_bl * sr);
+            atomicAdd(Rr + tp.i_br, tp.w_br * sr);
+        }
+    }
+}
+
+// optics.py:983-987: one workgroup per point.
+__global__ void __launch_bounds__(kBlock) k_psf_normalize(float* __restrict__ psf, int tile)
+{
+    __shared__ float red[kBlock / 64];
+    float* g = psf + (int64_t)blockIdx.x * tile;
+    float mx = -INFINITY;
+    for (int i = threadIdx.x; i < tile; i += blockDim.x) mx = fmaxf(mx, g[i]);
+    mx = block_max(mx, red);
+    const float den = mx + 1e-6f;
+    for (int i = threadIdx.x; i < tile; i += blockDim.x) g[i] = g[i] / den;
+}
+
+// ---------------------------------------------------------------------------
+// fused kernels
+// ---------------------------------------------------------------------------
+
+// psf_center: one workgroup per point, Sc rays, fp64 partial sums reduced in a
+// fixed order (deterministic).
+template <class HotMath>
+__global__ void __launch_bounds__(kFused, 8)
+k_chief_center(TripTable trips /* kernarg offset 0 */, const DevSurface* __restrict__ lens, int K,
+               const float* __restrict__ po, const float* __restrict__ xc,
+               const float* __restrict__ yc, int Sc, float pz, float zs,
+               float* __restrict__ center, int32_t* __restrict__ any_valid,
+               uint32_t* __restrict__ conv_mask)
+{
+    __shared__ uint32_t lds_mask[SDIRT_MAX_SURFACES];
+    __shared__ double red[3][kFused];
+    __shared__ int red_any;
+    const int n = blockIdx.x;
+    if (threadIdx.x < SDIRT_MAX_SURFACES) lds_mask[threadIdx.x] = 0;
+    if (threadIdx.x == 0) red_any = 0;
+    __syncthreads();
+    const float px = po[3 * n], py = po[3 * n + 1], pzo = po[3 * n + 2];
+    double sx = 0.0, sy = 0.0, sr = 0.0;
+    int any = 0;
+    for (int s = threadIdx.x; s < Sc; s += blockDim.x) {
+        Ray r = make_ray<HotMath>(px, py, pzo, xc[s], yc[s], pz);
+        trace_ray<true, HotMath>(lens, 0, K, kernarg_at(0), r, conv_mask ? lds_mask : nullptr);
+        propagate_to<HotMath>(r, zs);
+        sx += (double)(r.ox * r.ra);
+        sy += (double)(r.oy * r.ra);
+        sr += (double)r.ra;
+        any |= (r.ra == 1.0f);
+    }
+    red[0][threadIdx.x] = sx; red[1][threadIdx.x] = sy; red[2][threadIdx.x] = sr;
+    if (any) red_any = 1;
+    __syncthreads();
+    for (int off = kFused / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + off];
+            red[1][threadIdx.x] += red[1][threadIdx.x + off];
+            red[2][threadIdx.x] += red[2][threadIdx.x + off];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float den = (float)red[2][0] + (float)1e-9;
+        center[2 * n] = -((float)red[0][0] / den);
+        center[2 * n + 1] = -((float)red[1][0] / den);
+        if (any_valid && red_any) atomicOr(any_valid, 1);
+    }
+    if (conv_mask && (int)threadIdx.x < K && lds_mask[threadIdx.x])
+        atomicOr(&conv_mask[threadIdx.x], lds_mask[threadIdx.x]);
+}
+
+// psf_diff fused: sample -> trace -> propagate -> window -> DP weights -> LDS
+// splat -> (max-normalise) -> store.  gridDim.x = N * nsplit; the workgroup
+// (n, j) handles samples [j*chunk, (j+1)*chunk) of point n.
+//   nsplit == 1 : the tile is complete in LDS -> normalise (flag) and store.
+//   nsplit  > 1 : tiles are added to the pre-zeroed output with global float
+//                 atomics; the caller normalises afterwards.
+// Arguments of the optional in-kernel chief-ray pass (CENTER instantiations, nsplit == 1): the
+// workgroup first traces the Sc shrunk-pupil samples of its point through the GREEN lens table
+// (optics.py:900), reduces the centroid exactly like k_chief_center, and only then splats.
+struct CenterArgs {
+    const DevSurface* lens_c;
+    const float* xc;
+    const float* yc;
+    int Sc;
+    float* center_out;       // [N,2]
+    int32_t* any_valid;
+    uint32_t* conv_mask_c;
+};
+
+// __launch_bounds__(512, 8): four workgroups per CU = 8 waves per SIMD (<= 80 SGPRs, <= 64 VGPRs).
+// The big-radius microlens branch (corner-clipped areas, monte_carlo.py:242-372) needs ~90 VGPRs:
+// capped at 64 it would spill 60 of them to scratch, so it runs at 4 waves per SIMD instead.
+// `sb` MUST stay the first parameter: the kernel reads it as a 64-byte block at offset 0 of its
+// kernel-argument segment (see SplatBlock) and never through the parameter itself.
+// blockIdx.y = wavelength slot w of a multi-wavelength launch (psf_rgb: gridDim.y = 3, one lens
+// table, pupil sample set, trip table and mask row per slot; a plain call has gridDim.y = 1): the
+// output is [N, gridDim.y, ks, ks], the reference's psf_rgb layout (optics.py:1015).
+struct LensSet {
+    const DevSurface* p[SDIRT_MAX_WAVELENGTHS];
+};
+struct TripSet {
+    TripTable t[SDIRT_MAX_WAVELENGTHS];
+};
+template <bool HAVE_R, bool BIG, class HotMath, bool CENTER>
+__global__ void __launch_bounds__(kFused, BIG ? 4 : 8)
+k_psf_lr(SplatBlock sb /* kernarg offset 0 */, TripSet trips /* 64 */, TripSet trips_c /* 64 + 64 W */,
+         LensSet lens_set, int K, const float* __restrict__ po, const float* __restrict__ x2,
+         const float* __restrict__ y2, int S, int nsplit, int chunk, float pz, float zs, int ks, float tr,
+         float tl, const float* __restrict__ center, uint32_t flags, float* __restrict__ lout,
+         float* __restrict__ rout, uint32_t* __restrict__ conv_mask, CenterArgs ca)
+{
+    extern __shared__ __attribute__((aligned(16))) float tiles[];   // [L | R] ks*ks each
+    __shared__ uint32_t lds_mask[SDIRT_MAX_SURFACES];
+    __shared__ float red[kFused / 64];
+    __shared__ float c_sh[2];
+    const int tile = ks * ks;
+    float* tl_ = tiles;
+    float* trr = tiles + tile;
+    const int n = blockIdx.x / nsplit;
+    const int j = blockIdx.x - n * nsplit;
+    const int w = blockIdx.y, W = gridDim.y;
+    const int N = gridDim.x / nsplit;
+    const DevSurface* __restrict__ lens = lens_set.p[w];
+    constexpr int kTripsAt = 64, kTripsCAt = 64 + 64 * SDIRT_MAX_WAVELENGTHS;
+    x2 += (int64_t)w * S; y2 += (int64_t)w * S;
+    if (conv_mask) conv_mask += w * SDIRT_MAX_SURFACES;
+    if (CENTER) {
+        ca.xc += (int64_t)w * ca.Sc; ca.yc += (int64_t)w * ca.Sc;
+        ca.center_out += (int64_t)w * N * 2;
+        if (ca.any_valid) ca.any_valid += w;
+        if (ca.conv_mask_c) ca.conv_mask_c += w * SDIRT_MAX_SURFACES;
+    } else if (center) {
+        center += (int64_t)w * N * 2;
+    }
+    const float px = po[3 * n], py = po[3 * n + 1], pzo = po[3 * n + 2];
+
+    if (CENTER) {
+        // ---- chief-ray centre of this point (same arithmetic and reduction order as
+        // k_chief_center; the fp64 scratch aliases the not-yet-used tile memory)
+        double* redd = reinterpret_cast<double*>(tiles);             // [3][kFused]
+        if (threadIdx.x < SDIRT_MAX_SURFACES) lds_mask[threadIdx.x] = 0;
+        if (threadIdx.x == 0) c_sh[0] = 0.0f;
+        __syncthreads();
+        double sx = 0.0, sy = 0.0, sr = 0.0;
+        int any = 0;
+        for (int s = threadIdx.x; s < ca.Sc; s += blockDim.x) {
+            Ray r = make_ray<HotMath>(px, py, pzo, ca.xc[s], ca.yc[s], pz);
+            trace_ray<true, HotMath>(ca.lens_c, 0, K, kernarg_at(kTripsCAt + 64 * w), r,
+                                     ca.conv_mask_c ? lds_mask : nullptr);
+            propagate_to<HotMath>(r, zs);
+            sx += (double)(r.ox * r.ra);
+            sy += (double)(r.oy * r.ra);
+            sr += (double)r.ra;
+            any |= (r.ra == 1.0f);
+        }
+        redd[threadIdx.x] = sx; redd[kFused + threadIdx.x] = sy; redd[2 * kFused + threadIdx.x] = sr;
+        if (any) c_sh[0] = 1.0f;                                     // benign race: all write 1
+        __syncthreads();
+        for (int off = kFused / 2; off > 0; off >>= 1) {
+            if ((int)threadIdx.x < off) {
+                redd[threadIdx.x] += redd[threadIdx.x + off];
+                redd[kFused + threadIdx.x] += redd[kFused + threadIdx.x + off];
+                redd[2 * kFused + threadIdx.x] += redd[2 * kFused + threadIdx.x + off];
+            }
+            __syncthreads();
+        }
+        if (ca.conv_mask_c && (int)threadIdx.x < K && lds_mask[threadIdx.x])
+            atomicOr(&ca.conv_mask_c[threadIdx.x], lds_mask[threadIdx.x]);
+        const float any_f = c_sh[0];
+        const float den = (float)redd[2 * kFused] + (float)1e-9;
+        const float ccx = -((float)redd[0] / den), ccy = -((float)redd[kFused] / den);
+        __syncthreads();                                             // everyone has read redd / c_sh
+        if (threadIdx.x == 0) {
+            ca.center_out[2 * n] = ccx; ca.center_out[2 * n + 1] = ccy;
+            c_sh[0] = ccx; c_sh[1] = ccy;
+            if (ca.any_valid && any_f != 0.0f) atomicOr(ca.any_valid, 1);
+        }
+    }
+
+    for (int i = threadIdx.x; i < (HAVE_R ? 2 : 1) * tile; i += blockDim.x) tiles[i] = 0.0f;
+    if (threadIdx.x < SDIRT_MAX_SURFACES) lds_mask[threadIdx.x] = 0;
+    __syncthreads();
+
+    const float cx = CENTER ? c_sh[0] : center[2 * n], cy = CENTER ? c_sh[1] : center[2 * n + 1];
+    const int s_end = min(S, (j + 1) * chunk);
+    const void* kernarg = kernarg_at(0);
+    auto splat = [&](float sx, float sy, float dx, float dz, float ra) {
+        // the splat constants: one 64-byte scalar load per ray, dead again after the splat
+        const u32x16 q = sload_block(kernarg);
+        const auto F = [&](int i) { return __uint_as_float(q[i]); };
+        SplatGeom gm;
+        gm.lim = F(0); gm.x_min = F(1); gm.y_max = F(2); gm.dx_rng = F(3); gm.dy_rng = F(4);
+        gm.ksm1 = F(5); gm.ks = (int)q[6];
+        DevDpParams dp;
+        dp.h = F(7); dp.f = F(8); dp.w = F(9); dp.r = F(10); dp.fmh = F(11); dp.rr = F(12);
+        dp.inv_r = F(13); dp.r_pow2 = (int)q[14]; dp.tr = tr; dp.tl = tl; dp.big = BIG; dp.have_r = HAVE_R;
+        SplatTaps tp;
+        if (!splat_taps(gm, UDiv<HotMath>::make(gm.dy_rng), UDiv<HotMath>::make(gm.dx_rng), sx, sy, cx, cy,
+                        ra, tp))
+            return;
+        const float x_tan = HotMath::div(-dx, dz);
+        float sl, sr;
+        if (BIG) dp_weights_big(dp, x_tan, sl, sr);      // separate instantiation: the rarely
+        else dp_weights_small(dp, UDiv<HotMath>::make(dp.fmh), x_tan, sl, sr);   // used r > 0.5 branch costs registers
+        atomicAdd(&tl_[tp.i_tl], tp.w_tl * sl);
+        atomicAdd(&tl_[tp.i_tr], tp.w_tr * sl);
+        atomicAdd(&tl_[tp.i_bl], tp.w_bl * sl);
+        atomicAdd(&tl_[tp.i_br], tp.w_br * sl);
+        if (HAVE_R) {
+            atomicAdd(&trr[tp.i_tl], tp.w_tl * sr);
+            atomicAdd(&trr[tp.i_tr], tp.w_tr * sr);
+            atomicAdd(&trr[tp.i_bl], tp.w_bl * sr);
+            atomicAdd(&trr[tp.i_br], tp.w_br * sr);
+        }
+    };
+    for (int s = j * chunk + threadIdx.x; s < s_end; s += blockDim.x) {
+        Ray r = make_ray<HotMath>(px, py, pzo, x2[s], y2[s], pz);
+        trace_ray<true, HotMath>(lens, 0, K, kernarg_at(kTripsAt + 64 * w), r, conv_mask ? lds_mask : nullptr);
+        propagate_to<HotMath>(r, zs);
+        splat(r.ox, r.oy, r.dx, r.dz, r.ra);
+    }
+    __syncthreads();
+
+    float* Lg = lout + ((int64_t)n * W + w) * tile;
+    float* Rg = HAVE_R ? rout + ((int64_t)n * W + w) * tile : nullptr;
+    if (nsplit == 1) {
+        if (flags & SDIRT_PSF_NORMALIZE) {
+            float mx = -INFINITY;
+            for (int i = threadIdx.x; i < tile; i += blockDim.x) mx = fmaxf(mx, tl_[i]);
+            const auto div_l = UDiv<HotMath>::make(block_max(mx, red) + 1e-6f);
+            auto div_r = div_l;
+            if (HAVE_R) {
+                mx = -INFINITY;
+                for (int i = threadIdx.x; i < tile; i += blockDim.x) mx = fmaxf(mx, trr[i]);
+                div_r = UDiv<HotMath>::make(block_max(mx, red) + 1e-6f);
+            }
+            for (int i = threadIdx.x; i < tile; i += blockDim.x) {
+                Lg[i] = div_l(tl_[i]);
+                if (HAVE_R) Rg[i] = div_r(trr[i]);
+            }
+        } else {
+            for (int i = threadIdx.x; i < tile; i += blockDim.x) {
+                Lg[i] = tl_[i];
+                if (HAVE_R) Rg[i] = trr[i];
+            }
+        }
+    } else {
+        for (int i = threadIdx.x; i < tile; i += blockDim.x) {
+            const float a = tl_[i];
+            if (a != 0.0f) atomicAdd(&Lg[i], a);
+            if (HAVE_R) {
+                const float b = trr[i];
+                if (b != 0.0f) atomicAdd(&Rg[i], b);
+            }
+        }
+    }
+    if (conv_mask && (int)threadIdx.x < K && lds_mask[threadIdx.x])
+        atomicOr(&conv_mask[threadIdx.x], lds_mask[threadIdx.x]);
+}
+
+// ---------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------
+extern "C" {
+
+int sdirt_forward_integral(sdirt_rays rays, int64_t S, int64_t N, double ps, int32_t ks,
+                           const float* center, const sdirt_dp_params* dp, float* l_grid,
+                           float* r_grid, void* stream)
+{
+    if (int rc = check_rays(rays)) return rc;
+    if (int rc = check_ks(ks)) return rc;
+    if (!center || !l_grid || S < 0 || N < 0) return fail(SDIRT_ERR_INVALID_ARGUMENT, "bad argument");
+    if (dp && !(dp->r > 0.0)) return fail(SDIRT_ERR_INVALID_ARGUMENT, "dp->r must be > 0");
+    if (N == 0) return SDIRT_OK;
+    const size_t bytes = sizeof(float) * (size_t)N * ks * ks;
+    HIP_TRY(hipMemsetAsync(l_grid, 0, bytes, as_stream(stream)));
+    if (r_grid) HIP_TRY(hipMemsetAsync(r_grid, 0, bytes, as_stream(stream)));
+    if (S == 0) return SDIRT_OK;
+    k_forward_integral<<<grid_for(S * N, kBlock), kBlock, 0, as_stream(stream)>>>(
+        rays, S, N, make_geom(ps, ks), make_dp(dp), center, l_grid, r_grid);
+    LAUNCH_CHECK();
+    return SDIRT_OK;
+}
+
+int sdirt_psf_normalize(float* psf, int64_t N, int32_t ks, void* stream)
+{
+    if (!psf || N < 0) return fail(SDIRT_ERR_INVALID_ARGUMENT, "bad argument");
+    if (ks < 1) return fail(SDIRT_ERR_INVALID_ARGUMENT, "ks < 1");
+    if (N == 0) return SDIRT_OK;
+    k_psf_normalize<<<(int)N, kBlock, 0, as_stream(stream)>>>(psf, ks * ks);
+    LAUNCH_CHECK();
+    return SDIRT_OK;
+}
+
+int sdirt_chief_center(const sdirt_lens* lens, const float* point_obj, int64_t N, const float* xc,
+                       const float* yc, int64_t Sc, double pupil_z, double d_sensor,
+                       const int32_t* trips, uint32_t flags, float* center, int32_t* any_valid,
+                       uint32_t* conv_mask, void* stream)
+{
+    if (!lens || !point_obj || !xc || !yc || !center || N < 0 || Sc < 0 || Sc > (1ll << 30))
+        return fail(SDIRT_ERR_INVALID_ARGUMENT, "bad argument");
+    TripTable tt;
+    if (int rc = make_trips(lens, trips, tt)) return rc;
+    if (N == 0) return SDIRT_OK;
+    if (!(flags & SDIRT_PSF_STRICT_IEEE))
+        k_chief_center<Lean><<<(int)N, kFused, 0, as_stream(stream)>>>(
+            tt, lens->dev, lens->n_surfaces, point_obj, xc, yc, (int)Sc, (float)pupil_z,
+            (float)d_sensor, center, any_valid, conv_mask);
+    else
+        k_chief_center<Ieee><<<(int)N, kFused, 0, as_stream(stream)>>>(
+            tt, lens->dev, lens->n_surfaces, point_obj, xc, yc, (int)Sc, (float)pupil_z,
+            (float)d_sensor, center, any_valid, conv_mask);
+    LAUNCH_CHECK();
+    return SDIRT_OK;
+}
+
+// Shared launcher of sdirt_psf_lr / sdirt_psf_lr_centered / sdirt_psf_rgb_centered.  `cen` != nullptr
+// requests the chief-ray pass: inside the same kernel when one workgroup owns a point (nsplit ==
+// 1), as a preceding k_chief_center launch otherwise.  W wavelength slots (W > 1 needs nsplit == 1):
+// lens[w], trips[w], x2 / y2 [W][S], outputs [N][W][ks][ks], masks [W][SDIRT_MAX_SURFACES].
+struct CenterRequest {
+    const sdirt_lens* lens_c;
+    const float* xc;              // [W][Sc]
+    const float* yc;
+    int64_t Sc;
+    TripSet trips_c;
+    float* center_out;            // [W][N][2]
+    int32_t* any_valid;           // [W]
+    uint32_t* conv_mask_c;        // [W][SDIRT_MAX_SURFACES]
+};
+
+static int spp_split(int64_t N, int64_t S, int* chunk_out)
+{
+    // Fill the chip: at least ~4 workgroups per CU; split the spp axis when the
+    // number of points alone cannot (e.g. PSFNet training: N=64, S=20000).
+    int nsplit = 1;
+    const int64_t want_blocks = 256 * 4;
+    if (N < want_blocks && S > 2 * kFused) {
+        nsplit = (int)((want_blocks + N - 1) / N);
+        const int max_split = (int)((S + 2 * kFused - 1) / (2 * kFused));
+        if (nsplit > max_split) nsplit = max_split;
+        if (nsplit < 1) nsplit = 1;
+    }
+    int chunk = (int)((S + nsplit - 1) / nsplit);
+    chunk = ((chunk + kFused - 1) / kFused) * kFused;
+    nsplit = (int)((S + chunk - 1) / (chunk > 0 ? chunk : 1));
+    if (nsplit < 1) nsplit = 1;
+    if (chunk_out) *chunk_out = chunk;
+    return nsplit;
+}
+
+static int launch_psf(const sdirt_lens* const* lens, int W, const float* point_obj, int64_t N,
+                      const float* x2, const float* y2, int64_t S, double pupil_z, double d_sensor,
+                      double ps, int32_t ks, const float* center, const CenterRequest* cen,
+                      const sdirt_dp_params* dp, const TripSet& tt, uint32_t flags, float* l_psf,
+                      float* r_psf, uint32_t* conv_mask, void* stream)
+{
+    const bool have_r = r_psf != nullptr;
+    const int tile = ks * ks;
+    const size_t lds = sizeof(float) * tile * (have_r ? 2 : 1);
+    // a multi-wavelength launch keeps one workgroup per (point, wavelength): the chief-ray pass
+    // stays fused and the whole of psf_rgb is one kernel, also for the few points of a psf_map
+    int chunk = ((int)S + kFused - 1) / kFused * kFused;
+    const int nsplit = W > 1 ? 1 : spp_split(N, S, &chunk);
+    const int K = lens[0]->n_surfaces;
+
+    hipStream_t st = as_stream(stream);
+    const bool lean = (flags & SDIRT_PSF_STRICT_IEEE) == 0;
+    const bool fuse_center = cen != nullptr && nsplit == 1;
+    if (cen && !fuse_center) {                       // split spp axis: centre as its own launch
+        if (lean)
+            k_chief_center<Lean><<<(int)N, kFused, 0, st>>>(
+                cen->trips_c.t[0], cen->lens_c->dev, K, point_obj, cen->xc, cen->yc, (int)cen->Sc,
+                (float)pupil_z, (float)d_sensor, cen->center_out, cen->any_valid, cen->conv_mask_c);
+        else
+            k_chief_center<Ieee><<<(int)N, kFused, 0, st>>>(
+                cen->trips_c.t[0], cen->lens_c->dev, K, point_obj, cen->xc, cen->yc, (int)cen->Sc,
+                (float)pupil_z, (float)d_sensor, cen->center_out, cen->any_valid, cen->conv_mask_c);
+        LAUNCH_CHECK();
+        center = cen->center_out;
+    }
+    if (nsplit > 1) {
+        HIP_TRY(hipMemsetAsync(l_psf, 0, sizeof(float) * (size_t)N * tile, st));
+        if (have_r) HIP_TRY(hipMemsetAsync(r_psf, 0, sizeof(float) * (size_t)N * tile, st));
+    }
+    const SplatGeom gm = make_geom(ps, ks);
+    const DevDpParams dpp = make_dp(dp);
+    const SplatBlock sblk = make_splat_block(gm, dpp);
+    const dim3 grid((unsigned)(N * nsplit), (unsigned)W);
+    const bool both = have_r && dpp.have_r;
+    size_t lds_bytes = both ? lds : sizeof(float) * tile;
+    CenterArgs ca;
+    TripSet ttc;
+    LensSet ls;
+    std::memset(&ca, 0, sizeof(ca));
+    std::memset(&ttc, 0, sizeof(ttc));
+    std::memset(&ls, 0, sizeof(ls));
+    for (int w = 0; w < W; ++w) ls.p[w] = lens[w]->dev;
+    if (fuse_center) {
+        ca.lens_c = cen->lens_c->dev; ttc = cen->trips_c; ca.xc = cen->xc; ca.yc = cen->yc;
+        ca.Sc = (int)cen->Sc; ca.center_out = cen->center_out; ca.any_valid = cen->any_valid;
+        ca.conv_mask_c = cen->conv_mask_c;
+        lds_bytes = std::max(lds_bytes, sizeof(double) * 3 * kFused);   // fp64 reduction scratch
+    }
+#define SDIRT_LAUNCH_PSF(HR, BG, MM, CT)                                                          \
+    do {                                                                                          \
+        if (lds_bytes > 48 * 1024) /* large tiles: opt in to the full 160 KiB of LDS */           \
+            HIP_TRY(hipFuncSetAttribute((const void*)k_psf_lr<HR, BG, MM, CT>,                    \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize,               \
+                                        160 * 1024 - 1024));                                      \
+        k_psf_lr<HR, BG, MM, CT><<<grid, kFused, lds_bytes, st>>>(                                \
+            sblk, tt, ttc, ls, K, point_obj, x2, y2, (int)S, nsplit, chunk, (float)pupil_z,       \
+            (float)d_sensor, ks, dpp.tr, dpp.tl, center, flags, l_psf, both ? r_psf : nullptr,    \
+            conv_mask, ca);                                                                       \
+    } while (0)
+#define SDIRT_LAUNCH_PSF_C(HR, BG, MM)                                                            \
+    do {                                                                                          \
+        if (fuse_center) SDIRT_LAUNCH_PSF(HR, BG, MM, true); else SDIRT_LAUNCH_PSF(HR, BG, MM, false); \
+    } while (0)
+#define SDIRT_LAUNCH_PSF_M(HR, BG)                                                                \
+    do {                                                                                          \
+        if (lean) SDIRT_LAUNCH_PSF_C(HR, BG, Lean); else SDIRT_LAUNCH_PSF_C(HR, BG, Ieee);        \
+    } while (0)
+    if (both) {
+        if (dpp.big) SDIRT_LAUNCH_PSF_M(true, true); else SDIRT_LAUNCH_PSF_M(true, false);
+    } else {
+        if (dpp.big) SDIRT_LAUNCH_PSF_M(false, true); else SDIRT_LAUNCH_PSF_M(false, false);
+        // param_list=None leaves the R grid all-zero (monte_carlo.py:230-235)
+        if (have_r) HIP_TRY(hipMemsetAsync(r_psf, 0, sizeof(float) * (size_t)N * W * tile, st));
+    }
+#undef SDIRT_LAUNCH_PSF_M
+#undef SDIRT_LAUNCH_PSF_C
+#undef SDIRT_LAUNCH_PSF
+    LAUNCH_CHECK();
+    if (nsplit > 1 && (flags & SDIRT_PSF_NORMALIZE)) {
+        k_psf_normalize<<<(int)N, kBlock, 0, st>>>(l_psf, tile);
+        if (have_r && dpp.have_r) k_psf_normalize<<<(int)N, kBlock, 0, st>>>(r_psf, tile);
+        LAUNCH_CHECK();
+    }
+    return SDIRT_OK;
+}
+
+int sdirt_psf_lr(const sdirt_lens* lens, const float* point_obj, int64_t N, const float* x2,
+                 const float* y2, int64_t S, double pupil_z, double d_sensor, double ps, int32_t ks,
+                 const float* center, const sdirt_dp_params* dp, const int32_t* trips,
+                 uint32_t flags, float* l_psf, float* r_psf, uint32_t* conv_mask, void* stream)
+{
+    if (!lens || !point_obj || !x2 || !y2 || !center || !l_psf || N < 0 || S < 0 ||
+        S > (1ll << 30) || N > (1ll << 30))
+        return fail(SDIRT_ERR_INVALID_ARGUMENT, "bad argument");
+    if (int rc = check_ks(ks)) return rc;
+    if (dp && !(dp->r > 0.0)) return fail(SDIRT_ERR_INVALID_ARGUMENT, "dp->r must be > 0");
+    TripSet tt;
+    std::memset(&tt, 0, sizeof(tt));
+    if (int rc = make_trips(lens, trips, tt.t[0])) return rc;
+    if (N == 0) return SDIRT_OK;
+    return launch_psf(&lens, 1, point_obj, N, x2, y2, S, pupil_z, d_sensor, ps, ks, center, nullptr, dp,
+                      tt, flags, l_psf, r_psf, conv_mask, stream);
+}
+
+int sdirt_psf_lr_centered(const sdirt_lens* lens, const sdirt_lens* lens_center,
+                          const float* point_obj, int64_t N, const float* x2, const float* y2,
+                          int64_t S, const float* xc, const float* yc, int64_t Sc, double pupil_z,
+                          double d_sensor, double ps, int32_t ks, const sdirt_dp_params* dp,
+                          const int32_t* trips, const int32_t* trips_center, uint32_t flags,
+                          float* center, int32_t* any_valid, float* l_psf, float* r_psf,
+                          uint32_t* conv_mask, uint32_t* conv_mask_center, void* stream)
+{
+    return sdirt_psf_rgb_centered(&lens, 1, lens_center, point_obj, N, x2, y2, S, xc, yc, Sc, pupil_z,
+                                  d_sensor, ps, ks, dp, trips, trips_center, flags, center, any_valid,
+                                  l_psf, r_psf, conv_mask, conv_mask_center, stream);
+}
+
+int sdirt_psf_rgb_centered(const sdirt_lens* const* lens, int32_t W, const sdirt_lens* lens_center,
+                           const float* point_obj, int64_t N, const float* x2, const float* y2,
+                           int64_t S, const float* xc, const float* yc, int64_t Sc, double pupil_z,
+                           double d_sensor, double ps, int32_t ks, const sdirt_dp_params* dp,
+                           const int32_t* trips, const int32_t* trips_center, uint32_t flags,
+                           float* center, int32_t* any_valid, float* l_psf, float* r_psf,
+                           uint32_t* conv_mask, uint32_t* conv_mask_center, void* stream)
+{
+    if (!lens || W < 1 || W > SDIRT_MAX_WAVELENGTHS || !lens_center || !point_obj || !x2 || !y2 || !xc ||
+        !yc || !center || !l_psf || N < 0 || S < 0 || Sc < 0 || S > (1ll << 30) || Sc > (1ll << 30) ||
+        N > (1ll << 30))
+        return fail(SDIRT_ERR_INVALID_ARGUMENT, "bad argument");
+    for (int w = 0; w < W; ++w)
+        if (!lens[w] || lens[w]->n_surfaces != lens_center->n_surfaces)
+            return fail(SDIRT_ERR_INVALID_ARGUMENT, "lens[%d] missing or surface count differs from lens_center", w);
+    if (int rc = check_ks(ks)) return rc;
+    if (dp && !(dp->r > 0.0)) return fail(SDIRT_ERR_INVALID_ARGUMENT, "dp->r must be > 0");
+    const int K = lens_center->n_surfaces;
+    TripSet tt;
+    CenterRequest cr;
+    std::memset(&tt, 0, sizeof(tt));
+    std::memset(&cr.trips_c, 0, sizeof(cr.trips_c));
+    for (int w = 0; w < W; ++w) {
+        if (int rc = make_trips(lens[w], trips ? trips + (size_t)w * K : nullptr, tt.t[w])) return rc;
+        if (int rc = make_trips(lens_center, trips_center ? trips_center + (size_t)w * K : nullptr,
+                                cr.trips_c.t[w]))
+            return rc;
+    }
+    if (N == 0) return SDIRT_OK;
+    cr.lens_c = lens_center; cr.xc = xc; cr.yc = yc; cr.Sc = Sc; cr.center_out = center;
+    cr.any_valid = any_valid; cr.conv_mask_c = conv_mask_center;
+    return launch_psf(lens, W, point_obj, N, x2, y2, S, pupil_z, d_sensor, ps, ks, nullptr, &cr, dp, tt,
+                      flags, l_psf, r_psf, conv_mask, stream);
+}
+
+}  // extern "C"

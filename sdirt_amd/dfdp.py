@@ -67,11 +67,12 @@ class _CostVolume(torch.autograd.Function):
 
 def dp_cost_volume(x, y, d_max=20):
     """dddnet.py:155-178 / 136-148: x, y [B,C,H,W] -> [B,2C,d_max,H,W] (differentiable)."""
-    if x.is_cuda:
-        if x.dtype not in (torch.float16, torch.float32):
-            raise _lib.SdirtError(f"sdirt_dp_cost_volume is built for fp16 / fp32, got {x.dtype}")
+    if x.is_cuda and x.dtype in (torch.float16, torch.float32):
         return _CostVolume.apply(x, y, d_max)
-    return _cost_volume_reference(x, y, d_max)          # CPU tensors: stock torch ops
+    # CPU tensors, and the dtypes the kernel is not built for (bf16 autocast, float64 gradcheck):
+    # the reference's own formulation in stock torch ops -- a documented path chosen by dtype,
+    # never a fallback from a failed launch (the fp16 / fp32 kernel raises on any error)
+    return _cost_volume_reference(x, y, d_max)
 
 
 class BasicConv(nn.Module):

@@ -253,7 +253,53 @@ class Lensgroup:
             with torch.cuda.device(self.device):
                 dl = _DevLens(self.surfaces, key)
             self._dev[key] = dl
+            self._prefetch_selftest(dl.handle)
         return dl.handle
+
+    def _prefetch_selftest(self, handle):
+        """Second guard of the hand-scheduled scalar prefetch in the trace loop (the first is the
+        ISA check of the build, tools/check_prefetch_hazard.py): when a prescription is first
+        uploaded, a fan of probe rays is traced twice -- next surface's constants prefetched one
+        surface ahead / loaded on the spot (SDIRT_TRACE_NO_PREFETCH) -- forward and backward, both
+        math policies; the two must agree bit for bit.  A compiler that moved an instruction into
+        the in-flight window would make the prefetching loop trace with stale constants or trip
+        counts; then every call on this lens raises instead of returning wrong PSFs.  Draws no random numbers."""
+        if Lensgroup._selftest_done.get((self.device.index, len(self.surfaces))) == self._table_digest():
+            return
+        K = len(self.surfaces)
+        front, back = self.surfaces[0], self.surfaces[-1]
+        n = 16
+        lin = torch.linspace(-0.6, 0.6, n, device=self.device)
+        gx, gy = torch.meshgrid(lin, lin, indexing="xy")
+        trips = (C.c_int32 * K)(*self._fixed_trips_for("max").tolist())
+        for forward in (True, False):
+            surf = front if forward else back
+            z0 = float(surf.d) - 40.0 if forward else float(self.d_sensor)
+            o = torch.stack((gx * 3.0, gy * 3.0 + 0.5, torch.full_like(gx, z0)), -1).reshape(-1, 3)
+            aim = torch.stack((gx * float(surf.r), gy.flip(0) * float(surf.r),
+                               torch.full_like(gx, float(surf.d))), -1).reshape(-1, 3)
+            for flags in (0, _lib.PSF_STRICT_IEEE):
+                a = Ray(o, aim - o, device=self.device)
+                b = a.clone()
+                for ray, extra in ((a, 0), (b, _lib.TRACE_NO_PREFETCH)):
+                    _lib.check(_lib.lib().sdirt_trace(handle, 0, K, 0 if forward else 1, trips, flags | extra,
+                                                      ray.c_rays(), ray.numel, None, stream_ptr(self.device)))
+                if not torch.equal(a.soa.view(torch.int32), b.soa.view(torch.int32)):
+                    raise _lib.SdirtError(
+                        "libsdirt_dp.so self-test failed: the trace loop with prefetched surface constants "
+                        "disagrees with the load-and-wait form (miscompiled surf_issue/surf_wait window?); "
+                        "rebuild with `make -C sdirt_amd/csrc` and check tools/check_prefetch_hazard.py")
+        Lensgroup._selftest_done[(self.device.index, K)] = self._table_digest()
+
+    _selftest_done = {}
+
+    def _table_digest(self):
+        return hash(tuple((s.kind, float(s.r), float(s.d), float(s.c), float(s.k),
+                           tuple(float(a) for a in (s.ai if s.ai is not None else ()))) for s in self.surfaces))
+
+    def _fixed_trips_for(self, policy):
+        n = NEWTON_MAXITER if policy == "max" else -NEWTON_MAXITER
+        return np.where(self._curved(), n, 0).astype(np.int32)
 
     def _math_flags(self):
         if self.precision not in ("ieee", "lean"):
@@ -280,8 +326,7 @@ class Lensgroup:
         "up to 10, each wave stops when its own rays are done" ('adaptive')."""
         if self.trip_policy not in ("max", "adaptive"):
             raise ValueError(f"unknown trip_policy {self.trip_policy!r}")
-        n = NEWTON_MAXITER if self.trip_policy == "max" else -NEWTON_MAXITER
-        return np.where(self._curved(), n, 0).astype(np.int32)
+        return self._fixed_trips_for(self.trip_policy)
 
     def _run_with_trips(self, key, order, enqueue):
         """enqueue(trips_ctypes, mask_ptr) launches the kernels.  Returns the trip
@@ -455,10 +500,16 @@ class Lensgroup:
     def _zeroed_control_block(self, n, rows=64):
         """An int32 [n] device block that is zero, cut from a pool that is cleared `rows` blocks
         at a time (one fill kernel per `rows` launches instead of one per launch)."""
-        pool = self.__dict__.get("_ctl_pool")
-        if pool is None or pool["n"] != n or pool["next"] >= rows:
-            pool = self.__dict__["_ctl_pool"] = {
-                "n": n, "next": 0, "buf": torch.zeros((rows, n), dtype=torch.int32, device=self.device)}
+        # one pool per (size, stream): the fill runs on the stream that is current when the pool is
+        # created, and rows are only ever handed to launches on THAT stream -- so the fill is ordered
+        # before every kernel that ORs into a row, and the caching allocator (which hands memory back
+        # to the stream it was allocated on) cannot recycle the pool under a foreign stream's kernel
+        pools = self.__dict__.setdefault("_ctl_pools", {})
+        key = (n, torch.cuda.current_stream(self.device).cuda_stream)
+        pool = pools.get(key)
+        if pool is None or pool["next"] >= rows:
+            pool = pools[key] = {"next": 0,
+                                 "buf": torch.zeros((rows, n), dtype=torch.int32, device=self.device)}
         row = pool["buf"][pool["next"]]
         pool["next"] += 1
         return row
@@ -468,6 +519,11 @@ class Lensgroup:
         result for the LAST tensor is kept: a caller that renders the same grid call after call (a
         PSF volume, an evaluation set) pays for the conversion once.  The key is the tensor object
         itself, its version counter (any in-place write bumps it) and every lens scalar used."""
+        # only device tensors that track a version counter are cached: a CPU tensor can be written
+        # behind torch's back (torch.from_numpy + a numpy-side store leaves _version unchanged), an
+        # inference-mode tensor has no counter at all
+        if not points.is_cuda or points.is_inference():
+            return self._points_to_object_now(points)
         key = (points._version, tuple(points.shape), points.dtype, float(np.tan(self.hfov)),
                float(self.r_last), float(self.sensor_size[1]), float(self.sensor_size[0]),
                str(self.device), torch.cuda.current_stream(self.device).cuda_stream)
@@ -545,7 +601,7 @@ class Lensgroup:
     @torch.no_grad()
     def psf_lr(self, points, ks=31, wvln=DEFAULT_WAVE, spp=GEO_SPP, center=True,
                dp=(0.78, 1.44, 0.3, 0.5), normalize=True, want_r=True, _default_r_zero=False,
-               pupil_xy=None, center_pupil_xy=None, out=None, defer=False):
+               pupil_xy=None, center_pupil_xy=None, out=None, defer=False, center_out=None):
         """Left AND right dual-pixel PSFs of one ray-traced batch: (L, R), each
         [N,ks,ks] (or [ks,ks] for a single point), max-normalised separately as
         optics.py:983-987 would normalise each of them.  dp = (h, f, w, r) of
@@ -559,6 +615,9 @@ class Lensgroup:
         out: optional (L, R) float32 CUDA tensors [N,ks,ks] to write into -- a consumer
         that renders batch after batch (PSFNet fitting) re-uses its buffers instead of
         asking the caching allocator for two 277 MB blocks per call.
+
+        center_out: optional float32 CUDA [N,2] tensor that receives the PSF centres the splat used
+        (the chief-ray centres of optics.py:969 with center=True).
 
         defer=True (center=True only): enqueue the kernel with the speculated Newton trip tables
         and return a `PendingPSF` at once; its `.wait()` reads the convergence masks back,
@@ -590,7 +649,13 @@ class Lensgroup:
             x2, y2 = [torch.as_tensor(v).to(self.device, torch.float32).contiguous()
                       for v in pupil_xy]
             spp = x2.shape[0]
-        cen = torch.empty((N, 2), dtype=torch.float32, device=self.device)
+        if center_out is not None:
+            if not (center_out.is_cuda and center_out.dtype == torch.float32 and center_out.is_contiguous()
+                    and tuple(center_out.shape) == (N, 2)):
+                raise ValueError("center_out must be a contiguous float32 CUDA [N, 2] tensor")
+            cen = center_out
+        else:
+            cen = torch.empty((N, 2), dtype=torch.float32, device=self.device)
         xc = yc = None
         if center:
             _, pupilr_c = self.entrance_pupil(shrink_pupil=True)

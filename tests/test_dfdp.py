@@ -132,3 +132,20 @@ def test_dfdp_net_and_cost_volume_kernel_on_the_gpu():
                                      "gt_depth": inputs.gt.clone().to(dev)}, train=True)
     assert losses["total"].item() == pytest.approx(float(fx["deblur_loss_total"]), rel=2e-3)
     assert np.abs(outputs["pred_aif"][0, :, ::16, ::16].cpu().numpy() - fx["pred_aif_head"]).max() < 2e-3
+
+
+@pytest.mark.gpu
+def test_cost_volume_other_cuda_dtypes_take_the_reference_formulation():
+    """bf16 autocast and float64 gradcheck of the depth network on the GPU: dtypes the
+    kernel is not built for go through the reference's own slice-assignment formulation."""
+    from sdirt_amd.dfdp import dp_cost_volume, _cost_volume_reference
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(1, 4, 6, 12, generator=g).cuda()
+    y = torch.randn(1, 4, 6, 12, generator=g).cuda()
+    want = dp_cost_volume(x, y, 8)
+    for dt in (torch.bfloat16, torch.float64):
+        got = dp_cost_volume(x.to(dt), y.to(dt), 8)
+        assert got.dtype == dt and torch.equal(got, _cost_volume_reference(x.to(dt), y.to(dt), 8))
+        assert torch.allclose(got.float(), want, atol=2e-2)
+    xd = x.double().requires_grad_(True)
+    assert torch.autograd.gradcheck(lambda a: dp_cost_volume(a, y.double(), 8), (xd,), nondet_tol=0)

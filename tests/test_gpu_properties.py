@@ -56,18 +56,14 @@ def test_full_config2_volume(lens):
     assert torch.allclose(R1.sum((1, 2)), L2.sum((1, 2)), rtol=2e-5)
 
 
-@pytest.mark.parametrize("name,ks,spp,n_z", [("rf35mm", 65, 4096, 16), ("rf50mm", 21, 8192, 8)])
-def test_other_baseline_configs_full_size(name, ks, spp, n_z):
+@pytest.mark.parametrize("name,workload,ks,spp,n_z", [("rf35mm", "c4", 65, 4096, 16), ("rf50mm", "c3", 21, 8192, 8)])
+def test_other_baseline_configs_full_size(name, workload, ks, spp, n_z):
     """BASELINE config 4 (rf35mm, 21 surfaces, same volume) and one GPU's share of config 3
     (dense grid, 8192 spp, ks 21) at full size: finite, non-negative, every PSF normalised,
     L and R energies consistent with the closed-form sub-pixel areas (s_l + s_r <= 1)."""
     import bench
     ln = make_lens(name, DEV)
-    bench.GRID_Z = n_z
-    try:
-        pts = bench.volume_points(1)
-    finally:
-        bench.GRID_Z = 16
+    pts = bench.volume_points(1, workload)
     torch.manual_seed(4)
     L, R = ln.psf_lr(pts, ks=ks, spp=spp, dp=DP, normalize=False)
     assert L.shape == (1024 * n_z, ks, ks)
@@ -534,3 +530,64 @@ def test_control_blocks_from_the_pool_are_zero_and_distinct(lens):
     assert len({b.data_ptr() for b in blocks}) == len(blocks)
     blocks[0].fill_(7)
     assert int(blocks[1].abs().sum()) == 0
+
+
+def test_control_block_pools_are_per_stream(lens):
+    """Rows handed out under stream B never come from a pool that was zero-filled on stream A
+    (the fill could run after a kernel on B had OR-ed its masks into the row)."""
+    a = lens._zeroed_control_block(65)
+    side = torch.cuda.Stream(DEV)
+    with torch.cuda.stream(side):
+        b = lens._zeroed_control_block(65)
+        c = lens._zeroed_control_block(65)
+    d = lens._zeroed_control_block(65)
+    base = lambda t: t.untyped_storage().data_ptr()
+    assert base(a) == base(d) and base(b) == base(c) and base(a) != base(b)
+    # two streams rendering on one lens (train_psfnet's producer / evaluator pattern)
+    pts = torch.tensor([[0.1, 0.2, -1000.0], [-0.4, 0.3, -5000.0]], device=DEV)
+    torch.manual_seed(3)
+    L0, R0 = lens.psf_lr(pts, ks=21, spp=512)
+    with torch.cuda.stream(side):
+        torch.manual_seed(3)
+        L1, R1 = lens.psf_lr(pts, ks=21, spp=512)
+    torch.cuda.synchronize()
+    assert torch.allclose(L0, L1, atol=2e-6) and torch.allclose(R0, R1, atol=2e-6)
+
+
+def test_inference_mode_and_cpu_points_bypass_the_object_point_cache(lens):
+    with torch.inference_mode():
+        pts = torch.tensor([[0.1, 0.2, -1000.0]], device=DEV)
+        torch.manual_seed(9)
+        L0, _ = lens.psf_lr(pts, ks=21, spp=256)
+    arr = np.array([[0.1, 0.2, -1000.0]], dtype=np.float32)
+    cpu = torch.from_numpy(arr)
+    torch.manual_seed(9)
+    L1, _ = lens.psf_lr(cpu, ks=21, spp=256)
+    assert torch.allclose(L0, L1, atol=2e-6)
+    arr[0, 0] = -0.6                                   # numpy-side write: no version bump
+    torch.manual_seed(9)
+    L2, _ = lens.psf_lr(cpu, ks=21, spp=256)
+    assert not torch.allclose(L1, L2, atol=1e-3)
+
+
+def test_prefetch_selftest_runs_at_first_upload_and_catches_a_disagreement(monkeypatch):
+    """The load-time guard of the hand-scheduled scalar prefetch: passes on the shipped library,
+    and raises when the two trace forms are made to disagree."""
+    from sdirt_amd import _lib, Lensgroup
+    Lensgroup._selftest_done.clear()
+    ln = make_lens("rf50mm", DEV)
+    ln.dev_lens(0.589)                                  # runs the self-test
+    assert Lensgroup._selftest_done
+    Lensgroup._selftest_done.clear()
+    real = _lib.lib().sdirt_trace
+
+    def skewed(handle, first, last, backward, trips, flags, rays, n, mask, stream):
+        if flags & _lib.TRACE_NO_PREFETCH:               # trace one surface less: a stand-in for stale constants
+            last = last - 1 if not backward else last
+            first = first + 1 if backward else first
+        return real(handle, first, last, backward, trips, flags, rays, n, mask, stream)
+    monkeypatch.setattr(_lib.lib(), "sdirt_trace", skewed)
+    with pytest.raises(_lib.SdirtError, match="self-test failed"):
+        make_lens("rf50mm", DEV).dev_lens(0.589)
+    monkeypatch.undo()
+    Lensgroup._selftest_done.clear()

@@ -186,6 +186,11 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(h, s), f"libsdirt_dp.so does not export {s}"
     assert h.sdirt_abi_version() == 1
+    # ... and nothing but them (no kernel stubs, no experiment hooks)
+    import subprocess
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH], text=True)
+    exported = {l.split()[-1] for l in out.splitlines() if l.split()[-2] in "TDB"}
+    assert exported == syms, exported ^ syms
 
 
 def test_ctypes_structs_match_the_c_header(tmp_path):
@@ -337,32 +342,3 @@ def test_shard_bounds_partition_properties():
         sizes = [hi - lo for lo, hi in b]
         assert max(sizes) - min(sizes) <= 1
     check()
-
-
-def test_specialised_trace_source_carries_the_table_constants():
-    """sdirt_emit_spec (experimental, host only): one accessor type per surface and table, the
-    constants as the exact bit patterns of the device table, the surface loop unrolled."""
-    import ctypes as C
-    import struct
-    from sdirt_amd import _lib
-    from sdirt_amd.basics import DEFAULT_WAVE
-    from conftest import make_lens
-    lens = make_lens("rf50mm", "cpu")
-    K = len(lens.surfaces)
-    arr = _lib.SurfaceDesc * K
-    prim = arr(*[s.desc(0.486) for s in lens.surfaces])
-    cen = arr(*[s.desc(DEFAULT_WAVE) for s in lens.surfaces])
-    h = _lib.lib()
-    n = h.sdirt_emit_spec(prim, cen, K, None, 0)
-    assert n > 1000
-    buf = C.create_string_buffer(n)
-    assert h.sdirt_emit_spec(prim, cen, K, buf, n) == n
-    txt = buf.value.decode()
-    assert txt.count("surface_reaction<true, M>") == 2 * K and f"kSpecSurfaces = {K}" in txt
-    bits = lambda v: "0x%08xu" % struct.unpack("<I", struct.pack("<f", v))[0]
-    s1 = lens.surfaces[1]
-    assert bits(np.float32(s1.c)) in txt and bits(np.float32(s1.d)) in txt
-    # the two tables differ in their refractive indices only
-    eta = lambda w: bits(np.float32(s1.desc(w).n1 / s1.desc(w).n2))
-    assert eta(0.486) in txt and eta(DEFAULT_WAVE) in txt and eta(0.486) != eta(DEFAULT_WAVE)
-    assert h.sdirt_emit_spec(prim, cen, 0, None, 0) == -1

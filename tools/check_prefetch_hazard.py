@@ -9,8 +9,9 @@ particular no v_writelane spill of those SGPRs.  This script walks the control-f
 kernel in the `.s` from each issue site along ALL paths until an `s_waitcnt` that covers
 lgkmcnt(0), and fails if an instruction on the way names one of the destination registers.
 
-  make -C sdirt_amd/csrc asm && python tools/check_prefetch_hazard.py sdirt_amd/csrc/sdirt_dp.gfx950.s
-(__graft_entry__.build() runs it.)
+  python tools/check_prefetch_hazard.py sdirt_amd/csrc/obj/sdirt_psf-hip-amdgcn-amd-amdhsa-gfx950.s
+(run by the compile rule of sdirt_amd/csrc/Makefile on the ISA of that very compile: an object of a
+trace TU only exists if its ISA passed.)
 """
 import re
 import sys

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Instruction-class histogram of one kernel's gfx950 ISA, loop by loop.
 
-  make -C sdirt_amd/csrc asm
-  python tools/isa_hist.py sdirt_amd/csrc/sdirt_dp.gfx950.s 'k_psf_lrILb1ELb0EN5sdirt4LeanELb1' [--json out.json]
+  make -C sdirt_amd/csrc        (leaves the device ISA of every translation unit in csrc/obj/)
+  python tools/isa_hist.py sdirt_amd/csrc/obj/sdirt_psf-hip-amdgcn-amd-amdhsa-gfx950.s \
+         'k_psf_lrILb1ELb0EN5sdirt4LeanELb1' [--json out.json]
 
 Reads the compiler's `.s` (hipcc -S --cuda-device-only), cuts out the kernel whose mangled name
 contains the pattern, assigns every instruction to its innermost loop using LLVM's own block
