@@ -330,7 +330,7 @@ __device__ __forceinline__ void normalize3(float& x, float& y, float& z)
 // SGPR source operand issues at 0.55x the rate of one with VGPR / inline-constant sources on
 // gfx950 (tools/form_bench.hip: 4.2 vs 2.25 cycles per SIMD at 8 waves); six per trip against
 // four v_mov per surface.  (End to end the two forms time the same within run-to-run noise:
-// profiles/r02 kbench logs; SDIRT_CONIC_SGPR selects the SGPR form.)
+// profiles/r02 kbench logs, profiles/r03/k_psf_lr_sites.txt; tools/variants/form_conic_sgpr.py builds the SGPR form.)
 struct ConicV {
     float c, c2, onepk, d;
 };
@@ -392,8 +392,7 @@ template <class M, bool KGT, class P, bool UNITK = false, class S = Surf>
 __device__ __forceinline__ bool newton_k(const S& s, const P& pol, const Ray& r, int trips, float& t_out,
                                          uint32_t& mask_out)
 {
-    using CV =
-        ConicV;
+    using CV = ConicV;
     const bool adaptive = trips < 0;
     const int cap = adaptive ? -trips : trips;
     const float tol_loose = (float)50e-6, tol_tight = (float)10e-6, eps = (float)1e-9;

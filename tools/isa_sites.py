@@ -30,24 +30,29 @@ HALF = ("valu_s", "valu_f64", "lane")
 
 def parse(body, files):
     """-> list of (file, line, loop header, depth, class, text)"""
-    out, cur, loc = [], ("straight", 0), ("?", 0)
+    out, cur, loc, last_label = [], ("straight", 0), ("?", 0), None
     for l in body:
         t = l.strip()
         m = re.match(r"\.loc\s+(\d+)\s+(\d+)", t)
         if m:
             loc = (files.get(int(m.group(1)), m.group(1)), int(m.group(2)))
             continue
-        h = re.search(r"=>This (?:Inner )?Loop Header: Depth=(\d+)", l)
-        if h:
-            lab = re.match(r"^(\.LBB\d+_\d+):", l)
-            cur = (lab.group(1)[1:] if lab else "?", int(h.group(1)))
+        lab = re.match(r"^\.(LBB\d+_\d+):", l)
+        if lab:
+            last_label = lab.group(1)[1:]
+            i = re.search(r"in Loop: Header=(BB\d+_\d+) Depth=(\d+)", l)
+            if i:
+                cur = (i.group(1), int(i.group(2)))
+            elif "Loop" not in l:
+                cur = ("straight", 0)
+        # the header of a loop: the comment may sit on the label's line or on a continuation line
+        h = re.search(r"=>\s*This (?:Inner )?Loop Header: Depth=(\d+)", l)
+        if h and last_label:
+            cur = (last_label, int(h.group(1)))
             continue
-        i = re.search(r"in Loop: Header=(BB\d+_\d+) Depth=(\d+)", l)
-        if i:
-            cur = (i.group(1), int(i.group(2)))
-            continue
-        if (t.startswith("; %bb.") or re.match(r"^\.LBB\d+_\d+:", l)) and "Loop" not in l:
-            cur = ("straight", 0)
+        if t.startswith("; %bb."):
+            i = re.search(r"in Loop: Header=(BB\d+_\d+) Depth=(\d+)", l)
+            cur = (i.group(1), int(i.group(2))) if i else ("straight", 0)
             continue
         if not t or t.startswith(";") or t.startswith(".") or t.endswith(":"):
             continue
