@@ -267,6 +267,44 @@ int sdirt_psf_rgb_centered(const sdirt_lens* const* lens /*host [n_wvln]*/, int3
                            float* center, int32_t* any_valid, float* l_psf, float* r_psf,
                            uint32_t* conv_mask, uint32_t* conv_mask_center, void* stream);
 
+/* ---- speculate, verify on the device, re-render once ---------------------- */
+
+/* How sdirt_psf_lr_centered cuts the spp axis for (n_points, spp): 1 = one workgroup per point (the
+ * chief-ray pass runs inside the same kernel); > 1 = few points with many samples (the PSFNet
+ * fitting loop: 64 points x 20000 spp, deeplens/psfnet.py:101-167), several workgroups per point. */
+int32_t sdirt_psf_spp_slices(int64_t n_points, int64_t spp);
+
+/* Control block of sdirt_psf_lr_verified: SDIRT_CTL_WORDS uint32 words at the start of `scratch`. */
+#define SDIRT_CTL_STATUS 0     /* 0: the speculated tables were the reference's (round 2 did nothing);       */
+                               /* else bit 0 | bit 1 (primary table corrected) | bit 2 (chief-ray table corrected) */
+#define SDIRT_CTL_ANY_VALID 1  /* 1 if any chief ray reached the sensor (optics.py:902)                      */
+#define SDIRT_CTL_TRIPS2 16    /* 16 + 16 words: the tables round 2 ran, one signed byte per surface         */
+#define SDIRT_CTL_MASKS 64     /* 4 x 64 words: convergence masks of round 1 (primary, chief), round 2 (same) */
+#define SDIRT_CTL_WORDS 320
+int64_t sdirt_psf_verified_scratch_bytes(int64_t n_points, int64_t spp_center);
+
+/* sdirt_psf_lr_centered for the case sdirt_psf_spp_slices(n_points, spp) > 1, WITHOUT a host round trip
+ * when the speculated trip tables turn out wrong: round 1 renders with `trips` / `trips_center`; its
+ * last kernel checks both tables against the convergence masks the round produced (the rule of
+ * sdirt_trace, evaluated on the device) and writes the corrected tables into the control block;
+ * round 2 -- the same kernels, enqueued right behind -- re-renders with them, or returns at once
+ * when round 1 was right.  The host reads the control block once: status, the tables that were
+ * run, the masks of both rounds.  (A table speculated from above is corrected exactly in one round;
+ * if round 2's masks still disagree the caller goes on as with sdirt_psf_lr_centered.)
+ * The chief-ray pass runs in slices too (partial sums in `scratch`, added in slice order).
+ * scratch: dev, 8-byte aligned, sdirt_psf_verified_scratch_bytes(n_points, spp_center) bytes, its first
+ * SDIRT_CTL_WORDS words zeroed by the caller.  Returns SDIRT_ERR_UNSUPPORTED when
+ * sdirt_psf_spp_slices(n_points, spp) == 1. */
+int sdirt_psf_lr_verified(const sdirt_lens* lens, const sdirt_lens* lens_center,
+                          const float* point_obj /*dev [N,3]*/, int64_t n_points,
+                          const float* x2 /*dev [S]*/, const float* y2 /*dev [S]*/, int64_t spp,
+                          const float* xc /*dev [Sc]*/, const float* yc /*dev [Sc]*/, int64_t spp_center,
+                          double pupil_z, double d_sensor, double ps, int32_t ks,
+                          const sdirt_dp_params* dp /*host or NULL*/, const int32_t* trips /*host [K]*/,
+                          const int32_t* trips_center /*host [K]*/, uint32_t flags,
+                          float* center /*dev [N,2], out*/, float* l_psf /*dev [N,ks,ks]*/,
+                          float* r_psf /*dev or NULL*/, void* scratch /*dev*/, void* stream);
+
 /* ---- diagnostics ----------------------------------------------------------- */
 
 /* Counts how often the lean arithmetic (the default, see SDIRT_PSF_STRICT_IEEE) differs from correctly rounded IEEE:

@@ -19,6 +19,7 @@ MAX_WAVELENGTHS = 3
 PSF_NORMALIZE = 1
 PSF_STRICT_IEEE = 4
 TRACE_NO_PREFETCH = 8
+CTL_STATUS, CTL_ANY_VALID, CTL_TRIPS2, CTL_MASKS, CTL_WORDS = 0, 1, 16, 64, 320
 
 KIND_PLANE, KIND_SPHERE, KIND_ASPHERE = 0, 1, 2
 
@@ -75,6 +76,11 @@ SIGNATURES = {
     "sdirt_psf_rgb_centered": (C.c_int, [C.POINTER(_P), _I32, _P, _P, _I64, _P, _P, _I64, _P, _P, _I64, _D, _D, _D,
                                          _I32, C.POINTER(DpParams), C.POINTER(_I32), C.POINTER(_I32), _U32,
                                          _P, _P, _P, _P, _P, _P, _P]),
+    "sdirt_psf_spp_slices": (_I32, [_I64, _I64]),
+    "sdirt_psf_verified_scratch_bytes": (_I64, [_I64, _I64]),
+    "sdirt_psf_lr_verified": (C.c_int, [_P, _P, _P, _I64, _P, _P, _I64, _P, _P, _I64, _D, _D, _D, _I32,
+                                        C.POINTER(DpParams), C.POINTER(_I32), C.POINTER(_I32), _U32,
+                                        _P, _P, _P, _P, _P]),
     "sdirt_selftest_math": (C.c_int, [_I32, C.c_uint64, C.c_uint64, _I32, _P, _P]),
     "sdirt_local_psf_render": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P, _P]),
     "sdirt_psfnet_render": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P]),
@@ -114,17 +120,26 @@ class _Library:
     def _guard(fn):
         def call(*args):
             st = args[-1]
-            if isinstance(st, StreamArg):
-                import torch
-                if st.index != torch.cuda.current_device():
-                    with torch.cuda.device(st.index):
-                        return fn(*args)
+            if st.__class__ is StreamArg and st.index != _torch_cuda.current_device():
+                with _torch_cuda.device(st.index):
+                    return fn(*args)
             return fn(*args)
         call.__name__ = fn.__name__
         return call
 
 
 _lib = None
+
+
+class _LazyTorchCuda:
+    """torch.cuda, imported on first use (this module loads without torch for header checks)."""
+    def __getattr__(self, name):
+        import torch
+        globals()["_torch_cuda"] = torch.cuda
+        return getattr(torch.cuda, name)
+
+
+_torch_cuda = _LazyTorchCuda()
 
 
 def lib():

@@ -175,6 +175,146 @@ k_chief_center(TripTable trips /* kernarg offset 0 */, const DevSurface* __restr
         atomicOr(&conv_mask[threadIdx.x], lds_mask[threadIdx.x]);
 }
 
+// ---------------------------------------------------------------------------
+// speculate -> verify ON THE DEVICE -> re-render once (sdirt_psf_lr_verified)
+// ---------------------------------------------------------------------------
+// Control block of a verified call, uint32 words in device memory (zeroed by the caller):
+// what the host needs to accept the result -- or to go on correcting -- in ONE readback.
+constexpr int kCtlStatus = SDIRT_CTL_STATUS, kCtlAnyValid = SDIRT_CTL_ANY_VALID,
+              kCtlTrips2P = SDIRT_CTL_TRIPS2, kCtlTrips2C = SDIRT_CTL_TRIPS2 + 16,
+              kCtlMask1P = SDIRT_CTL_MASKS, kCtlMask1C = SDIRT_CTL_MASKS + 64,
+              kCtlMask2P = SDIRT_CTL_MASKS + 128, kCtlMask2C = SDIRT_CTL_MASKS + 192;
+static_assert(kCtlMask2C + 64 == SDIRT_CTL_WORDS, "control block layout");
+
+// Arguments of the split path (several workgroups per point) of a verified call.
+struct SplitArgs {
+    const uint32_t* gate;        // round 2: the control block; the kernel returns at once when its
+                                 // status word says that round 1 was already right
+    const uint32_t* trips_dev;   // round 2: the corrected trip table (TripTable layout) in device memory
+    const double* part;          // chief-ray partial sums [N][nslice][3] (sx, sy, sr), or nullptr
+    int nslice;
+};
+
+// The chief-ray pass of a point cut into `nslice` workgroups (N = 64 points alone leave three
+// quarters of the chip idle and every lane with four rays in a row): each writes its fp64 partial
+// sums; the consumers add them in slice order (a fixed order: deterministic).  Also clears the
+// output grids the primary pass will add to (global float atomics).
+template <class HotMath>
+__global__ void __launch_bounds__(kFused, 8)
+k_chief_slices(TripTable trips /* kernarg offset 0 */, SplitArgs sa, const DevSurface* __restrict__ lens, int K,
+               const float* __restrict__ po, const float* __restrict__ xc, const float* __restrict__ yc,
+               int Sc, int chunk, float pz, float zs, double* __restrict__ part, uint32_t* __restrict__ any_valid,
+               uint32_t* __restrict__ conv_mask, float* __restrict__ zero_a, float* __restrict__ zero_b,
+               int64_t zero_n)
+{
+    __shared__ uint32_t lds_mask[SDIRT_MAX_SURFACES];
+    __shared__ double red[3][kFused];
+    __shared__ int red_any;
+    if (sa.gate && sa.gate[kCtlStatus] == 0u) return;              // wave-uniform
+    const void* trip_words = sa.trips_dev ? (const void*)sa.trips_dev : kernarg_at(0);
+    const int n = blockIdx.x / sa.nslice, j = blockIdx.x - n * sa.nslice;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < zero_n; i += (int64_t)gridDim.x * blockDim.x) {
+        zero_a[i] = 0.0f;
+        if (zero_b) zero_b[i] = 0.0f;
+    }
+    if (threadIdx.x < SDIRT_MAX_SURFACES) lds_mask[threadIdx.x] = 0;
+    if (threadIdx.x == 0) red_any = 0;
+    __syncthreads();
+    const float px = po[3 * n], py = po[3 * n + 1], pzo = po[3 * n + 2];
+    double sx = 0.0, sy = 0.0, sr = 0.0;
+    int any = 0;
+    const int s_end = min(Sc, (j + 1) * chunk);
+    for (int s = j * chunk + threadIdx.x; s < s_end; s += blockDim.x) {
+        Ray r = make_ray<HotMath>(px, py, pzo, xc[s], yc[s], pz);
+        trace_ray<true, HotMath>(lens, 0, K, trip_words, r, lds_mask);
+        propagate_to<HotMath>(r, zs);
+        sx += (double)(r.ox * r.ra);
+        sy += (double)(r.oy * r.ra);
+        sr += (double)r.ra;
+        any |= (r.ra == 1.0f);
+    }
+    red[0][threadIdx.x] = sx; red[1][threadIdx.x] = sy; red[2][threadIdx.x] = sr;
+    if (any) red_any = 1;
+    __syncthreads();
+    for (int off = kFused / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + off];
+            red[1][threadIdx.x] += red[1][threadIdx.x + off];
+            red[2][threadIdx.x] += red[2][threadIdx.x + off];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        double* o = part + (int64_t)blockIdx.x * 3;
+        o[0] = red[0][0]; o[1] = red[1][0]; o[2] = red[2][0];
+        if (red_any) atomicOr(any_valid, 1u);
+    }
+    if ((int)threadIdx.x < K && lds_mask[threadIdx.x]) atomicOr(&conv_mask[threadIdx.x], lds_mask[threadIdx.x]);
+}
+
+// sdirt_amd/newton.py: verify() on the device.  `t` ran, `mask` is what it reported; writes the
+// table the next round should run (t itself when it was exactly the reference's) and says whether
+// t was right.  One thread; K <= 64.
+__device__ bool verify_trips(const TripTable& t, const uint32_t* __restrict__ mask,
+                             const DevSurface* __restrict__ lens, int K, uint32_t* __restrict__ out_words)
+{
+    uint32_t nw[SDIRT_MAX_SURFACES / 4];
+    for (int i = 0; i < SDIRT_MAX_SURFACES / 4; ++i) nw[i] = t.w[i];
+    bool failed = false;
+    for (int k = 0; k < K; ++k) {
+        const int sh = (k & 3) * 8;
+        const int T = (int)(int8_t)(t.w[k >> 2] >> sh);
+        int nv;
+        if ((lens[k].h.flags & 3u) == 0u) {
+            nv = 0;                                            // planes: no Newton solve
+        } else {
+            int j = 0;                                         // first clear bit among 1..T
+            const uint32_t m = mask[k];
+            for (int b = 1; b <= T; ++b)
+                if (!((m >> b) & 1u)) { j = b; break; }
+            if (!failed) {
+                if (T >= 1 && (j == T || (j == 0 && T == SDIRT_NEWTON_MAXITER))) continue;
+                failed = true;
+            }
+            nv = j ? j : min(max(T, 0) + 1, SDIRT_NEWTON_MAXITER);
+        }
+        nw[k >> 2] = (nw[k >> 2] & ~(0xffu << sh)) | ((uint32_t)(uint8_t)(int8_t)nv << sh);
+    }
+    for (int i = 0; i < SDIRT_MAX_SURFACES / 4; ++i) out_words[i] = failed ? nw[i] : t.w[i];
+    return !failed;
+}
+
+// Last kernel of a round of the split path: max-normalise L (blockIdx.y 0) and R (1), and -- round 1
+// -- check both trip tables against the masks the round produced: status 0 = the reference's tables,
+// nothing more to do; else bit 0 set (bit 1: primary table wrong, bit 2: chief-ray table wrong) and
+// the corrected tables stand in the control block for round 2, which is already enqueued.
+struct FinishArgs {
+    const uint32_t* gate;      // round 2: skip unless status != 0
+    uint32_t* ctl;             // round 1: verify into this block (nullptr: no verification)
+    const DevSurface* lens;    // surface kinds (the same in every wavelength's table)
+    int K;
+    TripTable tp, tc;          // the tables round 1 ran
+};
+__global__ void __launch_bounds__(kBlock) k_psf_finish(float* __restrict__ l, float* __restrict__ r, int tile,
+                                                       int normalize, FinishArgs fa)
+{
+    __shared__ float red[kBlock / 64];
+    if (fa.gate && fa.gate[kCtlStatus] == 0u) return;
+    float* g = (blockIdx.y == 0 ? l : r) + (int64_t)blockIdx.x * tile;
+    if (normalize) {
+        float mx = -INFINITY;
+        for (int i = threadIdx.x; i < tile; i += blockDim.x) mx = fmaxf(mx, g[i]);
+        mx = block_max(mx, red);
+        const float den = mx + 1e-6f;
+        for (int i = threadIdx.x; i < tile; i += blockDim.x) g[i] = g[i] / den;
+    }
+    if (fa.ctl && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        const bool okp = verify_trips(fa.tp, fa.ctl + kCtlMask1P, fa.lens, fa.K, fa.ctl + kCtlTrips2P);
+        const bool okc = verify_trips(fa.tc, fa.ctl + kCtlMask1C, fa.lens, fa.K, fa.ctl + kCtlTrips2C);
+        fa.ctl[kCtlStatus] = (okp && okc) ? 0u : (1u | (okp ? 0u : 2u) | (okc ? 0u : 4u));
+    }
+}
+
 // psf_diff fused: sample -> trace -> propagate -> window -> DP weights -> LDS
 // splat -> (max-normalise) -> store.  gridDim.x = N * nsplit; the workgroup
 // (n, j) handles samples [j*chunk, (j+1)*chunk) of point n.
@@ -214,9 +354,10 @@ k_psf_lr(SplatBlock sb /* kernarg offset 0 */, TripSet trips /* 64 */, TripSet t
          LensSet lens_set, int K, const float* __restrict__ po, const float* __restrict__ x2,
          const float* __restrict__ y2, int S, int nsplit, int chunk, float pz, float zs, int ks, float tr,
          float tl, const float* __restrict__ center, uint32_t flags, float* __restrict__ lout,
-         float* __restrict__ rout, uint32_t* __restrict__ conv_mask, CenterArgs ca)
+         float* __restrict__ rout, uint32_t* __restrict__ conv_mask, CenterArgs ca, SplitArgs sa)
 {
     extern __shared__ __attribute__((aligned(16))) float tiles[];   // [L | R] ks*ks each
+    if (!CENTER && sa.gate && sa.gate[kCtlStatus] == 0u) return;    // round 2 of a verified call, nothing to redo
     __shared__ uint32_t lds_mask[SDIRT_MAX_SURFACES];
     __shared__ float red[kFused / 64];
     __shared__ float c_sh[2];
@@ -284,13 +425,28 @@ k_psf_lr(SplatBlock sb /* kernarg offset 0 */, TripSet trips /* 64 */, TripSet t
         }
     }
 
+    const bool from_parts = !CENTER && sa.part != nullptr;
+    if (from_parts && threadIdx.x == 0) {
+        // the chief-ray centre from the slices' partial sums, added in slice order (k_chief_slices);
+        // the finish is k_chief_center's
+        double sx = 0.0, sy = 0.0, sr = 0.0;
+        for (int q = 0; q < sa.nslice; ++q) {
+            const double* pq = sa.part + ((int64_t)n * sa.nslice + q) * 3;
+            sx += pq[0]; sy += pq[1]; sr += pq[2];
+        }
+        const float den = (float)sr + (float)1e-9;
+        c_sh[0] = -((float)sx / den);
+        c_sh[1] = -((float)sy / den);
+        if (j == 0) { ca.center_out[2 * n] = c_sh[0]; ca.center_out[2 * n + 1] = c_sh[1]; }
+    }
     for (int i = threadIdx.x; i < (HAVE_R ? 2 : 1) * tile; i += blockDim.x) tiles[i] = 0.0f;
     if (threadIdx.x < SDIRT_MAX_SURFACES) lds_mask[threadIdx.x] = 0;
     __syncthreads();
 
-    const float cx = CENTER ? c_sh[0] : center[2 * n], cy = CENTER ? c_sh[1] : center[2 * n + 1];
+    const float cx = (CENTER || from_parts) ? c_sh[0] : center[2 * n], cy = (CENTER || from_parts) ? c_sh[1] : center[2 * n + 1];
     const int s_end = min(S, (j + 1) * chunk);
     const void* kernarg = kernarg_at(0);
+    const void* primary_trips = (!CENTER && sa.trips_dev) ? (const void*)sa.trips_dev : kernarg_at(kTripsAt + 64 * w);
     auto splat = [&](float sx, float sy, float dx, float dz, float ra) {
         // the splat constants: one 64-byte scalar load per ray, dead again after the splat
         const u32x16 q = sload_block(kernarg);
@@ -322,7 +478,7 @@ k_psf_lr(SplatBlock sb /* kernarg offset 0 */, TripSet trips /* 64 */, TripSet t
     };
     for (int s = j * chunk + threadIdx.x; s < s_end; s += blockDim.x) {
         Ray r = make_ray<HotMath>(px, py, pzo, x2[s], y2[s], pz);
-        trace_ray<true, HotMath>(lens, 0, K, kernarg_at(kTripsAt + 64 * w), r, conv_mask ? lds_mask : nullptr);
+        trace_ray<true, HotMath>(lens, 0, K, primary_trips, r, conv_mask ? lds_mask : nullptr);
         propagate_to<HotMath>(r, zs);
         splat(r.ox, r.oy, r.dx, r.dz, r.ra);
     }
@@ -448,19 +604,42 @@ static int spp_split(int64_t N, int64_t S, int* chunk_out)
         if (nsplit > max_split) nsplit = max_split;
         if (nsplit < 1) nsplit = 1;
     }
+    // slices of equal length up to a wave: a slice rounded up to whole workgroup passes (512) left the
+    // last slice nearly empty and the CUs unevenly loaded (20000 spp: 13 x 1536 + 32 -> 16 x 1280, 17 % faster)
     int chunk = (int)((S + nsplit - 1) / nsplit);
-    chunk = ((chunk + kFused - 1) / kFused) * kFused;
+    chunk = ((chunk + 63) / 64) * 64;
     nsplit = (int)((S + chunk - 1) / (chunk > 0 ? chunk : 1));
     if (nsplit < 1) nsplit = 1;
     if (chunk_out) *chunk_out = chunk;
     return nsplit;
 }
 
+// Device scratch of a verified call: the control block, then the chief-ray partial sums.
+struct VerifiedRequest {
+    uint32_t* ctl;     // [SDIRT_CTL_WORDS], zeroed by the caller
+    double* part;      // [N][chief slices][3]
+};
+
+// The chief-ray pass of the split path in slices: enough workgroups to touch every CU, at least
+// one ray per lane and slice.
+static int chief_slices(int64_t N, int64_t Sc, int* chunk_out)
+{
+    int64_t ns = std::min<int64_t>((Sc + kFused - 1) / kFused, (256 + N - 1) / std::max<int64_t>(N, 1));
+    if (ns < 1) ns = 1;
+    int chunk = (int)((Sc + ns - 1) / ns);
+    chunk = (chunk + 63) / 64 * 64;
+    if (chunk < 64) chunk = 64;
+    ns = (Sc + chunk - 1) / chunk;
+    if (ns < 1) ns = 1;
+    if (chunk_out) *chunk_out = chunk;
+    return (int)ns;
+}
+
 static int launch_psf(const sdirt_lens* const* lens, int W, const float* point_obj, int64_t N,
                       const float* x2, const float* y2, int64_t S, double pupil_z, double d_sensor,
                       double ps, int32_t ks, const float* center, const CenterRequest* cen,
                       const sdirt_dp_params* dp, const TripSet& tt, uint32_t flags, float* l_psf,
-                      float* r_psf, uint32_t* conv_mask, void* stream)
+                      float* r_psf, uint32_t* conv_mask, void* stream, const VerifiedRequest* vr = nullptr)
 {
     const bool have_r = r_psf != nullptr;
     const int tile = ks * ks;
@@ -474,7 +653,10 @@ static int launch_psf(const sdirt_lens* const* lens, int W, const float* point_o
     hipStream_t st = as_stream(stream);
     const bool lean = (flags & SDIRT_PSF_STRICT_IEEE) == 0;
     const bool fuse_center = cen != nullptr && nsplit == 1;
-    if (cen && !fuse_center) {                       // split spp axis: centre as its own launch
+    if (vr && (!cen || nsplit == 1 || W != 1))
+        return fail(SDIRT_ERR_UNSUPPORTED, "verified call: one workgroup per point here (sdirt_psf_spp_slices == 1); "
+                                           "use sdirt_psf_lr_centered");
+    if (cen && !fuse_center && !vr) {                // split spp axis: centre as its own launch
         if (lean)
             k_chief_center<Lean><<<(int)N, kFused, 0, st>>>(
                 cen->trips_c.t[0], cen->lens_c->dev, K, point_obj, cen->xc, cen->yc, (int)cen->Sc,
@@ -486,7 +668,7 @@ static int launch_psf(const sdirt_lens* const* lens, int W, const float* point_o
         LAUNCH_CHECK();
         center = cen->center_out;
     }
-    if (nsplit > 1) {
+    if (nsplit > 1 && !vr) {
         HIP_TRY(hipMemsetAsync(l_psf, 0, sizeof(float) * (size_t)N * tile, st));
         if (have_r) HIP_TRY(hipMemsetAsync(r_psf, 0, sizeof(float) * (size_t)N * tile, st));
     }
@@ -509,6 +691,37 @@ static int launch_psf(const sdirt_lens* const* lens, int W, const float* point_o
         ca.conv_mask_c = cen->conv_mask_c;
         lds_bytes = std::max(lds_bytes, sizeof(double) * 3 * kFused);   // fp64 reduction scratch
     }
+    SplitArgs sa;
+    std::memset(&sa, 0, sizeof(sa));
+    // ---- verified call on the split path: round 1 with the speculated tables, the tables checked on
+    // the device by the round's last kernel, round 2 with the corrected tables enqueued right behind
+    // it -- its kernels return at once when round 1 was right.  No host round trip in between.
+    const int rounds = vr ? 2 : 1;
+    int chunk_c = 0;
+    const int nslice_c = vr ? chief_slices(N, cen->Sc, &chunk_c) : 0;
+    for (int round = 0; round < rounds; ++round) {
+    if (vr) {
+        uint32_t* ctl = vr->ctl;
+        sa.gate = round ? ctl : nullptr;
+        sa.part = vr->part;
+        sa.nslice = nslice_c;
+        sa.trips_dev = round ? ctl + kCtlTrips2C : nullptr;
+        uint32_t* mask_c = ctl + (round ? kCtlMask2C : kCtlMask1C);
+        float* zr = both ? r_psf : nullptr;
+        if (lean)
+            k_chief_slices<Lean><<<(int)(N * nslice_c), kFused, 0, st>>>(
+                cen->trips_c.t[0], sa, cen->lens_c->dev, K, point_obj, cen->xc, cen->yc, (int)cen->Sc, chunk_c,
+                (float)pupil_z, (float)d_sensor, vr->part, ctl + kCtlAnyValid, mask_c, l_psf, zr, (int64_t)N * tile);
+        else
+            k_chief_slices<Ieee><<<(int)(N * nslice_c), kFused, 0, st>>>(
+                cen->trips_c.t[0], sa, cen->lens_c->dev, K, point_obj, cen->xc, cen->yc, (int)cen->Sc, chunk_c,
+                (float)pupil_z, (float)d_sensor, vr->part, ctl + kCtlAnyValid, mask_c, l_psf, zr, (int64_t)N * tile);
+        LAUNCH_CHECK();
+        sa.trips_dev = round ? ctl + kCtlTrips2P : nullptr;
+        conv_mask = ctl + (round ? kCtlMask2P : kCtlMask1P);
+        ca.center_out = cen->center_out;
+        center = nullptr;
+    }
 #define SDIRT_LAUNCH_PSF(HR, BG, MM, CT)                                                          \
     do {                                                                                          \
         if (lds_bytes > 48 * 1024) /* large tiles: opt in to the full 160 KiB of LDS */           \
@@ -518,7 +731,7 @@ static int launch_psf(const sdirt_lens* const* lens, int W, const float* point_o
         k_psf_lr<HR, BG, MM, CT><<<grid, kFused, lds_bytes, st>>>(                                \
             sblk, tt, ttc, ls, K, point_obj, x2, y2, (int)S, nsplit, chunk, (float)pupil_z,       \
             (float)d_sensor, ks, dpp.tr, dpp.tl, center, flags, l_psf, both ? r_psf : nullptr,    \
-            conv_mask, ca);                                                                       \
+            conv_mask, ca, sa);                                                                   \
     } while (0)
 #define SDIRT_LAUNCH_PSF_C(HR, BG, MM)                                                            \
     do {                                                                                          \
@@ -532,14 +745,25 @@ static int launch_psf(const sdirt_lens* const* lens, int W, const float* point_o
         if (dpp.big) SDIRT_LAUNCH_PSF_M(true, true); else SDIRT_LAUNCH_PSF_M(true, false);
     } else {
         if (dpp.big) SDIRT_LAUNCH_PSF_M(false, true); else SDIRT_LAUNCH_PSF_M(false, false);
-        // param_list=None leaves the R grid all-zero (monte_carlo.py:230-235)
-        if (have_r) HIP_TRY(hipMemsetAsync(r_psf, 0, sizeof(float) * (size_t)N * W * tile, st));
     }
+    LAUNCH_CHECK();
+    if (vr) {
+        FinishArgs fa;
+        std::memset(&fa, 0, sizeof(fa));
+        fa.gate = round ? vr->ctl : nullptr;
+        fa.ctl = round ? nullptr : vr->ctl;
+        fa.lens = lens[0]->dev; fa.K = K; fa.tp = tt.t[0]; fa.tc = cen->trips_c.t[0];
+        k_psf_finish<<<dim3((unsigned)N, both ? 2u : 1u), kBlock, 0, st>>>(
+            l_psf, r_psf, tile, (flags & SDIRT_PSF_NORMALIZE) ? 1 : 0, fa);
+        LAUNCH_CHECK();
+    }
+    }   // rounds
 #undef SDIRT_LAUNCH_PSF_M
 #undef SDIRT_LAUNCH_PSF_C
 #undef SDIRT_LAUNCH_PSF
-    LAUNCH_CHECK();
-    if (nsplit > 1 && (flags & SDIRT_PSF_NORMALIZE)) {
+    // param_list=None leaves the R grid all-zero (monte_carlo.py:230-235)
+    if (!both && have_r) HIP_TRY(hipMemsetAsync(r_psf, 0, sizeof(float) * (size_t)N * W * tile, st));
+    if (!vr && nsplit > 1 && (flags & SDIRT_PSF_NORMALIZE)) {
         k_psf_normalize<<<(int)N, kBlock, 0, st>>>(l_psf, tile);
         if (have_r && dpp.have_r) k_psf_normalize<<<(int)N, kBlock, 0, st>>>(r_psf, tile);
         LAUNCH_CHECK();
@@ -611,6 +835,55 @@ int sdirt_psf_rgb_centered(const sdirt_lens* const* lens, int32_t W, const sdirt
     cr.any_valid = any_valid; cr.conv_mask_c = conv_mask_center;
     return launch_psf(lens, W, point_obj, N, x2, y2, S, pupil_z, d_sensor, ps, ks, nullptr, &cr, dp, tt,
                       flags, l_psf, r_psf, conv_mask, stream);
+}
+
+int32_t sdirt_psf_spp_slices(int64_t N, int64_t S)
+{
+    if (N < 1 || S < 1) return 1;
+    return spp_split(N, S, nullptr);
+}
+
+static size_t ctl_bytes() { return (sizeof(uint32_t) * SDIRT_CTL_WORDS + 63) / 64 * 64; }
+
+int64_t sdirt_psf_verified_scratch_bytes(int64_t N, int64_t Sc)
+{
+    if (N < 0 || Sc < 0) return -1;
+    return (int64_t)ctl_bytes() + (int64_t)sizeof(double) * 3 * N * chief_slices(std::max<int64_t>(N, 1), Sc, nullptr);
+}
+
+int sdirt_psf_lr_verified(const sdirt_lens* lens, const sdirt_lens* lens_center, const float* point_obj,
+                          int64_t N, const float* x2, const float* y2, int64_t S, const float* xc,
+                          const float* yc, int64_t Sc, double pupil_z, double d_sensor, double ps, int32_t ks,
+                          const sdirt_dp_params* dp, const int32_t* trips, const int32_t* trips_center,
+                          uint32_t flags, float* center, float* l_psf, float* r_psf, void* scratch,
+                          void* stream)
+{
+    if (!lens || !lens_center || !point_obj || !x2 || !y2 || !xc || !yc || !center || !l_psf || !scratch ||
+        N < 0 || S < 0 || Sc < 0 || S > (1ll << 30) || Sc > (1ll << 30) || N > (1ll << 30))
+        return fail(SDIRT_ERR_INVALID_ARGUMENT, "bad argument");
+    if (((uintptr_t)scratch) & 7) return fail(SDIRT_ERR_INVALID_ARGUMENT, "scratch must be 8-byte aligned");
+    if (lens->n_surfaces != lens_center->n_surfaces)
+        return fail(SDIRT_ERR_INVALID_ARGUMENT, "surface count of lens and lens_center differ");
+    if (int rc = check_ks(ks)) return rc;
+    if (dp && !(dp->r > 0.0)) return fail(SDIRT_ERR_INVALID_ARGUMENT, "dp->r must be > 0");
+    if (!trips || !trips_center) return fail(SDIRT_ERR_INVALID_ARGUMENT, "a verified call needs both speculated tables");
+    for (int k = 0; k < lens->n_surfaces; ++k)
+        if (trips[k] < 0 || trips_center[k] < 0)
+            return fail(SDIRT_ERR_INVALID_ARGUMENT, "a verified call runs the reference's batch-wide counts: no negative (per-wave) entries");
+    TripSet tt;
+    CenterRequest cr;
+    std::memset(&tt, 0, sizeof(tt));
+    std::memset(&cr.trips_c, 0, sizeof(cr.trips_c));
+    if (int rc = make_trips(lens, trips, tt.t[0])) return rc;
+    if (int rc = make_trips(lens_center, trips_center, cr.trips_c.t[0])) return rc;
+    if (N == 0) return SDIRT_OK;
+    VerifiedRequest vr;
+    vr.ctl = static_cast<uint32_t*>(scratch);
+    vr.part = reinterpret_cast<double*>(static_cast<char*>(scratch) + ctl_bytes());
+    cr.lens_c = lens_center; cr.xc = xc; cr.yc = yc; cr.Sc = Sc; cr.center_out = center;
+    cr.any_valid = nullptr; cr.conv_mask_c = nullptr;
+    return launch_psf(&lens, 1, point_obj, N, x2, y2, S, pupil_z, d_sensor, ps, ks, nullptr, &cr, dp, tt, flags,
+                      l_psf, r_psf, nullptr, stream, &vr);
 }
 
 }  // extern "C"

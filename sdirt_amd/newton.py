@@ -84,7 +84,8 @@ class TripPlanner:
         self.cache = {}          # key -> last verified table
         self.votes = {}          # key -> {table: times verified}
         self.launches = 0
-        self.relaunches = 0
+        self.relaunches = 0          # rounds the HOST had to launch again
+        self.device_relaunches = 0   # corrections the device made on its own (sdirt_psf_lr_verified)
 
     def initial(self, key, curved):
         """Batches of one workload flip between a few neighbouring tables (the slowest ray of
@@ -123,23 +124,37 @@ class TripPlanner:
             trips = new
         raise RuntimeError("Newton trip-table speculation did not converge")  # pragma: no cover
 
-    def run_many(self, keys, curved, order, launch, max_rounds=None, first=None):
+    def run_many(self, keys, curved, order, launch, max_rounds=None, first=None, done=None):
         """Several independent passes verified in ONE launch/readback round (the chief-ray pass
         and the primary pass of a psf call).  launch(list_of_trip_tables) -> list of mask
         arrays, one per key.  All passes are re-launched together when any table was wrong.
         first = (tables, masks): a round that was already launched with `tables` (speculated by
-        `initial`) and has reported `masks` -- deferred verification, see Lensgroup.psf_lr."""
+        `initial`) and has reported `masks` -- deferred verification, see Lensgroup.psf_lr.
+        done = [(tables, masks), ...]: SEVERAL rounds the device has already run on its own
+        (sdirt_psf_lr_verified: round 1 with the speculated tables, round 2 with the tables the
+        device derived from round 1's masks).  Each is checked here with the same rule; the
+        device's correction must be the one this planner would have made."""
         K = len(curved)
-        tables = [self.initial(k, curved) for k in keys] if first is None else first[0]
+        if first is not None:
+            done = [first]
+        done = list(done or [])
+        tables = [self.initial(k, curved) for k in keys] if not done else done[0][0]
         rounds = max_rounds if max_rounds is not None else 3 * K + 3
         for i in range(rounds):
-            masks = first[1] if (first is not None and i == 0) else launch(tables)
+            masks = done[i][1] if i < len(done) else launch(tables)
             self.launches += 1
             results = [verify(t, m, order, curved, aggressive=i > 0) for t, m in zip(tables, masks)]
             if all(ok for ok, _ in results):
                 for k, t in zip(keys, tables):
                     self.learn(k, t)
                 return tables
-            self.relaunches += 1
             tables = [t if ok else new for t, (ok, new) in zip(tables, results)]
+            if i + 1 < len(done):
+                # the device re-rendered on its own: its tables are the first-round correction
+                self.device_relaunches += 1
+                dev = done[i + 1][0]
+                if not all(np.array_equal(np.asarray(a), np.asarray(b)) for a, b in zip(dev, tables)):
+                    raise RuntimeError(f"device-side trip correction {dev} differs from the host's {tables}")
+            else:
+                self.relaunches += 1
         raise RuntimeError("Newton trip-table speculation did not converge")  # pragma: no cover

@@ -186,6 +186,7 @@ class Lensgroup:
     def _invalidate(self):
         self._dev.clear()
         self._pupil_cache.clear()
+        self.__dict__.pop("_curved_cache", None)
 
     def find_aperture(self):
         """optics.py:193-201: first surface with air-like media on both sides."""
@@ -310,7 +311,10 @@ class Lensgroup:
         return _EventBracket(self.kernel_events, name, self.device)
 
     def _curved(self):
-        return [s.kind != _lib.KIND_PLANE for s in self.surfaces]
+        c = self.__dict__.get("_curved_cache")
+        if c is None or len(c) != len(self.surfaces):
+            c = self.__dict__["_curved_cache"] = [s.kind != _lib.KIND_PLANE for s in self.surfaces]
+        return c
 
     def _mask_buffer(self):
         return torch.zeros(_lib.MAX_SURFACES, dtype=torch.int32, device=self.device)
@@ -363,12 +367,12 @@ class Lensgroup:
                                                 stream_ptr(self.device)))
         return ray
 
-    def _staging(self, spp, depth=8):
-        """A page-locked [2, spp] buffer from a ring of `depth` per size, and the event that
+    def _staging(self, spp, depth=8, rows=2):
+        """A page-locked [rows, spp] buffer from a ring of `depth` per size, and the event that
         marks its upload as done; a slot is reused only after its previous upload has finished."""
-        ring = self.__dict__.setdefault("_stage_ring", {}).setdefault(spp, {"slots": [], "next": 0})
+        ring = self.__dict__.setdefault("_stage_ring", {}).setdefault((rows, spp), {"slots": [], "next": 0})
         if len(ring["slots"]) < depth:
-            ring["slots"].append((torch.empty((2, spp), dtype=torch.float32, pin_memory=True),
+            ring["slots"].append((torch.empty((rows, spp), dtype=torch.float32, pin_memory=True),
                                   torch.cuda.Event()))
             return ring["slots"][-1]
         slot = ring["slots"][ring["next"]]
@@ -417,6 +421,45 @@ class Lensgroup:
         main.wait_stream(side)
         xy.record_stream(main)
         return xy[0], xy[1]
+
+    def _pupil_samples_pair(self, spp, pupil_r, spp_c, pupil_r_c, side_stream=True):
+        """The two sample sets of one psf call -- `spp` points on the pupil, then `spp_c` on the
+        shrunk pupil of the chief-ray pass -- with ONE draw, ONE upload and one device block:
+        torch.rand(2 spp + 2 spp_c) is, value for value, the four consecutive draws
+        rand(spp), rand(spp), rand(spp_c), rand(spp_c) of the reference (optics.py:483-484 twice;
+        the CPU generator hands out one 24-bit number per element, whatever the call sizes:
+        tests/test_host_logic.py).  -> (x2, y2, xc, yc)."""
+        if self.pupil_mapping == "host":
+            return self._pupil_samples(spp, pupil_r) + self._pupil_samples(spp_c, pupil_r_c)
+        n = 2 * (spp + spp_c)
+        a, b = 2 * spp, 2 * spp + spp_c
+        h = _lib.lib()
+
+        def upload_and_map():
+            stage, done = self._staging(n, rows=1)
+            torch.rand(n, out=stage[0])
+            u = stage[0].to(self.device, non_blocking=True)
+            done.record(torch.cuda.current_stream(self.device))
+            xy = torch.empty(n, dtype=torch.float32, device=self.device)
+            st = stream_ptr(self.device)
+            pu, pxy = u.data_ptr(), xy.data_ptr()
+            P = lambda base, off: C.c_void_p(base + 4 * off)
+            _lib.check(h.sdirt_pupil_samples(P(pu, 0), P(pu, spp), spp, float(pupil_r), P(pxy, 0), P(pxy, spp), st))
+            _lib.check(h.sdirt_pupil_samples(P(pu, a), P(pu, b), spp_c, float(pupil_r_c), P(pxy, a), P(pxy, b), st))
+            return u, xy
+
+        if not side_stream:
+            # synchronous caller: nothing of an earlier call is in flight that the upload could run
+            # beside -- straight onto the caller's stream, no stream switch, no cross-stream waits
+            u, xy = upload_and_map()
+        else:
+            main = torch.cuda.current_stream(self.device)
+            side = self._side_stream("_sample_stream")
+            with torch.cuda.stream(side):
+                u, xy = upload_and_map()
+            main.wait_stream(side)
+            xy.record_stream(main)
+        return xy[:spp], xy[spp:a], xy[a:b], xy[b:]
 
     # ----------------------------------------------------------------- tracing
     def trace(self, ray, lens_range=None, record=False, forward=None):
@@ -643,7 +686,13 @@ class Lensgroup:
         # RNG order of the reference: primary pupil samples first (optics.py:963),
         # then the chief-ray samples inside psf_center (optics.py:969).
         pupilz, pupilr = self.entrance_pupil()
-        if pupil_xy is None:
+        both_drawn = None
+        if pupil_xy is None and center and center_pupil_xy is None:
+            # both sample sets of the call in one draw / upload (same numbers, same order)
+            both_drawn = self._pupil_samples_pair(spp, pupilr, GEO_SPP, self.entrance_pupil(shrink_pupil=True)[1],
+                                                  side_stream=defer)
+            x2, y2 = both_drawn[:2]
+        elif pupil_xy is None:
             x2, y2 = self._pupil_samples(spp, pupilr)
         else:
             x2, y2 = [torch.as_tensor(v).to(self.device, torch.float32).contiguous()
@@ -659,7 +708,9 @@ class Lensgroup:
         xc = yc = None
         if center:
             _, pupilr_c = self.entrance_pupil(shrink_pupil=True)
-            if center_pupil_xy is None:
+            if both_drawn is not None:
+                xc, yc = both_drawn[2:]
+            elif center_pupil_xy is None:
                 xc, yc = self._pupil_samples(GEO_SPP, pupilr_c)
             else:
                 xc, yc = [torch.as_tensor(v).to(self.device, torch.float32).contiguous()
@@ -692,7 +743,9 @@ class Lensgroup:
             MS = _lib.MAX_SURFACES
             # one control block: [primary masks | chief-ray masks | any-valid flag] -> one readback
             reference = self.trip_policy == "reference"
-            ctl = self._zeroed_control_block(2 * MS + 1)
+            verified = (reference and self.mask_reduce is None and N > 0
+                        and _lib.lib().sdirt_psf_spp_slices(N, spp) > 1)
+            ctl = None if verified else self._zeroed_control_block(2 * MS + 1)
 
             def enqueue2(tp, tc):
                 if N == 0:
@@ -739,20 +792,72 @@ class Lensgroup:
                     launch.any_valid = int(host[2 * MS])
                     return read_masks(host)
 
-                if defer:
-                    tables = [self.trips.initial(k, self._curved()) for k in keys]
-                    enqueue_round(tables, again=False)
-                    # the readback runs on its own stream: on the caller's it would sit between this
-                    # kernel and the next call's
+                def readback(block, n_words):
+                    """Asynchronous copy of the first n_words of a control block into page-locked
+                    memory on the read-back stream (on the caller's it would sit between this call's
+                    kernels and the next call's); -> (host tensor, event)."""
                     main = torch.cuda.current_stream(self.device)
                     rb = self._side_stream("_readback_stream")
                     rb.wait_stream(main)
-                    host = torch.empty(ctl.shape, dtype=ctl.dtype, pin_memory=True)
+                    host = torch.empty(n_words, dtype=block.dtype, pin_memory=True)
                     with torch.cuda.stream(rb):
-                        host.copy_(ctl, non_blocking=True)
-                    ctl.record_stream(rb)
+                        host.copy_(block[:n_words], non_blocking=True)
+                    block.record_stream(rb)
                     done = torch.cuda.Event()
                     done.record(rb)
+                    return host, done
+
+                if verified:
+                    # few points, many samples (the PSFNet fitting loop): several workgroups per point.
+                    # Speculate, verify ON THE DEVICE, re-render once behind it -- no host round trip
+                    # when the bet on the trip tables was wrong (sdirt_psf_lr_verified).
+                    W_ = _lib.CTL_WORDS
+                    words = _lib.lib().sdirt_psf_verified_scratch_bytes(N, xc.shape[0]) // 4
+                    scratch = self._zeroed_control_block(int(words))
+                    tables = [self.trips.initial(k, self._curved()) for k in keys]
+                    with self._timed("psf_lr_verified"):
+                        _lib.check(_lib.lib().sdirt_psf_lr_verified(
+                            handle, handle_c, dptr(po), N, dptr(x2), dptr(y2), spp, dptr(xc), dptr(yc),
+                            xc.shape[0], float(pupilz), float(self.d_sensor), float(self.pixel_size), ks, dp_ref,
+                            (C.c_int32 * K)(*[int(t) for t in tables[0]]),
+                            (C.c_int32 * K)(*[int(t) for t in tables[1]]), flags, dptr(cen), dptr(L), dptr(R),
+                            dptr(scratch), stream_ptr(self.device)))
+
+                    def settle(h):
+                        h = h.astype(np.int64) & 0xFFFFFFFF
+                        launch.any_valid = int(h[_lib.CTL_ANY_VALID])
+                        rounds = [(tables, [h[_lib.CTL_MASKS:_lib.CTL_MASKS + K],
+                                            h[_lib.CTL_MASKS + 64:_lib.CTL_MASKS + 64 + K]])]
+                        if h[_lib.CTL_STATUS]:
+                            unpack = lambda w: np.array([((int(w[k >> 2]) >> ((k & 3) * 8)) & 0xFF) for k in range(K)],
+                                                        np.int32).astype(np.int8).astype(np.int32)
+                            t2 = [unpack(h[_lib.CTL_TRIPS2:_lib.CTL_TRIPS2 + 16]),
+                                  unpack(h[_lib.CTL_TRIPS2 + 16:_lib.CTL_TRIPS2 + 32])]
+                            rounds.append((t2, [h[_lib.CTL_MASKS + 128:_lib.CTL_MASKS + 128 + K],
+                                                h[_lib.CTL_MASKS + 192:_lib.CTL_MASKS + 192 + K]]))
+                        self.trips.run_many(keys, self._curved(), list(range(K)), launch, done=rounds)
+                        assert launch.any_valid == 1, "No sampled rays is valid."   # optics.py:902
+                        return squeeze(L, R) if keep else None
+
+                    if defer:
+                        host, done = readback(scratch, W_)
+
+                        def finish_v():
+                            done.synchronize()
+                            return settle(host.numpy())
+                        return PendingPSF(finish_v)
+                    # synchronous form: into a page-locked buffer kept on the lens, then wait for the stream
+                    hbuf = self.__dict__.get("_ctl_host")
+                    if hbuf is None:
+                        hbuf = self.__dict__["_ctl_host"] = torch.empty(W_, dtype=torch.int32, pin_memory=True)
+                    hbuf.copy_(scratch[:W_], non_blocking=True)
+                    torch.cuda.current_stream(self.device).synchronize()
+                    return settle(hbuf.numpy().copy())
+
+                if defer:
+                    tables = [self.trips.initial(k, self._curved()) for k in keys]
+                    enqueue_round(tables, again=False)
+                    host, done = readback(ctl, 2 * MS + 1)
 
                     def finish():
                         done.synchronize()

@@ -591,3 +591,61 @@ def test_prefetch_selftest_runs_at_first_upload_and_catches_a_disagreement(monke
         make_lens("rf50mm", DEV).dev_lens(0.589)
     monkeypatch.undo()
     Lensgroup._selftest_done.clear()
+
+
+def _training_shape_inputs(n=64, spp=20000, seed=5):
+    st = load_state("rf50mm")
+    g = torch.Generator().manual_seed(seed)
+    pts = torch.stack([(torch.rand(n, generator=g) - 0.5) * 2, (torch.rand(n, generator=g) - 0.5) * 2,
+                       -(200 + torch.rand(n, generator=g) * 19800)], -1)
+    u = torch.rand(2, spp, generator=g)
+    th, r = u[0] * 2 * np.pi, torch.sqrt(u[1] * st["pupil_r"] ** 2)
+    uc = torch.rand(2, 2048, generator=g)
+    thc, rc = uc[0] * 2 * np.pi, torch.sqrt(uc[1] * (st["pupil_r"] * 0.25) ** 2)
+    return pts, (r * torch.cos(th), r * torch.sin(th)), (rc * torch.cos(thc), rc * torch.sin(thc))
+
+
+@pytest.mark.parametrize("bet", ["learned", "from_above", "from_below"])
+def test_device_side_trip_verification_on_the_split_path(bet):
+    """PSFNet's fitting shape (64 points x 20000 spp, ks 21): several workgroups per point,
+    sdirt_psf_lr_verified.  Whatever the speculated tables are, the call ends on the reference's
+    tables -- checked and, if need be, corrected and re-rendered ON THE DEVICE, without a host
+    re-launch when the bet was an upper bound -- and on the PSFs of the host-verified path."""
+    pts, xy, xyc = _training_shape_inputs()
+    ref_lens = make_lens("rf50mm", DEV)
+    ref_lens.mask_reduce = lambda m: m                    # forces the host-verified (round-2) path
+    L0, R0 = ref_lens.psf_lr(pts, ks=21, dp=DP, pupil_xy=xy, center_pupil_xy=xyc)
+    want = {k: np.asarray(v) for k, v in ref_lens.trips.cache.items()}
+    c0 = torch.empty((64, 2), device=DEV)
+    ref_lens.psf_lr(pts, ks=21, dp=DP, pupil_xy=xy, center_pupil_xy=xyc, center_out=c0)
+
+    ln = make_lens("rf50mm", DEV)
+    curved = np.array(ln._curved())
+    if bet != "learned":
+        for key, t in want.items():
+            wrong = t.copy()
+            k = int(np.flatnonzero(curved & (t < 10))[2])          # a surface in the middle of the stack
+            wrong[k] += 1 if bet == "from_above" else -1
+            ln.trips.learn(key, wrong)
+    else:
+        ln.psf_lr(pts, ks=21, dp=DP, pupil_xy=xy, center_pupil_xy=xyc)   # discovers the tables
+    r0, d0 = ln.trips.relaunches, ln.trips.device_relaunches
+    c1 = torch.empty((64, 2), device=DEV)
+    L1, R1 = ln.psf_lr(pts, ks=21, dp=DP, pupil_xy=xy, center_pupil_xy=xyc, center_out=c1)
+    for key, t in want.items():
+        assert np.array_equal(ln.trips.cache[key], t), (key, ln.trips.cache[key], t)
+    if bet == "learned":
+        assert (ln.trips.relaunches - r0, ln.trips.device_relaunches - d0) == (0, 0)
+    elif bet == "from_above":
+        assert (ln.trips.relaunches - r0, ln.trips.device_relaunches - d0) == (0, 1)
+    else:
+        assert ln.trips.device_relaunches - d0 == 1          # one trip more is the device's first guess
+    assert torch.equal(c0, c1) or float((c0 - c1).abs().max()) < 1e-6
+    assert float((L0 - L1).abs().max()) <= 3e-6 and float((R0 - R1).abs().max()) <= 3e-6
+    # deferred form: same call, verification in .wait()
+    pend = ln.psf_lr(pts, ks=21, dp=DP, pupil_xy=xy, center_pupil_xy=xyc, defer=True)
+    L2, R2 = pend.wait()
+    assert float((L0 - L2).abs().max()) <= 3e-6 and float((R0 - R2).abs().max()) <= 3e-6
+    # default param_list (R grid stays zero, monte_carlo.py:231) through the same path
+    a = ln.psf_diff(pts, ks=21, spp=20000)
+    assert a.shape == (64, 21, 21) and float(a.amax((1, 2)).min()) > 0.99

@@ -342,3 +342,18 @@ def test_shard_bounds_partition_properties():
         sizes = [hi - lo for lo, hi in b]
         assert max(sizes) - min(sizes) <= 1
     check()
+
+
+def test_one_rand_call_equals_the_reference_s_four_consecutive_draws():
+    """Lensgroup._pupil_samples_pair draws 2 spp + 2 x 2048 uniforms with ONE torch.rand call; the
+    reference makes four (optics.py:483-484 in sample_from_points, then again inside psf_center).
+    Same generator state, same numbers, whatever the sizes."""
+    import torch
+    for spp in (1, 17, 256, 4096, 20000):
+        torch.manual_seed(spp)
+        four = torch.cat([torch.rand(spp), torch.rand(spp), torch.rand(2048), torch.rand(2048)])
+        after4 = torch.rand(3)
+        torch.manual_seed(spp)
+        one = torch.rand(2 * spp + 4096)
+        after1 = torch.rand(3)
+        assert torch.equal(four, one) and torch.equal(after4, after1)

@@ -21,4 +21,5 @@ for i in range(300):
     seen[tuple((k if isinstance(k, str) else str(k), tuple(int(x) for x in v)) for k, v in sorted(m.trips.cache.items(), key=lambda kv: str(kv[0])))] += 1
 for tabs, n in seen.most_common(12):
     print(n, *[f"{k}:{''.join(format(x, 'x') for x in v)}" for k, v in tabs])
-print("launches", m.trips.launches, "relaunches", m.trips.relaunches)
+print("rounds checked", m.trips.launches, "| corrected and re-rendered on the device", m.trips.device_relaunches,
+      "| re-launched by the host", m.trips.relaunches)
