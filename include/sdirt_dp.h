@@ -267,6 +267,18 @@ int sdirt_psf_rgb_centered(const sdirt_lens* const* lens /*host [n_wvln]*/, int3
                            float* center, int32_t* any_valid, float* l_psf, float* r_psf,
                            uint32_t* conv_mask, uint32_t* conv_mask_center, void* stream);
 
+/* Lensgroup.psf_rgb(center=False), deeplens/optics.py:999-1015 with :972-976, as ONE kernel launch:
+ * sdirt_psf_lr for n_wvln wavelength slots (gridDim.y = n_wvln, one workgroup per (point, wavelength)),
+ * the PSFs centred on caller-supplied centres (the pinhole image points) instead of chief rays.
+ * Layouts as sdirt_psf_rgb_centered: lens host [n_wvln]; x2 / y2 dev [n_wvln][S]; trips host [n_wvln][K];
+ * center dev [n_wvln][N][2]; l_psf / r_psf dev [N][n_wvln][ks][ks]; conv_mask dev [n_wvln][SDIRT_MAX_SURFACES]. */
+int sdirt_psf_rgb(const sdirt_lens* const* lens /*host [n_wvln]*/, int32_t n_wvln,
+                  const float* point_obj /*dev [N,3]*/, int64_t n_points, const float* x2, const float* y2,
+                  int64_t spp, double pupil_z, double d_sensor, double ps, int32_t ks,
+                  const float* center /*dev [n_wvln][N][2]*/, const sdirt_dp_params* dp /*host or NULL*/,
+                  const int32_t* trips /*host [n_wvln][K]*/, uint32_t flags, float* l_psf, float* r_psf /*dev or NULL*/,
+                  uint32_t* conv_mask /*dev or NULL*/, void* stream);
+
 /* ---- speculate, verify on the device, re-render once ---------------------- */
 
 /* How sdirt_psf_lr_centered cuts the spp axis for (n_points, spp): 1 = one workgroup per point (the

@@ -76,6 +76,8 @@ SIGNATURES = {
     "sdirt_psf_rgb_centered": (C.c_int, [C.POINTER(_P), _I32, _P, _P, _I64, _P, _P, _I64, _P, _P, _I64, _D, _D, _D,
                                          _I32, C.POINTER(DpParams), C.POINTER(_I32), C.POINTER(_I32), _U32,
                                          _P, _P, _P, _P, _P, _P, _P]),
+    "sdirt_psf_rgb": (C.c_int, [C.POINTER(_P), _I32, _P, _I64, _P, _P, _I64, _D, _D, _D, _I32, _P,
+                                C.POINTER(DpParams), C.POINTER(_I32), _U32, _P, _P, _P, _P]),
     "sdirt_psf_spp_slices": (_I32, [_I64, _I64]),
     "sdirt_psf_verified_scratch_bytes": (_I64, [_I64, _I64]),
     "sdirt_psf_lr_verified": (C.c_int, [_P, _P, _P, _I64, _P, _P, _I64, _P, _P, _I64, _D, _D, _D, _I32,

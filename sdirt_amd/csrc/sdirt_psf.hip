@@ -789,6 +789,29 @@ int sdirt_psf_lr(const sdirt_lens* lens, const float* point_obj, int64_t N, cons
                       tt, flags, l_psf, r_psf, conv_mask, stream);
 }
 
+int sdirt_psf_rgb(const sdirt_lens* const* lens, int32_t W, const float* point_obj, int64_t N, const float* x2,
+                  const float* y2, int64_t S, double pupil_z, double d_sensor, double ps, int32_t ks,
+                  const float* center, const sdirt_dp_params* dp, const int32_t* trips, uint32_t flags,
+                  float* l_psf, float* r_psf, uint32_t* conv_mask, void* stream)
+{
+    if (!lens || W < 1 || W > SDIRT_MAX_WAVELENGTHS || !point_obj || !x2 || !y2 || !center || !l_psf || N < 0 ||
+        S < 0 || S > (1ll << 30) || N > (1ll << 30))
+        return fail(SDIRT_ERR_INVALID_ARGUMENT, "bad argument");
+    for (int w = 0; w < W; ++w)
+        if (!lens[w] || lens[w]->n_surfaces != lens[0]->n_surfaces)
+            return fail(SDIRT_ERR_INVALID_ARGUMENT, "lens[%d] missing or surface count differs from lens[0]", w);
+    if (int rc = check_ks(ks)) return rc;
+    if (dp && !(dp->r > 0.0)) return fail(SDIRT_ERR_INVALID_ARGUMENT, "dp->r must be > 0");
+    const int K = lens[0]->n_surfaces;
+    TripSet tt;
+    std::memset(&tt, 0, sizeof(tt));
+    for (int w = 0; w < W; ++w)
+        if (int rc = make_trips(lens[w], trips ? trips + (size_t)w * K : nullptr, tt.t[w])) return rc;
+    if (N == 0) return SDIRT_OK;
+    return launch_psf(lens, W, point_obj, N, x2, y2, S, pupil_z, d_sensor, ps, ks, center, nullptr, dp, tt, flags,
+                      l_psf, r_psf, conv_mask, stream);
+}
+
 int sdirt_psf_lr_centered(const sdirt_lens* lens, const sdirt_lens* lens_center,
                           const float* point_obj, int64_t N, const float* x2, const float* y2,
                           int64_t S, const float* xc, const float* yc, int64_t Sc, double pupil_z,

@@ -466,9 +466,9 @@ class Lensgroup:
         """optics.py:601-627: in place; returns (ray, valid, oss).  Direction is
         taken from the first ray's d_z like the reference unless `forward` is given."""
         self._require_gpu()
-        if record:
-            raise NotImplementedError("record=True (ray-path plotting) is outside the PSF path")
         K = len(self.surfaces)
+        if record:
+            return self._trace_recorded(ray, lens_range, forward)
         if lens_range is None:
             first, last = 0, K
         else:
@@ -502,10 +502,46 @@ class Lensgroup:
         valid = ray.ra == 1
         return ray, valid, None
 
+    def _trace_recorded(self, ray, lens_range, forward):
+        """trace(record=True), optics.py:666-717: `oss[i]` = the points ray i (row i of the first batch
+        dimension) passed through -- its origin, then its position after every surface it left alive --
+        as numpy arrays, for the reference's ray-path plots.  Traced surface by surface with the
+        staged kernel (each surface's batch-wide Newton trip count verified on its own), the positions
+        copied to the host after every surface: a plotting aid, not a fast path."""
+        K = len(self.surfaces)
+        idx = list(range(K)) if lens_range is None else list(lens_range)
+        if forward is None:
+            forward = bool(ray.soa[5, 0].item() > 0)             # optics.py:618
+        oss = [[p] for p in ray.o.cpu().numpy()]
+        for k in (idx if forward else idx[::-1]):
+            self.trace(ray, lens_range=range(k, k + 1), forward=forward)
+            alive = ((ray.ra == 1) if forward else (ray.ra > 0)).cpu().numpy()   # optics.py:681 / :707
+            for path, v, p in zip(oss, alive, ray.o.cpu().numpy()):
+                if np.any(v):
+                    path.append(p)
+        return ray, ray.ra == 1, oss
+
     def trace2sensor(self, ray, record=False, ignore_invalid=False):
-        """optics.py:638-664."""
-        ray, _, _ = self.trace(ray, record=record)
-        return ray.propagate_to(self.d_sensor)
+        """optics.py:638-664.  record=True: (p, oss) -- the sensor-plane positions [M,3] and the
+        recorded paths, each live ray's sensor point appended (twice, as the reference's two loops do)."""
+        if not record:
+            ray, _, _ = self.trace(ray)
+            return ray.propagate_to(self.d_sensor)
+        ray, _, oss = self.trace(ray, record=True)
+        ray.propagate_to(self.d_sensor)
+        valid, p = ray.ra == 1, ray.o
+        for path, v, pp in zip(oss, valid.cpu().numpy(), p.cpu().numpy()):
+            if np.any(v):
+                path.append(pp)
+        if ignore_invalid:
+            p = p[valid]
+        else:
+            assert p.dim() >= 2, "This function is not tested."
+            p = p.reshape(-1, 3)
+        for v, path, pp in zip(valid.cpu().numpy(), oss, p.cpu().numpy()):
+            if v:
+                path.append(pp)
+        return p, oss
 
     # --------------------------------------------------------------------- PSF
     def point_source_grid(self, depth, grid=9, normalized=True, quater=False, center=False):
@@ -904,17 +940,21 @@ class Lensgroup:
                 center_pupil_xy=None):
         """optics.py:999-1015: [N,3,ks,ks] (or [3,ks,ks]) -- the three wavelengths of WAVE_RGB, each an
         independent psf_diff (fresh pupil draws, in the reference's order; every chief-ray centre
-        through the green lens).  With center=True the three calls are
-        ONE kernel launch whatever the number of points (sdirt_psf_rgb_centered: lens table, pupil sets, trip tables and mask rows
-        indexed by blockIdx.y) and one control-block readback.
+        through the green lens).  The three calls are ONE kernel launch whatever the number of points
+        (center=True: sdirt_psf_rgb_centered; center=False: sdirt_psf_rgb -- lens table, pupil sets, trip
+        tables and mask rows indexed by blockIdx.y) and one control-block readback.
         pupil_xy [2, 3, spp] / center_pupil_xy [2, 3, 2048]: explicit pupil sample points per
         wavelength instead of random draws (ray-level parity hand-off)."""
         if not torch.is_tensor(points):
             points = torch.tensor(points)
         n_points = points.shape[0] if points.dim() == 2 else 1
-        fused = center and n_points > 0 and self.device.type == "cuda" and self.mask_reduce is None
-        if fused:
+        fused = n_points > 0 and self.device.type == "cuda" and self.mask_reduce is None
+        if fused and center:
             return self._psf_rgb_fused(points, ks, spp, param_list, pupil_xy, center_pupil_xy)
+        if fused:
+            if center_pupil_xy is not None:
+                raise ValueError("center=False runs no chief-ray pass")
+            return self._psf_rgb_uncentred(points, ks, spp, param_list, pupil_xy)
         if pupil_xy is not None or center_pupil_xy is not None:
             raise ValueError("explicit pupil points need the fused path (center=True)")
         psfs = [self.psf_diff(points=points, wvln=w, ks=ks, spp=spp, center=center,
@@ -986,6 +1026,59 @@ class Lensgroup:
         else:
             full = self._fixed_trips()
             enqueue([full] * (2 * W))
+        out = R if want_r else L
+        return out.squeeze(0) if single_point else out
+
+    @torch.no_grad()
+    def _psf_rgb_uncentred(self, points, ks, spp, param_list, pupil_xy=None):
+        """psf_rgb(center=False) as one launch (sdirt_psf_rgb): three wavelength slots, the PSFs centred on
+        the pinhole image points (optics.py:972-976), one fresh primary sample set per wavelength (two
+        random vectors each, optics.py:963), one control-block readback for the three trip checks."""
+        single_point = points.dim() == 1
+        pts = points.reshape(-1, 3)
+        N, W, K, MS = pts.shape[0], len(WAVE_RGB), len(self.surfaces), _lib.MAX_SURFACES
+        direct, dp_ref, dpp = "l", None, None
+        if param_list is not None:
+            h, f, w_, r, direct = param_list
+            dpp = _lib.DpParams(float(h), float(f), float(w_), float(r))
+            dp_ref = C.byref(dpp)
+        want_r = direct != "l"
+        po = self._points_to_object(pts)
+        pupilz, pupilr = self.entrance_pupil()
+        if pupil_xy is None:
+            prim = torch.stack([torch.stack(self._pupil_samples(spp, pupilr)) for _ in WAVE_RGB], 1).contiguous()
+        else:
+            prim = torch.as_tensor(pupil_xy).to(self.device, torch.float32).contiguous()              # [2, W, S]
+        spp = prim.shape[2]
+        ptd = pts.to(self.device, torch.float32)
+        one = torch.stack((ptd[:, 0] * (self.sensor_size[1] / 2), ptd[:, 1] * (self.sensor_size[0] / 2)), -1)
+        cen = one.unsqueeze(0).expand(W, N, 2).contiguous()                                          # the same for every colour
+        handles = (C.c_void_p * W)(*[self.dev_lens(w).value for w in WAVE_RGB])
+        L = torch.empty((N, W, ks, ks), dtype=torch.float32, device=self.device)
+        R = torch.empty_like(L) if want_r else None
+        flags = _lib.PSF_NORMALIZE | self._math_flags()
+        masks = torch.zeros((W, MS), dtype=torch.int32, device=self.device)
+        reference = self.trip_policy == "reference"
+
+        def enqueue(tables):
+            tp = np.concatenate([np.asarray(t, np.int32) for t in tables])
+            with self._timed("psf_rgb"):
+                _lib.check(_lib.lib().sdirt_psf_rgb(
+                    handles, W, dptr(po), N, dptr(prim[0]), dptr(prim[1]), spp, float(pupilz), float(self.d_sensor),
+                    float(self.pixel_size), ks, dptr(cen), dp_ref, (C.c_int32 * (W * K))(*tp.tolist()), flags,
+                    dptr(L), dptr(R), dptr(masks) if reference else None, stream_ptr(self.device)))
+
+        if reference:
+            keys = [("psf", round(float(w), 6), self.precision) for w in WAVE_RGB]
+
+            def launch(tables):
+                masks.zero_()
+                enqueue(tables)
+                m = masks.cpu().numpy()[:, :K].astype(np.int64) & 0xFFFFFFFF
+                return list(m)
+            self.trips.run_many(keys, self._curved(), list(range(K)), launch)
+        else:
+            enqueue([self._fixed_trips()] * W)
         out = R if want_r else L
         return out.squeeze(0) if single_point else out
 

@@ -298,7 +298,6 @@ def test_rgb_field_one_launch_and_psf_map():
     torch.manual_seed(5)
     b = torch.stack([lens.psf_diff(field[:2], wvln=w, ks=17, spp=8192) for w in [0.656, 0.589, 0.486]], dim=-3)
     assert torch.allclose(a, b, atol=3e-6)
-    # center=False has no fused form: three calls
     torch.manual_seed(6)
     c = lens.psf_rgb(field, ks=17, spp=256, center=False)
     assert c.shape == (9, 3, 17, 17) and float(c.max()) > 0.99
@@ -483,3 +482,78 @@ def test_psf_without_chief_ray_centre():
     torch.manual_seed(16)
     lens.psf_diff(pts, ks=33, spp=1024, center=False)
     assert torch.equal(torch.rand(3), expect)
+
+
+def test_psf_rgb_without_chief_ray_centre_is_one_launch():
+    """psf_rgb(center=False) (optics.py:999-1015 with :972-976), fixture F22: three wavelengths in ONE
+    launch (sdirt_psf_rgb, wavelength slot on blockIdx.y), pinhole centres, the reference's pupil
+    points handed over per wavelength; trip tables equal the reference's; same-seed call; equal to
+    three psf_diff(center=False) calls; the generator ends where the reference leaves it."""
+    st, g = load_state("rf50mm"), load_golden("f22_rf50_rgb_uncentred")
+    lens = make_lens("rf50mm", DEV, st)
+    pts = torch.tensor(g["points"])
+    ks, spp = int(g["ks"]), int(g["spp"])
+    hand = np.stack([g["pupil_x"], g["pupil_y"]])                   # [2, 3, spp]
+    lens.kernel_events = {}
+    psf = lens.psf_rgb(pts, ks=ks, center=False, param_list=DP + ["l"], pupil_xy=hand)
+    assert {k: len(v) for k, v in lens.kernel_events.items()} == {"psf_rgb": 2}     # 10-trip discovery + verified table
+    lens.kernel_events = {}
+    psf = lens.psf_rgb(pts, ks=ks, center=False, param_list=DP + ["l"], pupil_xy=hand)
+    assert {k: len(v) for k, v in lens.kernel_events.items()} == {"psf_rgb": 1}
+    lens.kernel_events = None
+    for i, w in enumerate(g["wvlns"]):
+        assert np.array_equal(lens.trips.cache[("psf", round(float(w), 6), "lean")], g["trips"][i])
+    d = np.abs(psf.cpu().numpy() - g["psf"]).max()
+    psf_r = lens.psf_rgb(pts, ks=ks, center=False, param_list=DP + ["r"], pupil_xy=hand)
+    dr = np.abs(psf_r.cpu().numpy() - g["psf_r"]).max()
+    print("psf_rgb(center=False) hand-off: L", d, "R", dr)
+    assert psf.shape == (3, 3, ks, ks) and d <= 1e-4 and dr <= 1e-4
+    torch.manual_seed(int(g["seed"]))
+    same_seed = lens.psf_rgb(pts, ks=ks, spp=spp, center=False, param_list=DP + ["l"])
+    tail = torch.rand(3)
+    assert np.abs(same_seed.cpu().numpy() - g["psf"]).max() <= 5e-4
+    torch.manual_seed(int(g["seed"]))
+    three = torch.stack([lens.psf_diff(pts, wvln=float(w), ks=ks, spp=spp, center=False, param_list=DP + ["l"])
+                         for w in g["wvlns"]], dim=-3)
+    assert torch.equal(torch.rand(3), tail)                        # six vectors drawn, no more
+    assert torch.allclose(same_seed, three, atol=3e-6)
+    one = lens.psf_rgb(pts[1], ks=ks, spp=256, center=False)
+    assert one.shape == (3, ks, ks)
+
+
+def _check_paths(got, want_len, want_pts, tol):
+    assert [len(p) for p in got] == list(want_len)
+    worst = 0.0
+    for path, n, ref in zip(got, want_len, want_pts):
+        worst = max(worst, float(np.abs(np.stack(path) - ref[:n]).max()))
+    assert worst <= tol, worst
+    return worst
+
+
+def test_recorded_ray_paths_against_the_reference():
+    """trace(ray, record=True) -> (ray, valid, oss) and trace2sensor(ray, record=True) -> (p, oss)
+    (optics.py:601-717): the intersection points of every ray with every surface it leaves alive,
+    forward (three rays of the fan survive, the others are lost at four different surfaces) and
+    backward, fixture F21."""
+    from sdirt_amd.basics import Ray
+    st, g = load_state("rf50mm"), load_golden("f21_rf50_recorded_paths")
+    lens = make_lens("rf50mm", DEV, st)
+    mk = lambda tag: Ray(torch.tensor(g[tag + "_o"]), torch.tensor(g[tag + "_aim"] - g[tag + "_o"]), device=DEV)
+    ray, valid, oss = lens.trace(mk("fwd"), record=True)
+    assert np.array_equal(valid.cpu().numpy(), g["fwd_valid"])
+    w1 = _check_paths(oss, g["fwd_len"], g["fwd_pts"], 2e-5)
+    # the recorded trace leaves the rays where the plain trace leaves them, bit for bit
+    plain, _, none = lens.trace(mk("fwd"))
+    assert none is None and torch.equal(plain.soa, ray.soa)
+    p, oss = lens.trace2sensor(mk("fwd"), record=True)
+    assert p.shape == (11, 3) and np.abs(p.cpu().numpy() - g["sensor_p"])[g["fwd_valid"]].max() <= 2e-5
+    w2 = _check_paths(oss, g["sensor_len"], g["sensor_pts"], 2e-5)
+    ray, valid, oss = lens.trace(mk("bwd"), record=True)
+    assert np.array_equal(valid.cpu().numpy(), g["bwd_valid"])
+    w3 = _check_paths(oss, g["bwd_len"], g["bwd_pts"], 2e-5)
+    print("recorded paths: max |dp| forward", w1, "to sensor", w2, "backward", w3, "mm")
+    # a [S, N] bundle: oss has S entries, row i appended while ANY of its rays is alive (optics.py:684)
+    two = Ray(torch.tensor(g["fwd_o"]).unsqueeze(0).repeat(2, 1, 1),
+              torch.tensor(g["fwd_aim"] - g["fwd_o"]).unsqueeze(0).repeat(2, 1, 1), device=DEV)
+    _, _, oss2 = lens.trace(two, record=True)
+    assert len(oss2) == 2 and len(oss2[0]) == 13 and oss2[0][-1].shape == (11, 3)
