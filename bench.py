@@ -56,6 +56,24 @@ WORKLOADS = {
                desc="rf35mm (21 surfaces) 32x32x{gz} PSF volume"),
 }
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s HBM3E
+VALU_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: vector fp32 (FMA counted as 2; the parity contract forbids contraction)
+# the two workloads either side of the hot path: not PSF-volume renders
+EXTRA_WORKLOADS = ("f1", "tcp")
+
+
+def source_hash():
+    """Hash of the kernel sources the loaded library was built from (csrc/*.hip, *.hpp, the ABI header):
+    carried PMC counters name the hash they were collected on; a mismatch is reported as `stale`."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "sdirt_amd", "csrc", "*.hip")) +
+                   glob.glob(os.path.join(ROOT, "sdirt_amd", "csrc", "*.hpp")) +
+                   [os.path.join(ROOT, "include", "sdirt_dp.h")])
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 FOC_Z_RF50 = (-1000.0 + 62.25 - (-200.0)) / (-20000.0 - (-200.0))   # psfnet.py:50-51, foc_z_arr[1]
@@ -134,9 +152,10 @@ def lens_state(lens):
     return st
 
 
-def cpu_baseline(lens, points, budget_s=12.0):
+def cpu_baseline(lens, points, pupil, budget_s=12.0):
     """Times the two CPU restatements of the reference path on every k-th point of the same
-    volume with the same 4096-spp sample set, on the cores this process may use:
+    volume with the pupil sample points of the GPU leg's LAST step (`pupil` = x2, y2, xc, yc as the
+    device mapped them), on the cores this process may use:
       * `value` (kind "port"): oracle/sdirt_oracle.c, a per-ray C port with OpenMP -- the
         strongest CPU implementation of the path we have;
       * `torch`: oracle/torch_port.py, the reference's own execution model (whole-tensor fp32
@@ -146,11 +165,8 @@ def cpu_baseline(lens, points, budget_s=12.0):
     st = lens_state(lens)
     cores = available_cores()
     orc.set_num_threads(cores)
-    rng = np.random.default_rng(0)
-    x2, y2 = orc.pupil_samples(rng.random(SPP, dtype=np.float32), rng.random(SPP, dtype=np.float32),
-                               st["pupil_r"])
-    xc, yc = orc.pupil_samples(rng.random(2048, dtype=np.float32),
-                               rng.random(2048, dtype=np.float32), st["pupil_r"] * 0.25)
+    x2, y2, xc, yc = [np.ascontiguousarray(v.detach().cpu().numpy(), dtype=np.float32) for v in pupil]
+    assert len(x2) == SPP and len(xc) == 2048
     pts = points.numpy()
 
     def subset(n):
@@ -225,8 +241,98 @@ def pmc_counters(workload):
         with open(files[-1]) as f:
             c = json.load(f)
         c["file"] = os.path.relpath(files[-1], ROOT)
+        c["stale"] = c.get("source_hash") != source_hash()
         return c
     return None
+
+
+def _hip_ms(fn, steps, warmup, device):
+    """steps calls of fn between two synchronisations -> (wall ms per call, mean HIP-event ms per call)."""
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize(device)
+    ev = []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(torch.cuda.current_stream(device))
+        fn()
+        e1.record(torch.cuda.current_stream(device))
+        ev.append((e0, e1))
+    torch.cuda.synchronize(device)
+    wall = (time.perf_counter() - t0) / steps * 1e3
+    return wall, float(np.mean([a.elapsed_time(b) for a, b in ev]))
+
+
+def bench_f1(args):
+    """local_psf_render_fast (render_psf.py:120-155) -- per-pixel left/right PSF
+    convolution of one 512 x 768 RGB frame with ks 21 kernels, the image-simulation step of
+    2_dfdp_net.py.  HBM-bound: every pixel's [2, 21, 21] fp32 kernels are read exactly once."""
+    from sdirt_amd.render_psf import local_psf_render_fast
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback exists)"
+    dev = torch.device("cuda", 0)
+    H, W, ks = 512, 768, 21
+    g = torch.Generator(device=dev).manual_seed(0)
+    img = torch.rand(1, 3, H, W, device=dev, generator=g)
+    psf = torch.rand(1, H, W, 2, ks, ks, device=dev, generator=g)
+    psf = psf / psf.sum((-1, -2), keepdim=True)
+    fn = lambda: local_psf_render_fast(img, psf, ks)
+    wall, kern = _hip_ms(fn, args.steps, max(args.warmup, 3), dev)
+    k_sus = max(args.steps, int(args.sustain_seconds / max(wall * 1e-3, 1e-6))) if args.sustain_seconds > 0 else 0
+    sus = _hip_ms(fn, k_sus, 0, dev)[0] if k_sus else None
+    alg_bytes = psf.numel() * 4 + img.numel() * 4 + 2 * img.numel() * 4
+    ach = alg_bytes / (kern * 1e-3) / 1e9
+    res = {"metric": "pixels/sec per-pixel DP-PSF convolution 512x768 RGB ks21 (local_psf_render_fast)",
+           "value": H * W / (wall * 1e-3), "unit": "pixels/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": wall, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16",
+           "data": "synthetic",
+           "config": {"workload": "one 512x768 RGB frame, per-pixel L/R kernels [1,512,768,2,21,21] fp32 (1.39 GB), "
+                                  "fp16 arithmetic of the _fast renderer, replicate padding", "name": "f1"},
+           "kernels_ms": {"local_psf_render": kern},
+           "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                        "traffic": None, "kernel": "k_local_psf_render_wave<3, half, 21, 64>",
+                        "algorithmic_bytes_per_launch": alg_bytes}}
+    if sus is not None:
+        res["ms_per_step_sustained"] = sus
+    print(json.dumps(res), flush=True)
+
+
+def bench_tcp(args):
+    """The one workload the reference itself times: PSFNet.time_compare_psf (psfnet.py:570-586) -- 24576
+    random points, 4096 spp, ks 21, the PSFs copied to the host inside the timed span.  `value` is the
+    device-resident rate (inputs and outputs in HBM, as every other line of this file);
+    `value_pcie_inclusive` is the reference's own span, host copy included."""
+    from sdirt_amd.psfnet import PSFNet
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback exists)"
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    np.random.seed(0)
+    m = PSFNet(os.path.join(ROOT, "sdirt_amd", "data", "rf50mm.json"), sensor_res=(512, 768), kernel_size=21,
+               device=dev)
+    m.refocus(-1000 + m.d_sensor)
+    n, spp, ks = 512 * 768 // 16, 4096, 21
+    for _ in range(max(args.warmup, 1)):
+        m.time_compare_psf(verbose=False)
+    t_trace, t_net = zip(*[m.time_compare_psf(verbose=False) for _ in range(args.steps)])
+    inp = torch.rand(n, 3)
+    inp[:, 2] = m.z2depth(inp[:, 2])
+    ind = inp.to(dev)
+    out = tuple(torch.empty((n, ks, ks), device=dev) for _ in range(2))
+    fn = lambda: m.psf_lr(ind, ks=ks, spp=spp, out=out, want_r=False, _default_r_zero=True)
+    wall, kern = _hip_ms(fn, args.steps, 2, dev)
+    res = {"metric": "rays/sec PSFNet.time_compare_psf: 24576 random points, 4096 spp, ks 21 (rf50mm)",
+           "value": n * spp / (wall * 1e-3), "unit": "rays/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": wall, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+           "data": "synthetic",
+           "value_pcie_inclusive": n * spp / float(np.mean(t_trace)),
+           "reference_harness": {"ray_tracing_seconds": float(np.mean(t_trace)), "network_seconds": float(np.mean(t_net)),
+                                 "what": "wall clock of the two spans of psfnet.py:570-586 as the reference prints them: "
+                                         "psf(...).to('cpu') (42.5 MB to the host) and pred(...).to('cpu') for a 128x192 field"},
+           "config": {"workload": "PSFNet.time_compare_psf: 24576 random points x 4096 spp (+2048 chief-ray rays/point), "
+                                  "21x21 L PSFs (param_list=None), lambda 0.589um, focus 1 m", "name": "tcp",
+                      "points_per_gpu": n, "spp": spp, "ks": ks},
+           "kernels_ms": {"psf_lr synchronous call (events)": kern}}
+    print(json.dumps(res), flush=True)
 
 
 def main():
@@ -240,11 +346,18 @@ def main():
                          "beside `value` either way)")
     ap.add_argument("--gather", action="store_true", help="(default; kept for older scripts)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--sustain-seconds", type=float, default=2.0,
+    ap.add_argument("--sustain-seconds", type=float, default=10.0,
                     help="after the K timed steps, keep stepping for this long and report "
-                         "ms_per_step_sustained (0 = skip)")
-    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2")
+                         "ms_per_step_sustained (0 = skip); long enough for a 5-second GPU-activity "
+                         "sampler to see the GPU phase of the run")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS) + list(EXTRA_WORKLOADS), default="c2",
+                    help="c2 (default, the headline) / c3 / c4: PSF-volume renders; f1: per-pixel DP-PSF "
+                         "convolution of a 512x768 frame (render_psf.py:120-155); tcp: the reference's own "
+                         "timing harness PSFNet.time_compare_psf (psfnet.py:570-586)")
     args = ap.parse_args()
+    if args.workload in EXTRA_WORKLOADS:
+        assert args.gpus == 1, f"--workload {args.workload} is a single-GPU measurement"
+        return bench_f1(args) if args.workload == "f1" else bench_tcp(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
     global KS, SPP, GRID_Z
@@ -409,29 +522,40 @@ def main():
         ach = alg_bytes / (k_ms[dom] * 1e-3) / 1e9
         traffic = valu = None
         counters = pmc_counters(args.workload)
+        # algorithmic flops of one launch: ~290 per curved surface (4.5 sag evaluations,
+        # normal, refraction, updates) + stop / propagate / splat: 3.4 kflop per primary and 3.3 kflop per
+        # chief-ray ray on rf50mm's 11 curved surfaces, the same per-surface figure on rf35mm's 20
+        n_curved = sum(1 for c_ in lens._curved() if c_)
+        flop_primary, flop_chief = 290 * n_curved + 210, 290 * n_curved + 110
+        alg_flops = n_local * (SPP * flop_primary + 2048 * flop_chief)
+        ach_tflops = alg_flops / (k_ms[dom] * 1e-3) / 1e12
+        valu_flops = {"algorithmic_flops_per_launch": alg_flops, "flop_per_primary_ray": flop_primary,
+                      "flop_per_chief_ray": flop_chief, "achieved": ach_tflops, "peak": VALU_PEAK_TFLOPS,
+                      "unit": "TFLOP/s", "frac": ach_tflops / VALU_PEAK_TFLOPS,
+                      "note": "peak counts an FMA as 2 flops; the parity contract (-ffp-contract=off: the reference's "
+                              "unfused torch ops) halves what this instruction stream can reach"}
         if counters:
             traffic = counters.get("k_psf_lr_hbm_bytes_per_launch")
             n_instr = counters.get("k_psf_lr_valu_wave_instructions_per_launch")
             if n_instr:
-                # what actually bounds the kernel: vector-instruction issue.  Peak = one full-rate
-                # wave64 instruction per 2 cycles per SIMD (1024 SIMDs, 2.4 GHz); quarter-rate
-                # instructions (v_rcp / v_sqrt, ~6 % of the mix) make the reachable figure lower.
+                # vector-instruction issue: peak = one full-rate wave64 instruction per 2 cycles per SIMD
+                # (1024 SIMDs, 2.4 GHz); half-rate forms and v_rcp / v_rsq make the reachable figure lower
                 peak = 1024 * 2.4e9 / 2
                 n_all = n_instr + (counters.get("salu_wave_instructions_per_launch") or 0) \
                     + (counters.get("smem_instructions_per_launch") or 0)
                 clk = counters.get("shader_clock_ghz") or 2.38
                 valu = {"wave_instructions_per_launch": n_instr,
-                        # SIMD cycles per VECTOR instruction; a plain fp32 one costs 2.25, compares / SGPR-operand
-                        # forms 4.2, v_rcp 8-13 (tools/form_bench.hip); scalar instructions run beside them
                         "all_instructions_per_launch": n_all,
                         "cycles_per_vector_instruction_per_simd": k_ms[dom] * 1e-3 * clk * 1e9 * 1024 / n_instr,
                         "plain_fp32_cycles_per_instruction": 2.25,
                         "achieved_per_s": n_instr / (k_ms[dom] * 1e-3), "peak_per_s": peak,
                         "frac": n_instr / (k_ms[dom] * 1e-3) / peak,
+                        "stale": bool(counters["stale"]),
                         "source": {"kind": "carried: SQ_INSTS_VALU of a separate rocprofv3 --pmc run "
                                            "of this command, divided by THIS run's kernel time",
                                    "file": counters["file"], "collected": counters.get("collected"),
-                                   "commit": counters.get("commit")}}
+                                   "commit": counters.get("commit"),
+                                   "source_hash": counters.get("source_hash"), "source_hash_now": source_hash()}}
         res = {
             "metric": f"rays/sec {wl['lens']} {KS}x{KS} DP-PSF @{SPP}spp", "value": rays / dt,
             "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -454,8 +578,13 @@ def main():
                        "newton_trip_policy": lens.trip_policy,
                        "relaunches_in_timed_region": relaunches},
             "kernels_ms": k_ms, "kernel_launches": n_launch,
-            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            # what bounds the kernel is its vector ALU time (profiles/r03/k_psf_lr_sites.txt):
+            # `valu_flops` is the fraction that says something; achieved / peak / frac / traffic are the
+            # mandated HBM figures (0.7 % by construction: 8 algorithmic bytes against 3.4 kflop per ray)
+            "roofline": {"bound": "valu", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_stale": bool(counters["stale"]) if counters else None,
+                         "valu_flops": valu_flops,
                          "kernel": "k_psf_lr<R,small-r,Lean,CENTER> (chief-ray pass + primary pass "
                                    "of a point in one workgroup)",
                          "algorithmic_bytes_per_launch": alg_bytes, "valu_issue": valu,
@@ -476,7 +605,7 @@ def main():
             res["value_sustained"] = n_total * SPP * k_sus / dt_sus
             res["sustained_steps"] = k_sus
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(lens, points_all)
+            res["cpu_baseline"] = cpu_baseline(lens, points_all, lens.last_pupil_points)
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

@@ -755,6 +755,8 @@ class Lensgroup:
             pts = points.to(self.device, torch.float32)
             cen[:, 0] = pts[:, 0] * (self.sensor_size[1] / 2)      # optics.py:973-975
             cen[:, 1] = pts[:, 1] * (self.sensor_size[0] / 2)
+        #: the pupil sample points of the most recent psf_lr call (x2, y2, xc, yc), device tensors
+        self.last_pupil_points = (x2, y2, xc, yc)
         need_r = want_r and not _default_r_zero
         if out is not None:
             L, R = out[0], (out[1] if need_r else None)

@@ -392,6 +392,33 @@ class PSFNet(Lensgroup):
         return torch.clip(render, 0.0, 1.0)
 
     # ------------------------------------------------------------------ checks the reference ships
+    def time_compare_psf(self, verbose=True):
+        """psfnet.py:570-586, the one timing harness the reference ships: 512*768/16 = 24576 random
+        points (x, y in [0, 1), z2depth of a uniform z), 2 * GEO_SPP = 4096 spp, kernel size of the
+        model, the PSFs copied to the host INSIDE the timed span; then one network prediction for a
+        128 x 192 field, copied to the host likewise.  Wall-clock seconds, as the reference prints
+        them -> (ray_tracing_seconds, network_seconds)."""
+        import time
+        from .basics import GEO_SPP
+        inp = torch.rand(512 * 768 // 16, 3)
+        inp[:, 2] = self.z2depth(inp[:, 2])
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+        start_time = time.time()
+        psfl = self.psf(points=inp, ks=self.kernel_size, center=True, spp=GEO_SPP * 2).to("cpu")
+        t_trace = time.time() - start_time
+        if verbose:
+            print(f"ray_tracing time cost: {t_trace}s")
+        inp = torch.rand(1, 512 // 4, 768 // 4, 3).to(self.device)
+        start_time = time.time()
+        with torch.no_grad():
+            psf2 = self.pred(inp).detach().to("cpu")
+        t_net = time.time() - start_time
+        if verbose:
+            print(f"network time cost: {t_net}s")
+        assert psfl.shape == (24576, self.kernel_size, self.kernel_size) and psf2.shape[-3:] == (2, self.kernel_size, self.kernel_size)
+        return t_trace, t_net
+
     def compare_psf(self, spp=None):
         """psfnet.py:529-568 without the figures: ray-traced vs predicted (L, R) kernels at three
         field points and two depths -> {depth: (traced [3,2,ks,ks], predicted [3,2,ks,ks])}."""

@@ -29,12 +29,13 @@ def _env(**kw):
 
 
 @pytest.mark.gpu
-def test_two_ranks_equal_one_call_over_the_whole_grid():
+@pytest.mark.parametrize("world", [2, 8])
+def test_ranks_equal_one_call_over_the_whole_grid(world):
     port = str(_free_port())
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_gpu_worker.py")],
-                              env=_env(RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_PORT=port),
+                              env=_env(RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_PORT=port),
                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
-             for r in range(2)]
+             for r in range(world)]
     outs = []
     for p in procs:
         try:
@@ -50,7 +51,7 @@ def test_two_ranks_equal_one_call_over_the_whole_grid():
     assert r0["max_abs_diff_L"] <= 3e-6 and r0["max_abs_diff_R"] <= 3e-6
     assert r0["tables"] == r0["solo_tables"]
     assert all(r["empty_shard_ok"] for r in rec)
-    print("2-rank vs solo:", r0["max_abs_diff_L"], r0["max_abs_diff_R"], "own tables differ:",
+    print(f"{world}-rank vs solo:", r0["max_abs_diff_L"], r0["max_abs_diff_R"], "own tables differ:",
           r0["own_tables_differ"], r0["tables"])
 
 
@@ -70,3 +71,27 @@ def test_bench_starts_its_own_ranks():
     res = json.loads(lines[0])
     assert res["n_gpus"] == 2 and res["config"]["gather"] is True
     assert res["value"] > 0 and res["value_no_gather"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_config3_with_eight_ranks_on_one_gpu():
+    """BASELINE config 3 as the driver would launch it on a node -- `bench.py --gpus 8 --workload c3`:
+    8 ranks x 8192 points, 8192 spp, ks 21, pupil broadcast, mask all-reduce, all-gather of the
+    65536-point volume to every rank -- on the ONE GPU of this pool (gloo dry-run backend: the
+    control path is the node's, the numbers mean nothing).  One JSON line, n_gpus 8, rc 0."""
+    env = _env(SDIRT_BENCH_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2",
+                        "--warmup", "1", "--workload", "c3", "--sustain-seconds", "0"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout + p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 8 and res["config"]["gather"] is True and res["config"]["name"] == "c3"
+    assert res["config"]["points_per_gpu"] == 8192 and res["value"] > 0 and res["value_no_gather"] > 0
+    log = os.environ.get("SDIRT_TEST_LOG_DIR")
+    if log:
+        with open(os.path.join(log, "bench_gpus8_dryrun_c3.log"), "w") as f:
+            f.write(lines[0] + "\n")

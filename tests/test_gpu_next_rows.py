@@ -350,3 +350,51 @@ def test_tone_curve_kernels_equal_the_torch_chain():
     assert (back - back_ref).abs().max().item() <= 1e-6
     assert (back == back_ref).float().mean().item() > 0.99
     assert (back - x).abs().max().item() < 1e-2               # gamma ~ inverse of degamma (two blended fits)
+
+
+def test_config5_image_simulation_then_depth_network_in_one_chain():
+    """BASELINE config 5 as ONE chain at its real size (2_dfdp_net.py:273-344 renders, :165-230 feeds
+    the depth network): seeded synthetic RGB-D frame 512 x 768 -> PSFNet.render with the full-size
+    MLP (3 -> 128 -> 512 x 9 -> 441, seeded weights: the reference's checkpoints are not in its
+    repository) -> DfDPNet (YRStereonet_3D) under fp16 autocast, as Basenet.forward runs it.
+    Asserted: shapes, finiteness, the fused render path == the op-by-op path, the autocast
+    disparity == the fp32 module's on the same dual-pixel pair."""
+    from sdirt_amd.psfnet import PSFNet
+    from sdirt_amd.dfdp import DfDPNet
+    H, W, ks = 512, 768, 21
+    torch.manual_seed(0)
+    np.random.seed(0)
+    m = PSFNet(os.path.join(DATA, "rf50mm.json"), sensor_res=(H, W), kernel_size=ks, device=DEV)
+    m.refocus(-1000 + m.d_sensor)
+    assert [l.out_features for l in m.psfnet.net if hasattr(l, "out_features")] == [128] + [512] * 9 + [441]
+    with torch.no_grad():
+        m.psfnet.net[-2].bias.add_(0.02)          # untrained kernels must not vanish under the final ReLU
+    g = torch.Generator(device=DEV).manual_seed(5)
+    img = torch.rand(1, 3, H, W, device=DEV, generator=g)
+    # a smooth depth map 0.5 ... 5 m (mm, negative towards the scene as the scripts pass it, :303)
+    yy, xx = torch.meshgrid(torch.linspace(0, 1, H, device=DEV), torch.linspace(0, 1, W, device=DEV), indexing="ij")
+    depth = -(500 + 4500 * (0.5 + 0.5 * torch.sin(3 * xx + 2 * yy)) * (0.3 + 0.7 * yy)).reshape(1, 1, H, W)
+    foc = torch.tensor([-1000.0], device=DEV)
+
+    dp = m.render(img, depth, foc)                                   # fused MLP + fused convolution
+    assert dp.shape == (1, 6, H, W) and dp.dtype == torch.float32
+    assert torch.isfinite(dp).all() and float(dp.min()) >= 0 and float(dp.max()) <= 1
+    assert float((dp[:, :3] - dp[:, 3:]).abs().max()) > 1e-3       # L and R views differ
+    m.fused_mlp = m.fused_render = False
+    dp_chain = m.render(img, depth, foc)                             # torch.nn layers, pred, local_psf_render_fast
+    m.fused_mlp = m.fused_render = True
+    d_render = float((dp - dp_chain).abs().max())
+
+    torch.manual_seed(1)
+    net = DfDPNet().to(DEV).eval()
+    left, right = dp[:, :3].contiguous(), dp[:, 3:].contiguous()
+    with torch.no_grad():
+        disp32 = net(left, right)
+        with torch.autocast("cuda", dtype=torch.float16):
+            disp16 = net(left, right)
+    assert disp32.shape[-2:] == (H, W) and disp16.shape == disp32.shape
+    assert torch.isfinite(disp16.float()).all() and torch.isfinite(disp32).all()
+    d_disp = float((disp16.float() - disp32).abs().max())
+    print(f"config 5 chain: fused vs op-by-op render {d_render:.2e}; fp16-autocast vs fp32 disparity {d_disp:.2e} px")
+    assert d_render <= 1.5e-3
+    assert d_disp <= 5e-2

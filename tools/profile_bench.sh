@@ -1,12 +1,12 @@
 #!/bin/bash
 # Profiling recipe for the bench workloads (run on the GPU box through gpurun):
-#   tools/profile_r02.sh <workload: c2|c3|c4> <commit> [round-dir, default r02]
+#   tools/profile_bench.sh <workload: c2|c3|c4> <commit> [round-dir, default r03]
 # Pass 1: kernel trace + stats of `python3 bench.py` (the same command the driver runs, minus the
 # CPU baseline).  Passes 2-4: PMC counters, each group in its own run (never trace domains
 # together with --pmc on this pool).  Output: gpurun_out/prof_<round>_<workload>/ and the condensed
 # gpurun_out/prof_<round>_<workload>/pmc_<workload>.json that bench.py reads from profiles/<round>/.
 set -u
-WL=${1:-c2}; COMMIT=${2:-unknown}; RND=${3:-r02}
+WL=${1:-c2}; COMMIT=${2:-unknown}; RND=${3:-r03}
 OUT=gpurun_out/prof_${RND}_${WL}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
@@ -22,11 +22,13 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- $CMD > "$O
 python3 tools/summarize_prof.py "$OUT" > "$OUT/summary.json"
 python3 - "$OUT" "$WL" "$COMMIT" <<'PY'
 import json, sys, time
+sys.path.insert(0, ".")
+import bench
 out, wl, commit = sys.argv[1:4]
 s = json.load(open(f"{out}/summary.json"))
 p, t = s["pmc"]["k_psf_lr"], s["kernel_trace"]["k_psf_lr"]
 v = lambda k: p[k]["last"]
-d = {"workload": wl, "commit": commit, "collected": time.strftime("%Y-%m-%d %H:%M UTC", time.gmtime()),
+d = {"workload": wl, "commit": commit, "source_hash": bench.source_hash(), "collected": time.strftime("%Y-%m-%d %H:%M UTC", time.gmtime()),
      "command": f"rocprofv3 --pmc <group> -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --workload {wl}",
      "kernel": "k_psf_lr<R, small-r, Lean, CENTER> (last dispatch of each pass)",
      "kernel_trace_median_us": t["median_us"], "kernel_trace_avg_us": t["avg_us"], "kernel_trace_calls": t["calls"],

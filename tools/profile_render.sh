@@ -1,0 +1,32 @@
+#!/bin/bash
+# Kernel trace + HBM counters of the f1 workload (per-pixel DP-PSF convolution, bench.py --workload f1):
+#   tools/profile_render.sh <commit> [round-dir, default r03]   -> gpurun_out/prof_<round>_f1/summary_render.json
+set -u
+COMMIT=${1:-unknown}; RND=${2:-r03}
+OUT=gpurun_out/prof_${RND}_f1
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+CMD="python3 bench.py --workload f1 --steps 50 --warmup 5 --sustain-seconds 0"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $CMD > "$OUT/trace.log" 2>&1
+CMD="python3 bench.py --workload f1 --steps 5 --warmup 2 --sustain-seconds 0"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- $CMD > "$OUT/pmc_fetch.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- $CMD > "$OUT/pmc_write.log" 2>&1
+python3 tools/summarize_prof.py "$OUT" k_local_psf_render > "$OUT/summary.json"
+python3 - "$OUT" "$COMMIT" <<'PY'
+import json, sys, time
+sys.path.insert(0, ".")
+import bench
+out, commit = sys.argv[1:3]
+s = json.load(open(f"{out}/summary.json"))
+name = next(k for k in s["kernel_trace"] if "render" in k)
+t, p = s["kernel_trace"][name], s["pmc"][name]
+alg = 512 * 768 * 2 * 441 * 4 + 3 * 512 * 768 * 4 * 3
+hbm = (2 * p["FETCH_SIZE"]["last"] + p["WRITE_SIZE"]["last"]) * 1024      # KB units, gfx950 reports half of the reads
+d = {"workload": "f1", "commit": commit, "source_hash": bench.source_hash(),
+     "collected": time.strftime("%Y-%m-%d %H:%M UTC", time.gmtime()), "kernel": name,
+     "kernel_trace_avg_us": t["avg_us"], "kernel_trace_median_us": t["median_us"], "calls": t["calls"],
+     "algorithmic_bytes": alg, "hbm_bytes_counted": hbm, "traffic_over_algorithmic": hbm / alg,
+     "achieved_GBs_avg": alg / (t["avg_us"] * 1e-6) / 1e9, "frac_of_8TBs": alg / (t["avg_us"] * 1e-6) / 8e12}
+json.dump(d, open(f"{out}/summary_render.json", "w"), indent=1)
+print(json.dumps(d))
+PY
