@@ -199,7 +199,21 @@ struct Ray {
 //        No operand on a valid ray is denormal or zero-denominator (eps = 1e-9 guards, unit
 //        direction vectors, |positions| in [1e-6, 2e4] mm), so valid rays are bit-identical
 //        to the Ieee instantiation; tests/test_gpu_parity.py runs both against the oracle.
+// Exact fusions (Lean only; Ieee keeps the reference's literal operation sequence).  A product with a power
+// of two or with a 0/1 flag is EXACT (no rounding, barring over/underflow), so the reference's
+// "round the product, then add" is what one fma computes:
+//   dfdt(dgd, y, dz)      : dgd * (2*y) - dz          = fma(2, dgd*y, -dz)        [2*(p) commutes with rounding]
+//   add_half_quot(s, a, b): s + (a*0.5)/b             = fma(0.5, a/b, s)          [(a/2)/b == (a/b)/2]
+//   one_minus_flagged(x,f): 1 - x*f,  f in {0, 1}     = fma(-x, f, 1)
+// One vector instruction less each, 2 per sag evaluation (49 evaluations per ray) and 1 per refraction.
+// Outside the normal range (|values| below 2^-125: a denormal product) the two forms can round differently;
+// no traced ray gets there (positions are sums of O(1)-mm terms: 0 or >= 1e-7 mm), and the parity tests
+// run both policies against the oracle.
 struct Ieee {
+    static constexpr bool kFused = false;
+    static __device__ __forceinline__ float dfdt(float dgd, float y, float dz) { return dgd * (2.0f * y) - dz; }
+    static __device__ __forceinline__ float add_half_quot(float s, float a, float b) { return s + (a * 0.5f) / b; }
+    static __device__ __forceinline__ float one_minus_flagged(float x, float f) { return 1.0f - x * f; }
     static __device__ __forceinline__ float div(float a, float b) { return a / b; }
     static __device__ __forceinline__ float sqrt(float x) { return __builtin_sqrtf(x); }
     static __device__ __forceinline__ float sqrt_pos(float x) { return __builtin_sqrtf(x); }
@@ -209,6 +223,16 @@ struct Ieee {
     }
 };
 struct Lean {
+    static constexpr bool kFused = true;
+    static __device__ __forceinline__ float dfdt(float dgd, float y, float dz)
+    {
+        return __builtin_fmaf(2.0f, dgd * y, -dz);
+    }
+    static __device__ __forceinline__ float add_half_quot(float s, float a, float b)
+    {
+        return __builtin_fmaf(0.5f, div(a, b), s);
+    }
+    static __device__ __forceinline__ float one_minus_flagged(float x, float f) { return __builtin_fmaf(-x, f, 1.0f); }
     static __device__ __forceinline__ float div(float a, float b)
     {
         const float y0 = __builtin_amdgcn_rcpf(b);
@@ -359,7 +383,7 @@ __device__ __forceinline__ void sag_g_dgd(const C& k, const NoPoly&, int, float 
     const float sf = INSIDE ? M::sqrt_pos(1.0f - a) : M::sqrt(1.0f - a);
     const float onesf = 1.0f + sf;
     g = M::div(r2 * k.c, onesf);
-    dgd = M::div((onesf + M::div(a * 0.5f, sf)) * k.c, onesf * onesf);   // a/2 == a*0.5 exactly
+    dgd = M::div(M::add_half_quot(onesf, a, sf) * k.c, onesf * onesf);   // (onesf + (a/2)/sf) * c / onesf^2
 }
 
 template <class M, bool INSIDE, class C, bool UNITK = false, class P = Poly>
@@ -439,8 +463,7 @@ __device__ __forceinline__ bool newton_k(const S& s, const P& pol, const Ray& r,
         float g, dgd;
         sag_g_dgd<M, KGT, CV, UNITK>(k, pol, deg, r2, g, dgd);
         const float ft = (g + k.d) - nz;
-        const float dr2dt = 2.0f * (dd * t + dox);
-        const float dfdt = dgd * dr2dt - r.dz;
+        const float dfdt = M::dfdt(dgd, dd * t + dox, r.dz);            // dgd * dr2dt - dz, dr2dt = 2((dx^2+dy^2) t + (dx ox + dy oy))
         const unsigned long long open = __ballot(__builtin_fabsf(ft) > tol_loose);
         const float tn = t - clamp_sym(M::div(ft, dfdt + eps), kNewtonStepBound);
         uint32_t tmp;
@@ -504,8 +527,7 @@ __device__ __forceinline__ bool newton_k(const S& s, const P& pol, const Ray& r,
     float g, dgd;
     sag_g_dgd<M, KGT, CV, UNITK>(k, pol, deg, r2, g, dgd);
     const float ft = (g + k.d) - nz;
-    const float dr2dt = 2.0f * (dd * t + dox);
-    const float dfdt = dgd * dr2dt - r.dz;
+    const float dfdt = M::dfdt(dgd, dd * t + dox, r.dz);
     t = t - clamp_sym(M::div(ft, dfdt + eps), kNewtonStepBound);
     nx = r.ox + r.dx * t;
     ny = r.oy + r.dy * t;
@@ -523,6 +545,8 @@ template <bool FWD, class M, class P, class S>
 __device__ __forceinline__ void refract(const S& s, const P& pol, Ray& r)
 {
     float nx, ny, nz;
+    float sgn = 1.0f;              // sign of the normal still to be applied (spheres under the Lean policy)
+    bool flip_fwd = FWD;
     if (!std::is_same<P, NoPoly>::value) {
         const float vf = r.ra > 0.0f ? 1.0f : 0.0f;
         const float xv = r.ox * vf, yv = r.oy * vf;
@@ -532,6 +556,15 @@ __device__ __forceinline__ void refract(const S& s, const P& pol, Ray& r)
         nx = (ds * 2.0f) * xv; ny = (ds * 2.0f) * yv; nz = -1.0f;
     } else if (s.kind() == 0) {
         nx = 0.0f; ny = 0.0f; nz = -1.0f;
+    } else if (s.kind() == 1 && M::kFused) {
+        // sphere: n = normalize(+-2 (o - centre)), negated when tracing forward (surfaces.py:607-615, 650).
+        // Scaling by +-2 is exact and commutes with every rounding of the normalisation, so
+        // n = sgn * m with m = normalize(o - centre) -- and the sign only survives in the sr * n term
+        // below (cosi * n = (sgn cm)(sgn m) = cm m): three multiplications by +-2 and the negation
+        // become one multiplication of sr by +-1.
+        nx = r.ox; ny = r.oy; nz = r.oz - s.d_plus_R();
+        sgn = (s.c_pos() != FWD) ? 1.0f : -1.0f;
+        flip_fwd = false;
     } else if (s.kind() == 1) {
         const float sg = s.c_pos() ? 2.0f : -2.0f;       // (+-2) * x is exact either way
         nx = sg * r.ox; ny = sg * r.oy; nz = sg * r.oz - sg * s.d_plus_R();
@@ -546,14 +579,15 @@ __device__ __forceinline__ void refract(const S& s, const P& pol, Ray& r)
     // >= 2^-24 by the validity test (sqrt_pos; a dead ray's garbage stays confined to the
     // discarded candidate direction)
     normalize3<M, true>(nx, ny, nz);
-    if (FWD) { nx = -nx; ny = -ny; nz = -nz; }
+    if (flip_fwd) { nx = -nx; ny = -ny; nz = -nz; }
     const float eta = s.eta(), eta2 = s.eta2();
-    const float cosi = (r.dx * nx + r.dy * ny) + r.dz * nz;
+    const float cosi = (r.dx * nx + r.dy * ny) + r.dz * nz;     // up to the pending sign
     const float c2i = cosi * cosi;
     const float omc = 1.0f - c2i;
     const bool v = c2i > 0.1f && eta2 * omc < 1.0f && r.ra > 0.0f;
     const float vf = v ? 1.0f : 0.0f;
-    const float sr = M::sqrt_pos(1.0f - (eta2 * omc) * vf);
+    float sr = M::sqrt_pos(M::one_minus_flagged(eta2 * omc, vf));
+    if (M::kFused && s.kind() == 1) sr = sr * sgn;
     float ndx = sr * nx + eta * (r.dx - cosi * nx);
     float ndy = sr * ny + eta * (r.dy - cosi * ny);
     float ndz = sr * nz + eta * (r.dz - cosi * nz);
@@ -734,15 +768,23 @@ struct SplatGeom {
     int32_t ks;
 };
 
-template <class DivY, class DivX>
+// UNIT_W: the ray's weight is exactly 0 or 1 (every TRACED ray's is: ra starts at 1 and is only ever
+// multiplied by 0/1 validity flags) -- then w is 0 or 1 and the seven products with it are identities.
+template <bool UNIT_W = false, class DivY, class DivX>
 __device__ __forceinline__ bool splat_taps(const SplatGeom& gm, const DivY& div_dy, const DivX& div_dx,
                                            float sx, float sy, float cx, float cy, float ra, SplatTaps& tp)
 {
     float px = (-sx) - cx;                     // points = -o.xy ; points - pointc_ref
     float py = (-sy) - cy;
-    float w = ra * (__builtin_fabsf(px) < gm.lim ? 1.0f : 0.0f);
-    w = w * (__builtin_fabsf(py) < gm.lim ? 1.0f : 0.0f);
-    if (!(w != 0.0f)) return false;            // adds exact zeros in the reference
+    float w;
+    if (UNIT_W) {
+        if (!(ra != 0.0f && __builtin_fabsf(px) < gm.lim && __builtin_fabsf(py) < gm.lim)) return false;
+        w = 1.0f;                              // the compiler folds the products below away
+    } else {
+        w = ra * (__builtin_fabsf(px) < gm.lim ? 1.0f : 0.0f);
+        w = w * (__builtin_fabsf(py) < gm.lim ? 1.0f : 0.0f);
+        if (!(w != 0.0f)) return false;        // adds exact zeros in the reference
+    }
     px = px * w; py = py * w;                  // :38
     const float pf0 = div_dy(py - gm.y_max) * gm.ksm1;   // row
     const float pf1 = div_dx(px - gm.x_min) * gm.ksm1;   // col

@@ -458,8 +458,8 @@ k_psf_lr(SplatBlock sb /* kernarg offset 0 */, TripSet trips /* 64 */, TripSet t
         dp.h = F(7); dp.f = F(8); dp.w = F(9); dp.r = F(10); dp.fmh = F(11); dp.rr = F(12);
         dp.inv_r = F(13); dp.r_pow2 = (int)q[14]; dp.tr = tr; dp.tl = tl; dp.big = BIG; dp.have_r = HAVE_R;
         SplatTaps tp;
-        if (!splat_taps(gm, UDiv<HotMath>::make(gm.dy_rng), UDiv<HotMath>::make(gm.dx_rng), sx, sy, cx, cy,
-                        ra, tp))
+        if (!splat_taps<HotMath::kFused>(gm, UDiv<HotMath>::make(gm.dy_rng), UDiv<HotMath>::make(gm.dx_rng), sx, sy, cx,
+                                         cy, ra, tp))
             return;
         const float x_tan = HotMath::div(-dx, dz);
         float sl, sr;
