@@ -108,6 +108,10 @@ typedef struct sdirt_dp_params {
  * prefetch would trace with stale constants -- the build-time ISA check is the first guard,
  * this is the second). */
 #define SDIRT_TRACE_NO_PREFETCH 8u
+/* sdirt_psf_lr_verified / sdirt_psf_call only: verify on the device (status word, corrected tables) but do NOT
+ * enqueue round 2 -- for callers whose speculated tables have been right for a long streak: three empty
+ * launches less per call; when the status comes back non-zero the caller launches the correction itself. */
+#define SDIRT_PSF_ONE_ROUND 16u
 
 /* ---- library ------------------------------------------------------------ */
 int sdirt_abi_version(void);
@@ -316,6 +320,23 @@ int sdirt_psf_lr_verified(const sdirt_lens* lens, const sdirt_lens* lens_center,
                           const int32_t* trips_center /*host [K]*/, uint32_t flags,
                           float* center /*dev [N,2], out*/, float* l_psf /*dev [N,ks,ks]*/,
                           float* r_psf /*dev or NULL*/, void* scratch /*dev*/, void* stream);
+
+/* One whole psf call of the fitting shape enqueued by ONE library call (a Python caller pays per call
+ * into the library, and this shape is launch-latency-bound): upload the 2 * spp + 2 * spp_center
+ * uniforms the caller drew (u_host, page-locked, in the reference's draw order -- theta[spp], r2[spp] of
+ * Lensgroup.sample_from_points, optics.py:483-484, then theta[spp_center], r2[spp_center] of the same lines
+ * inside psf_center, optics.py:898), map them onto the pupil and the shrunk pupil (sdirt_pupil_samples),
+ * run sdirt_psf_lr_verified, and copy the control block to ctl_host (page-locked, SDIRT_CTL_WORDS words).
+ * The caller synchronises the stream and reads ctl_host.  scratch: dev, 8-byte aligned,
+ * sdirt_psf_call_scratch_bytes(n_points, spp, spp_center) bytes, the first SDIRT_CTL_WORDS words zeroed. */
+int64_t sdirt_psf_call_scratch_bytes(int64_t n_points, int64_t spp, int64_t spp_center);
+int sdirt_psf_call(const sdirt_lens* lens, const sdirt_lens* lens_center, const float* point_obj /*dev [N,3]*/,
+                   int64_t n_points, const float* u_host /*host, page-locked*/, int64_t spp, int64_t spp_center,
+                   double pupil_r, double pupil_r_center, double pupil_z, double d_sensor, double ps, int32_t ks,
+                   const sdirt_dp_params* dp /*host or NULL*/, const int32_t* trips /*host [K]*/,
+                   const int32_t* trips_center /*host [K]*/, uint32_t flags, float* center /*dev [N,2], out*/,
+                   float* l_psf /*dev [N,ks,ks]*/, float* r_psf /*dev or NULL*/, void* scratch /*dev*/,
+                   uint32_t* ctl_host /*host, page-locked, out*/, void* stream);
 
 /* ---- diagnostics ----------------------------------------------------------- */
 

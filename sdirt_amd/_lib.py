@@ -19,6 +19,7 @@ MAX_WAVELENGTHS = 3
 PSF_NORMALIZE = 1
 PSF_STRICT_IEEE = 4
 TRACE_NO_PREFETCH = 8
+PSF_ONE_ROUND = 16
 CTL_STATUS, CTL_ANY_VALID, CTL_TRIPS2, CTL_MASKS, CTL_WORDS = 0, 1, 16, 64, 320
 
 KIND_PLANE, KIND_SPHERE, KIND_ASPHERE = 0, 1, 2
@@ -83,6 +84,9 @@ SIGNATURES = {
     "sdirt_psf_lr_verified": (C.c_int, [_P, _P, _P, _I64, _P, _P, _I64, _P, _P, _I64, _D, _D, _D, _I32,
                                         C.POINTER(DpParams), C.POINTER(_I32), C.POINTER(_I32), _U32,
                                         _P, _P, _P, _P, _P]),
+    "sdirt_psf_call_scratch_bytes": (_I64, [_I64, _I64, _I64]),
+    "sdirt_psf_call": (C.c_int, [_P, _P, _P, _I64, _P, _I64, _I64, _D, _D, _D, _D, _D, _I32, C.POINTER(DpParams),
+                                 C.POINTER(_I32), C.POINTER(_I32), _U32, _P, _P, _P, _P, _P, _P]),
     "sdirt_selftest_math": (C.c_int, [_I32, C.c_uint64, C.c_uint64, _I32, _P, _P]),
     "sdirt_local_psf_render": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P, _P]),
     "sdirt_psfnet_render": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P]),

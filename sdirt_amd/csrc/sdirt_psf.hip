@@ -696,7 +696,7 @@ static int launch_psf(const sdirt_lens* const* lens, int W, const float* point_o
     // ---- verified call on the split path: round 1 with the speculated tables, the tables checked on
     // the device by the round's last kernel, round 2 with the corrected tables enqueued right behind
     // it -- its kernels return at once when round 1 was right.  No host round trip in between.
-    const int rounds = vr ? 2 : 1;
+    const int rounds = (vr && !(flags & SDIRT_PSF_ONE_ROUND)) ? 2 : 1;
     int chunk_c = 0;
     const int nslice_c = vr ? chief_slices(N, cen->Sc, &chunk_c) : 0;
     for (int round = 0; round < rounds; ++round) {
@@ -907,6 +907,42 @@ int sdirt_psf_lr_verified(const sdirt_lens* lens, const sdirt_lens* lens_center,
     cr.any_valid = nullptr; cr.conv_mask_c = nullptr;
     return launch_psf(&lens, 1, point_obj, N, x2, y2, S, pupil_z, d_sensor, ps, ks, nullptr, &cr, dp, tt, flags,
                       l_psf, r_psf, nullptr, stream, &vr);
+}
+
+static size_t align64(size_t n) { return (n + 63) / 64 * 64; }
+
+int64_t sdirt_psf_call_scratch_bytes(int64_t N, int64_t S, int64_t Sc)
+{
+    if (N < 0 || S < 0 || Sc < 0) return -1;
+    return (int64_t)align64((size_t)sdirt_psf_verified_scratch_bytes(N, Sc)) + (int64_t)sizeof(float) * 4 * (S + Sc);
+}
+
+int sdirt_psf_call(const sdirt_lens* lens, const sdirt_lens* lens_center, const float* point_obj, int64_t N,
+                   const float* u_host, int64_t S, int64_t Sc, double pupil_r, double pupil_r_center,
+                   double pupil_z, double d_sensor, double ps, int32_t ks, const sdirt_dp_params* dp,
+                   const int32_t* trips, const int32_t* trips_center, uint32_t flags, float* center,
+                   float* l_psf, float* r_psf, void* scratch, uint32_t* ctl_host, void* stream)
+{
+    if (!u_host || !scratch || !ctl_host || N < 0 || S < 1 || Sc < 1 || S > (1ll << 30) || Sc > (1ll << 30))
+        return fail(SDIRT_ERR_INVALID_ARGUMENT, "bad argument");
+    if (((uintptr_t)scratch) & 7) return fail(SDIRT_ERR_INVALID_ARGUMENT, "scratch must be 8-byte aligned");
+    hipStream_t st = as_stream(stream);
+    const int64_t n = 2 * (S + Sc);
+    float* u = reinterpret_cast<float*>(static_cast<char*>(scratch) +
+                                        align64((size_t)sdirt_psf_verified_scratch_bytes(N, Sc)));
+    float* xy = u + n;
+    HIP_TRY(hipMemcpyAsync(u, u_host, sizeof(float) * (size_t)n, hipMemcpyHostToDevice, st));
+    // the reference's draw order (optics.py:483-484, then again inside psf_center): theta, r^2 of the primary
+    // pass, theta, r^2 of the chief-ray pass
+    if (int rc = sdirt_pupil_samples(u, u + S, S, pupil_r, xy, xy + S, stream)) return rc;
+    if (int rc = sdirt_pupil_samples(u + 2 * S, u + 2 * S + Sc, Sc, pupil_r_center, xy + 2 * S, xy + 2 * S + Sc, stream))
+        return rc;
+    if (int rc = sdirt_psf_lr_verified(lens, lens_center, point_obj, N, xy, xy + S, S, xy + 2 * S, xy + 2 * S + Sc, Sc,
+                                       pupil_z, d_sensor, ps, ks, dp, trips, trips_center, flags, center, l_psf, r_psf,
+                                       scratch, stream))
+        return rc;
+    HIP_TRY(hipMemcpyAsync(ctl_host, scratch, sizeof(uint32_t) * SDIRT_CTL_WORDS, hipMemcpyDeviceToHost, st));
+    return SDIRT_OK;
 }
 
 }  // extern "C"

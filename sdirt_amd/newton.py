@@ -86,6 +86,7 @@ class TripPlanner:
         self.launches = 0
         self.relaunches = 0          # rounds the HOST had to launch again
         self.device_relaunches = 0   # corrections the device made on its own (sdirt_psf_lr_verified)
+        self._accepted = set()       # (trip table, masks) pairs verify() has already accepted
 
     def initial(self, key, curved):
         """Batches of one workload flip between a few neighbouring tables (the slowest ray of
@@ -143,8 +144,17 @@ class TripPlanner:
         for i in range(rounds):
             masks = done[i][1] if i < len(done) else launch(tables)
             self.launches += 1
+            # a caller rendering the same kind of batch over and over reports the same masks for the
+            # same tables: what verify() accepted once it accepts again
+            sig = tuple((tuple(int(x) for x in t), tuple(int(x) for x in m)) for t, m in zip(tables, masks))
+            if sig in self._accepted and tuple(order) == tuple(range(K)):
+                for k, t in zip(keys, tables):
+                    self.learn(k, t)
+                return tables
             results = [verify(t, m, order, curved, aggressive=i > 0) for t, m in zip(tables, masks)]
             if all(ok for ok, _ in results):
+                if tuple(order) == tuple(range(K)) and len(self._accepted) < 4096:
+                    self._accepted.add(sig)
                 for k, t in zip(keys, tables):
                     self.learn(k, t)
                 return tables

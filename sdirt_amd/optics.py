@@ -722,6 +722,13 @@ class Lensgroup:
         # RNG order of the reference: primary pupil samples first (optics.py:963),
         # then the chief-ray samples inside psf_center (optics.py:969).
         pupilz, pupilr = self.entrance_pupil()
+        if (center and not defer and pupil_xy is None and center_pupil_xy is None and N > 0
+                and self.trip_policy == "reference" and self.mask_reduce is None and self.pupil_mapping == "device"
+                and self.kernel_events is None and _lib.lib().sdirt_psf_spp_slices(N, spp) > 1):
+            # the synchronous call of the fitting shape (few points, many samples): launch-latency-bound,
+            # so everything between the random draw and the stream synchronisation is ONE library call
+            return self._psf_call_one(points, po, N, ks, wvln, spp, dp, normalize, want_r, _default_r_zero, out,
+                                      center_out, single_point)
         both_drawn = None
         if pupil_xy is None and center and center_pupil_xy is None:
             # both sample sets of the call in one draw / upload (same numbers, same order)
@@ -931,6 +938,102 @@ class Lensgroup:
                         float(self.d_sensor), float(self.pixel_size), ks, dptr(cen), dp_ref, trips,
                         flags, dptr(L), dptr(R), mask_ptr, stream_ptr(self.device)))
             self._run_with_trips(("psf", wkey, self.precision), range(K), enqueue)
+        if R is None and want_r:
+            R = torch.zeros_like(L)
+        if single_point:
+            L = L.squeeze(0)
+            R = R.squeeze(0) if R is not None else None
+        return L, R
+
+    def _psf_call_one(self, points, po, N, ks, wvln, spp, dp, normalize, want_r, default_r_zero, out, center_out,
+                      single_point):
+        """psf_lr(center=True) for sdirt_psf_spp_slices(N, spp) > 1, synchronous form, through sdirt_psf_call:
+        the host draws the 2 spp + 2 x 2048 uniforms (one torch.rand, the reference's order) into page-locked
+        memory; ONE library call enqueues their upload, the two pupil mappings, both rounds of the
+        device-verified render and the copy of the control block back; the host waits for the stream and
+        checks what the device did (TripPlanner.run_many(done=...)).  Same results as the general path."""
+        h, K, MS = _lib.lib(), len(self.surfaces), _lib.MAX_SURFACES
+        Sc = GEO_SPP
+        pupilz, pupilr = self.entrance_pupil()
+        pupilr_c = self.entrance_pupil(shrink_pupil=True)[1]
+        need_r = want_r and not default_r_zero
+        if center_out is not None:
+            if not (center_out.is_cuda and center_out.dtype == torch.float32 and center_out.is_contiguous()
+                    and tuple(center_out.shape) == (N, 2)):
+                raise ValueError("center_out must be a contiguous float32 CUDA [N, 2] tensor")
+            cen = center_out
+        else:
+            cen = torch.empty((N, 2), dtype=torch.float32, device=self.device)
+        if out is not None:
+            L, R = out[0], (out[1] if need_r else None)
+            for t_ in (L, R):
+                if t_ is not None and not (t_.is_cuda and t_.dtype == torch.float32 and t_.is_contiguous()
+                                           and tuple(t_.shape) == (N, ks, ks)):
+                    raise ValueError("out tensors must be contiguous float32 CUDA [N, ks, ks]")
+        else:
+            L = torch.empty((N, ks, ks), dtype=torch.float32, device=self.device)
+            R = torch.empty_like(L) if need_r else None
+        dpp = None if (dp is None or default_r_zero) else _lib.DpParams(*[float(v) for v in dp])
+        dp_ref = C.byref(dpp) if dpp is not None else None
+        handle, handle_c = self.dev_lens(wvln), self.dev_lens(DEFAULT_WAVE)
+        flags = (_lib.PSF_NORMALIZE if normalize else 0) | self._math_flags()
+        wkey = round(float(wvln if wvln < 10 else wvln * 1e-3), 6)
+        keys = [("psf", wkey, self.precision), ("center", self.precision)]
+        curved = self._curved()
+        tables = [self.trips.initial(k, curved) for k in keys]
+        # a long streak of right bets (a caller rendering the same batch again and again): the correction
+        # round is not even enqueued -- if the device's check fails after all, the host launches it (below)
+        streak = self.__dict__.get("_right_streak", 0)
+        if streak >= 32:
+            flags |= _lib.PSF_ONE_ROUND
+        n = 2 * (spp + Sc)
+        words = int(h.sdirt_psf_call_scratch_bytes(N, spp, Sc) // 4)
+        scratch = self._zeroed_control_block(words)
+        hbuf = self.__dict__.get("_ctl_host")
+        if hbuf is None:
+            hbuf = self.__dict__["_ctl_host"] = torch.empty(_lib.CTL_WORDS, dtype=torch.int32, pin_memory=True)
+        stage, uploaded = self._staging(n, rows=1)
+        st = stream_ptr(self.device)
+        torch.rand(n, out=stage[0])                          # the reference's four draws, in one (see _pupil_samples_pair)
+        _lib.check(h.sdirt_psf_call(
+            handle, handle_c, dptr(po), N, C.c_void_p(stage.data_ptr()), spp, Sc, float(pupilr), float(pupilr_c),
+            float(pupilz), float(self.d_sensor), float(self.pixel_size), ks, dp_ref,
+            (C.c_int32 * K)(*[int(t) for t in tables[0]]), (C.c_int32 * K)(*[int(t) for t in tables[1]]), flags,
+            dptr(cen), dptr(L), dptr(R), dptr(scratch), C.c_void_p(hbuf.data_ptr()), st))
+        stream = torch.cuda.current_stream(self.device)
+        uploaded.record(stream)
+        stream.synchronize()
+        hh = hbuf.numpy().view(np.uint32).copy()
+        # the pupil points the device mapped: behind the control block and the partial sums in `scratch`
+        base = words - 2 * n
+        xy = scratch[base + n:].view(torch.float32)
+        x2, y2, xc, yc = xy[:spp], xy[spp:2 * spp], xy[2 * spp:2 * spp + Sc], xy[2 * spp + Sc:]
+        self.last_pupil_points = (x2, y2, xc, yc)
+        state = {"any": int(hh[_lib.CTL_ANY_VALID])}
+        self.__dict__["_right_streak"] = streak + 1 if hh[_lib.CTL_STATUS] == 0 else 0
+        rounds = [(tables, [hh[_lib.CTL_MASKS:_lib.CTL_MASKS + K], hh[_lib.CTL_MASKS + 64:_lib.CTL_MASKS + 64 + K]])]
+        if hh[_lib.CTL_STATUS] and not (flags & _lib.PSF_ONE_ROUND):
+            unpack = lambda w: np.array([((int(w[k >> 2]) >> ((k & 3) * 8)) & 0xFF) for k in range(K)],
+                                        np.int32).astype(np.int8).astype(np.int32)
+            rounds.append(([unpack(hh[_lib.CTL_TRIPS2:_lib.CTL_TRIPS2 + 16]),
+                            unpack(hh[_lib.CTL_TRIPS2 + 16:_lib.CTL_TRIPS2 + 32])],
+                           [hh[_lib.CTL_MASKS + 128:_lib.CTL_MASKS + 128 + K],
+                            hh[_lib.CTL_MASKS + 192:_lib.CTL_MASKS + 192 + K]]))
+
+        def launch(tabs):                                    # a further, host-driven round (rare)
+            ctl = self._zeroed_control_block(2 * MS + 1)
+            masks, anyv = ctl[:2 * MS].view(2, MS), ctl[2 * MS:]
+            _lib.check(h.sdirt_psf_lr_centered(
+                handle, handle_c, dptr(po), N, dptr(x2), dptr(y2), spp, dptr(xc), dptr(yc), Sc, float(pupilz),
+                float(self.d_sensor), float(self.pixel_size), ks, dp_ref, (C.c_int32 * K)(*[int(t) for t in tabs[0]]),
+                (C.c_int32 * K)(*[int(t) for t in tabs[1]]), flags, dptr(cen), dptr(anyv), dptr(L), dptr(R),
+                dptr(masks[0]), dptr(masks[1]), stream_ptr(self.device)))
+            host = ctl.cpu().numpy()
+            state["any"] = int(host[2 * MS])
+            m = host[:2 * MS].reshape(2, MS)[:, :K].astype(np.int64) & 0xFFFFFFFF
+            return [m[0], m[1]]
+        self.trips.run_many(keys, curved, list(range(K)), launch, done=rounds)
+        assert state["any"] == 1, "No sampled rays is valid."   # optics.py:902
         if R is None and want_r:
             R = torch.zeros_like(L)
         if single_point:

@@ -649,3 +649,67 @@ def test_device_side_trip_verification_on_the_split_path(bet):
     # default param_list (R grid stays zero, monte_carlo.py:231) through the same path
     a = ln.psf_diff(pts, ks=21, spp=20000)
     assert a.shape == (64, 21, 21) and float(a.amax((1, 2)).min()) > 0.99
+
+
+def test_one_call_synchronous_path_equals_the_general_path():
+    """sdirt_psf_call (draw -> one library call -> wait) against the general verified path handed the
+    same pupil points, and against a deferred call from the same seed: same PSFs, same centres, same
+    verified tables, the generator left where the reference leaves it (2 x 20000 + 2 x 2048 draws)."""
+    st = load_state("rf50mm")
+    pts, _, _ = _training_shape_inputs(seed=9)
+    ln = make_lens("rf50mm", DEV)
+    torch.manual_seed(42)
+    c1 = torch.empty((64, 2), device=DEV)
+    L1, R1 = ln.psf_lr(pts, ks=21, spp=20000, dp=DP, center_out=c1)          # one-call path
+    tail = torch.rand(4)
+    x2, y2, xc, yc = [v.clone() for v in ln.last_pupil_points]
+    torch.manual_seed(42)
+    torch.rand(2 * 20000 + 2 * 2048)
+    assert torch.equal(torch.rand(4), tail)
+    ln2 = make_lens("rf50mm", DEV)
+    c2 = torch.empty((64, 2), device=DEV)
+    L2, R2 = ln2.psf_lr(pts, ks=21, dp=DP, pupil_xy=(x2, y2), center_pupil_xy=(xc, yc), center_out=c2)
+    assert torch.equal(c1, c2)
+    assert float((L1 - L2).abs().max()) <= 3e-6 and float((R1 - R2).abs().max()) <= 3e-6
+    for k in (("psf", 0.589, "lean"), ("center", "lean")):
+        assert np.array_equal(ln.trips.cache[k], ln2.trips.cache[k])
+    torch.manual_seed(42)
+    L3, R3 = ln2.psf_lr(pts, ks=21, spp=20000, dp=DP, defer=True).wait()      # side-stream upload, deferred check
+    assert float((L1 - L3).abs().max()) <= 3e-6 and float((R1 - R3).abs().max()) <= 3e-6
+    # the device mapped the same pupil points the staged mapping kernel produces from the same uniforms
+    torch.manual_seed(42)
+    u = torch.rand(2 * 20000 + 2 * 2048)
+    want = ln2._pupil_samples_pair.__func__      # (same kernel: checked through the values)
+    torch.manual_seed(42)
+    a = ln2._pupil_samples_pair(20000, st["pupil_r"], 2048, st["pupil_r"] * 0.25, side_stream=False)
+    assert all(torch.equal(p, q) for p, q in zip(a, (x2, y2, xc, yc)))
+    # single point, default param_list (L only), a wrong bet: all through the one-call path
+    ln.trips.learn(("psf", 0.589, "lean"), np.where(np.array(ln._curved()), 10, 0))
+    d0 = ln.trips.device_relaunches
+    torch.manual_seed(1)
+    one = ln.psf(pts[3], ks=21, spp=20000)
+    assert one.shape == (21, 21) and float(one.max()) > 0.99 and ln.trips.device_relaunches == d0 + 1
+
+
+def test_long_streak_of_right_bets_skips_the_correction_round_and_recovers():
+    """After 32 calls whose speculated tables were right the one-call path stops enqueuing round 2
+    (SDIRT_PSF_ONE_ROUND); a batch that then needs another table is corrected by the host and the
+    streak starts over -- the result is the reference's either way."""
+    pts, _, _ = _training_shape_inputs(seed=11)
+    ln = make_lens("rf50mm", DEV)
+    for i in range(34):
+        torch.manual_seed(100)
+        L0, R0 = ln.psf_lr(pts, ks=21, spp=20000, dp=DP)
+    assert ln.__dict__["_right_streak"] >= 32
+    good = {k: v.copy() for k, v in ln.trips.cache.items()}
+    key = ("psf", 0.589, "lean")
+    wrong = good[key].copy()
+    wrong[3] += 1
+    for _ in range(70):
+        ln.trips.learn(key, wrong)                        # out-vote the right table: the next bet is wrong
+    r0 = ln.trips.relaunches
+    torch.manual_seed(100)
+    L1, R1 = ln.psf_lr(pts, ks=21, spp=20000, dp=DP)
+    assert ln.trips.relaunches == r0 + 1 and ln.__dict__["_right_streak"] == 0
+    assert np.array_equal(ln.trips.cache[key], good[key])
+    assert float((L0 - L1).abs().max()) <= 3e-6 and float((R0 - R1).abs().max()) <= 3e-6
