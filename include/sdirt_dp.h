@@ -338,6 +338,16 @@ int sdirt_psf_call(const sdirt_lens* lens, const sdirt_lens* lens_center, const 
                    float* l_psf /*dev [N,ks,ks]*/, float* r_psf /*dev or NULL*/, void* scratch /*dev*/,
                    uint32_t* ctl_host /*host, page-locked, out*/, void* stream);
 
+/* ---- host side: the reference's random stream ------------------------------ */
+
+/* torch.rand(n) on the CPU default generator -- the draws of Lensgroup.sample_from_points,
+ * deeplens/optics.py:483-484 -- without torch's per-number loop: th_state is the byte image
+ * torch.get_rng_state() returns (a copy the caller hands back with torch.set_rng_state); on return
+ * out[0..n) holds the n floats torch.rand(n) would have produced from that state and th_state the state
+ * torch would be in afterwards (MT19937 blocks of 624, (x & 0xffffff) * 2^-24 per number).  Host memory
+ * only, no GPU involved.  SDIRT_ERR_UNSUPPORTED when the state image does not look as expected. */
+int sdirt_host_uniform_fill(void* th_state /*host, in/out*/, int64_t state_bytes, int64_t n, float* out /*host*/);
+
 /* ---- diagnostics ----------------------------------------------------------- */
 
 /* Counts how often the lean arithmetic (the default, see SDIRT_PSF_STRICT_IEEE) differs from correctly rounded IEEE:

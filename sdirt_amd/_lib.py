@@ -87,6 +87,7 @@ SIGNATURES = {
     "sdirt_psf_call_scratch_bytes": (_I64, [_I64, _I64, _I64]),
     "sdirt_psf_call": (C.c_int, [_P, _P, _P, _I64, _P, _I64, _I64, _D, _D, _D, _D, _D, _I32, C.POINTER(DpParams),
                                  C.POINTER(_I32), C.POINTER(_I32), _U32, _P, _P, _P, _P, _P, _P]),
+    "sdirt_host_uniform_fill": (C.c_int, [_P, _I64, _I64, _P]),
     "sdirt_selftest_math": (C.c_int, [_I32, C.c_uint64, C.c_uint64, _I32, _P, _P]),
     "sdirt_local_psf_render": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P, _P]),
     "sdirt_psfnet_render": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P]),

@@ -20,7 +20,7 @@ import weakref
 import numpy as np
 import torch
 
-from . import _lib
+from . import _hostrng, _lib
 from .basics import DEFAULT_WAVE, DEPTH, GEO_SPP, WAVE_RGB, Ray, dptr, stream_ptr
 from .newton import NEWTON_MAXITER, TripPlanner
 from .surfaces import Aspheric
@@ -410,8 +410,8 @@ class Lensgroup:
             side = self.__dict__["_sample_stream"] = torch.cuda.Stream(self.device)
         with torch.cuda.stream(side):
             stage, done = self._staging(spp)
-            torch.rand(spp, out=stage[0])
-            torch.rand(spp, out=stage[1])
+            _hostrng.rand_into(stage[0])
+            _hostrng.rand_into(stage[1])
             u = stage.to(self.device, non_blocking=True)
             done.record(side)
             xy = torch.empty((2, spp), dtype=torch.float32, device=self.device)
@@ -437,7 +437,7 @@ class Lensgroup:
 
         def upload_and_map():
             stage, done = self._staging(n, rows=1)
-            torch.rand(n, out=stage[0])
+            _hostrng.rand_into(stage[0])
             u = stage[0].to(self.device, non_blocking=True)
             done.record(torch.cuda.current_stream(self.device))
             xy = torch.empty(n, dtype=torch.float32, device=self.device)
@@ -994,7 +994,7 @@ class Lensgroup:
             hbuf = self.__dict__["_ctl_host"] = torch.empty(_lib.CTL_WORDS, dtype=torch.int32, pin_memory=True)
         stage, uploaded = self._staging(n, rows=1)
         st = stream_ptr(self.device)
-        torch.rand(n, out=stage[0])                          # the reference's four draws, in one (see _pupil_samples_pair)
+        _hostrng.rand_into(stage[0])                         # the reference's four draws, in one (see _pupil_samples_pair)
         _lib.check(h.sdirt_psf_call(
             handle, handle_c, dptr(po), N, C.c_void_p(stage.data_ptr()), spp, Sc, float(pupilr), float(pupilr_c),
             float(pupilz), float(self.d_sensor), float(self.pixel_size), ks, dp_ref,

@@ -357,3 +357,26 @@ def test_one_rand_call_equals_the_reference_s_four_consecutive_draws():
         one = torch.rand(2 * spp + 4096)
         after1 = torch.rand(3)
         assert torch.equal(four, one) and torch.equal(after4, after1)
+
+
+def test_fast_host_random_stream_is_torch_rand():
+    """sdirt_host_uniform_fill (block-wise MT19937) against torch.rand on the default CPU generator: same
+    numbers and same generator state afterwards, for sizes around the 624-number block boundary, after
+    other draws, interleaved with torch's own draws (randn in between)."""
+    import torch
+    from sdirt_amd import _hostrng
+    assert _hostrng.enabled()
+    for n in (1, 2, 619, 623, 624, 625, 1247, 4096, 44096):
+        for pre in (0, 1, 620, 624, 1000):
+            torch.manual_seed(1000 + n)
+            if pre:
+                torch.rand(pre)
+            want = torch.rand(n)
+            tail = (torch.randn(5), torch.rand(7))
+            torch.manual_seed(1000 + n)
+            if pre:
+                torch.rand(pre)
+            got = _hostrng.rand_into(torch.empty(n))
+            tail2 = (torch.randn(5), torch.rand(7))
+            assert torch.equal(got, want), (n, pre)
+            assert torch.equal(tail[0], tail2[0]) and torch.equal(tail[1], tail2[1]), (n, pre)
