@@ -209,8 +209,22 @@ struct Ray {
 // Outside the normal range (|values| below 2^-125: a denormal product) the two forms can round differently;
 // no traced ray gets there (positions are sums of O(1)-mm terms: 0 or >= 1e-7 mm), and the parity tests
 // run both policies against the oracle.
+//   newton_step(ft, b)    : clamp(ft / b, -5, 5) (surfaces.py:557-559).  torch.clamp passes a NaN through; one
+//        v_med3_f32 returns a bound for it.  With finite rays the quotient is NaN only when b = dfdt + 1e-9 is
+//        exactly 0 -- where the reference divides to +-inf and steps by +-5, and Lean::div (which trades the
+//        inf for a NaN, see below) is not the reference anyway.  A ray that ENTERS a surface with a NaN
+//        position keeps a NaN t whatever the step is (t0 is NaN).  So under Lean the NaN is not put back:
+//        two vector instructions (v_cmp_u, v_cndmask) less per sag evaluation; Ieee puts it back.
+//   keep_if(ra, v)         : ra * (v ? 1 : 0) = v ? ra : 0 for every finite weight.
 struct Ieee {
     static constexpr bool kFused = false;
+    static __device__ __forceinline__ float newton_step(float ft, float b)
+    {
+        const float q = ft / b;
+        const float m = __builtin_amdgcn_fmed3f(q, -kNewtonStepBound, kNewtonStepBound);
+        return q != q ? q : m;
+    }
+    static __device__ __forceinline__ float keep_if(float ra, bool v) { return ra * (v ? 1.0f : 0.0f); }
     static __device__ __forceinline__ float dfdt(float dgd, float y, float dz) { return dgd * (2.0f * y) - dz; }
     static __device__ __forceinline__ float add_half_quot(float s, float a, float b) { return s + (a * 0.5f) / b; }
     static __device__ __forceinline__ float one_minus_flagged(float x, float f) { return 1.0f - x * f; }
@@ -224,6 +238,11 @@ struct Ieee {
 };
 struct Lean {
     static constexpr bool kFused = true;
+    static __device__ __forceinline__ float newton_step(float ft, float b)
+    {
+        return __builtin_amdgcn_fmed3f(div(ft, b), -kNewtonStepBound, kNewtonStepBound);
+    }
+    static __device__ __forceinline__ float keep_if(float ra, bool v) { return v ? ra : 0.0f; }
     static __device__ __forceinline__ float dfdt(float dgd, float y, float dz)
     {
         return __builtin_fmaf(2.0f, dgd * y, -dz);
@@ -316,15 +335,6 @@ __device__ __forceinline__ float clampf(float v, float lo, float hi)
 __device__ __forceinline__ float clamp_finite(float v, float lo, float hi)
 {
     return __builtin_amdgcn_fmed3f(v, lo, hi);
-}
-
-// torch.clamp(v, -b, b) in three instructions: v_med3_f32 (returns a bound for a NaN input),
-// then the NaN put back -- a NaN must stay a NaN: it fails the `|f| > tol` test of the next trip
-// exactly as it does in the reference
-__device__ __forceinline__ float clamp_sym(float v, float b)
-{
-    const float m = __builtin_amdgcn_fmed3f(v, -b, b);
-    return v != v ? v : m;
 }
 
 // torch.nn.functional.normalize over a last dim of 3 (basics.py:245,
@@ -465,7 +475,7 @@ __device__ __forceinline__ bool newton_k(const S& s, const P& pol, const Ray& r,
         const float ft = (g + k.d) - nz;
         const float dfdt = M::dfdt(dgd, dd * t + dox, r.dz);            // dgd * dr2dt - dz, dr2dt = 2((dx^2+dy^2) t + (dx ox + dy oy))
         const unsigned long long open = __ballot(__builtin_fabsf(ft) > tol_loose);
-        const float tn = t - clamp_sym(M::div(ft, dfdt + eps), kNewtonStepBound);
+        const float tn = t - M::newton_step(ft, dfdt + eps);
         uint32_t tmp;
         if (decltype(periodic_exit)::value) {
             open_prev = open_cur;
@@ -528,7 +538,7 @@ __device__ __forceinline__ bool newton_k(const S& s, const P& pol, const Ray& r,
     sag_g_dgd<M, KGT, CV, UNITK>(k, pol, deg, r2, g, dgd);
     const float ft = (g + k.d) - nz;
     const float dfdt = M::dfdt(dgd, dd * t + dox, r.dz);
-    t = t - clamp_sym(M::div(ft, dfdt + eps), kNewtonStepBound);
+    t = t - M::newton_step(ft, dfdt + eps);
     nx = r.ox + r.dx * t;
     ny = r.oy + r.dy * t;
     rr = nx * nx + ny * ny;
@@ -622,7 +632,7 @@ __device__ __forceinline__ uint32_t curved_reaction(const S& s, const P& pol, Ra
         v = vn;                                                                           // :495
     }
     r.ox = v ? nx : r.ox; r.oy = v ? ny : r.oy; r.oz = v ? nz : r.oz;
-    r.ra = r.ra * (v ? 1.0f : 0.0f);
+    r.ra = M::keep_if(r.ra, v);
     refract<FWD, M>(s, pol, r);
     return mask;
 }
@@ -638,7 +648,7 @@ __device__ __forceinline__ uint32_t surface_reaction(const S& s, const DevSurfac
         const float nx = r.ox + t * r.dx, ny = r.oy + t * r.dy, nz = r.oz + t * r.dz;
         const bool v = M::sqrt(nx * nx + ny * ny) <= s.r_lim() && r.ra > 0.0f;
         r.ox = v ? nx : r.ox; r.oy = v ? ny : r.oy; r.oz = v ? nz : r.oz;
-        r.ra = r.ra * (v ? 1.0f : 0.0f);
+        r.ra = M::keep_if(r.ra, v);
         between();
         if (s.do_refract()) refract<FWD, M>(s, NoPoly{}, r);
         return 0;
