@@ -587,6 +587,9 @@ class Lensgroup:
         key = (n, torch.cuda.current_stream(self.device).cuda_stream)
         pool = pools.get(key)
         if pool is None or pool["next"] >= rows:
+            pools.pop(key, None)
+            while len(pools) >= 8:                     # a caller sweeping over many shapes: keep the newest pools only
+                pools.pop(next(iter(pools)))
             pool = pools[key] = {"next": 0,
                                  "buf": torch.zeros((rows, n), dtype=torch.int32, device=self.device)}
         row = pool["buf"][pool["next"]]
