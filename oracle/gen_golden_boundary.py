@@ -80,6 +80,18 @@ def rgb_uncentred(rf50):
                 wvlns=np.asarray(gg.WAVE_RGB, np.float64))
 
 
+def mtf_case(rf50):
+    """F23 = Lensgroup.psf2mtf (optics.py:1043-1080), the FFT consumer of a PSF behind draw_mtf: a seeded
+    31x31 kernel -> (freq, tangential, sagittal)."""
+    g = torch.Generator().manual_seed(23)
+    yy, xx = torch.meshgrid(torch.arange(31.0), torch.arange(31.0), indexing="ij")
+    psf = torch.exp(-((xx - 15.3) ** 2 / 18 + (yy - 14.6) ** 2 / 7)) + 0.02 * torch.rand(31, 31, generator=g)
+    psf = psf / psf.max()
+    freq, tan, sag = rf50.psf2mtf(psf)
+    return dict(psf=psf.numpy(), freq=np.asarray(freq), tangential=np.asarray(tan), sagittal=np.asarray(sag),
+                pixel_size=np.float64(rf50.pixel_size))
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(HERE, "..", "tests", "golden"))
@@ -87,3 +99,4 @@ if __name__ == "__main__":
     rf50 = gg.build_lens("rf50mm")
     gg.save(out, "f21_rf50_recorded_paths", gg.twice(lambda: recorded(rf50)))
     gg.save(out, "f22_rf50_rgb_uncentred", gg.twice(lambda: rgb_uncentred(rf50)))
+    gg.save(out, "f23_psf2mtf", gg.twice(lambda: mtf_case(rf50)))

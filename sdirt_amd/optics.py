@@ -1198,6 +1198,18 @@ class Lensgroup:
         tiles = self.psf_rgb(points=field, ks=ks, center=center, spp=spp)        # [grid^2, 3, ks, ks]
         return tiles.view(grid, grid, 3, ks, ks).permute(2, 0, 3, 1, 4).reshape(3, grid * ks, grid * ks)
 
+    def psf2mtf(self, psf, diag=False):
+        """optics.py:1043-1080: the modulation transfer along the two axes of a PSF kernel -- |FFT| of its
+        centre row (sagittal) and centre column (tangential), each normalised to its maximum, at the
+        positive frequencies [cycles/mm] of a pixel_size sampling.  -> (freq, tangential, sagittal), numpy."""
+        k = psf.detach().cpu().numpy() if torch.is_tensor(psf) else np.asarray(psf)
+        row, col = k[k.shape[0] // 2, :], k[:, k.shape[1] // 2]
+        sagittal, tangential = np.abs(np.fft.fft(row)), np.abs(np.fft.fft(col))
+        sagittal, tangential = sagittal / sagittal.max(), tangential / tangential.max()
+        freq = np.fft.fftfreq(k.shape[0], self.pixel_size)
+        keep = freq > 0
+        return freq[keep], tangential[keep], sagittal[keep]
+
     # ------------------------------------------------------- geometrical optics
     def calc_scale_pinhole(self, depth):
         """optics.py:1302-1306."""

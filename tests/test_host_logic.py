@@ -380,3 +380,15 @@ def test_fast_host_random_stream_is_torch_rand():
             tail2 = (torch.randn(5), torch.rand(7))
             assert torch.equal(got, want), (n, pre)
             assert torch.equal(tail[0], tail2[0]) and torch.equal(tail[1], tail2[1]), (n, pre)
+
+
+def test_psf2mtf_matches_the_reference():
+    """Lensgroup.psf2mtf (optics.py:1043-1080, the FFT consumer behind draw_mtf), fixture F23."""
+    from conftest import load_golden, make_lens
+    g = load_golden("f23_psf2mtf")
+    lens = make_lens("rf50mm", "cpu")
+    assert lens.pixel_size == float(g["pixel_size"])
+    freq, tan, sag = lens.psf2mtf(g["psf"])
+    assert np.array_equal(freq, g["freq"])
+    np.testing.assert_allclose(tan, g["tangential"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(sag, g["sagittal"], rtol=1e-6, atol=1e-7)
