@@ -674,15 +674,30 @@ __device__ __forceinline__ float seg(float u)   // u - 1/2*sin(2u), monte_carlo.
     return u - 0.5f * __ocml_sin_f32(2.0f * u);
 }
 
-// seg(acos(z)) = acos(z) - z*sqrt(1-z^2), the area function of monte_carlo.py:179-183
-// with sin(2 acos z) = 2 z sqrt(1-z^2) applied.  (1-z)(1+z) instead of 1-z*z keeps the
-// root accurate next to the clamped ends z = +-1 (where it is exactly 0).  The result
-// differs from "sin(2*acos)" evaluated in fp32 by a few 1e-8 absolute -- less than the
-// reference's own MKL sin/acos differ from libm -- and it only scales splat WEIGHTS.
+// seg(acos(z)) = acos(z) - z*sqrt(1-z^2), the segment-area function of monte_carlo.py:179-183 (u - sin(2u)/2 at
+// u = acos z), for a clamped z in [-1, 1].  Evaluated as ONE function instead of acos + sqrt + product +
+// difference: S(z) = (1 - z)^(3/2) G(z) on [0, 1] with G analytic (degree-7 polynomial in u = 2z - 1, fit error
+// 4e-9), S(-z) = pi - S(z).  No cancellation next to the clamped ends (S -> 0 there, exactly 0 / pi at z = +-1);
+// absolute error <= 3.1e-7 over [0, 1] (2e6 points, against float64), relative error <= 2.7e-7 -- the fp32
+// "acos(z) - z sqrt((1-z)(1+z))" of rounds 1-2 had 1.4e-7 absolute and an unbounded relative error, the reference's
+// own "u - 0.5 sin(2u)" on MKL acos/sin is of the same order.  It only scales splat WEIGHTS (not bit-pinned:
+// DESIGN.md §4): 14 + v_sqrt instructions instead of 23 + two transcendentals, six times per splatted ray.
 __device__ __forceinline__ float seg_acos(float z)
 {
-    const float root = __builtin_amdgcn_sqrtf((1.0f - z) * (1.0f + z));
-    return __ocml_acos_f32(z) - z * root;
+    const float az = __builtin_fabsf(z);
+    const float u = __builtin_fmaf(2.0f, az, -1.0f);
+    const float t = 1.0f - az;
+    const float w = t * __builtin_amdgcn_sqrtf(t);
+    float g = 1.992103051e-06f;
+    g = __builtin_fmaf(g, u, -8.485991006e-06f);
+    g = __builtin_fmaf(g, u, 3.521309908e-05f);
+    g = __builtin_fmaf(g, u, -1.819916826e-04f);
+    g = __builtin_fmaf(g, u, 1.097788541e-03f);
+    g = __builtin_fmaf(g, u, -8.779404592e-03f);
+    g = __builtin_fmaf(g, u, 1.562758839e-01f);
+    g = __builtin_fmaf(g, u, 1.737177091e+00f);
+    const float sp = w * g;
+    return z < 0.0f ? (float)3.141592653589793 - sp : sp;
 }
 
 // x / r for the microlens radius: exact multiply when r is a power of two (default 0.5)
