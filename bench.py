@@ -62,14 +62,14 @@ EXTRA_WORKLOADS = ("f1", "tcp")
 
 
 def source_hash():
-    """Hash of the kernel sources the loaded library was built from (csrc/*.hip, *.hpp, the ABI header):
+    """Hash of what the loaded library was built from (csrc/*.hip, *.hpp, the Makefile with its flags, the ABI header):
     carried PMC counters name the hash they were collected on; a mismatch is reported as `stale`."""
     import glob
     import hashlib
     h = hashlib.sha256()
     files = sorted(glob.glob(os.path.join(ROOT, "sdirt_amd", "csrc", "*.hip")) +
                    glob.glob(os.path.join(ROOT, "sdirt_amd", "csrc", "*.hpp")) +
-                   [os.path.join(ROOT, "include", "sdirt_dp.h")])
+                   [os.path.join(ROOT, "include", "sdirt_dp.h"), os.path.join(ROOT, "sdirt_amd", "csrc", "Makefile")])
     for f in files:
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())
