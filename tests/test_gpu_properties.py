@@ -713,3 +713,28 @@ def test_long_streak_of_right_bets_skips_the_correction_round_and_recovers():
     assert ln.trips.relaunches == r0 + 1 and ln.__dict__["_right_streak"] == 0
     assert np.array_equal(ln.trips.cache[key], good[key])
     assert float((L0 - L1).abs().max()) <= 3e-6 and float((R0 - R1).abs().max()) <= 3e-6
+
+
+@pytest.mark.parametrize("n,spp,ks", [(1, 1025, 17), (1, 20000, 65), (7, 4096, 21), (64, 2049, 101), (513, 3000, 21),
+                                      (1023, 1100, 17), (200, 8192, 65)])
+def test_split_path_shapes_agree_with_the_host_verified_path(n, spp, ks):
+    """Every shape that takes several workgroups per point (sdirt_psf_spp_slices > 1) -- odd sample counts,
+    one point, 1023 points, tiles beyond 48 KB of LDS -- through the one-call device-verified path and through
+    the host-verified path of round 2: same PSFs, centres, trip tables."""
+    from sdirt_amd import _lib
+    assert _lib.lib().sdirt_psf_spp_slices(n, spp) > 1
+    g = torch.Generator().manual_seed(n * 7 + spp)
+    pts = torch.stack([(torch.rand(n, generator=g) - 0.5) * 1.9, (torch.rand(n, generator=g) - 0.5) * 1.9,
+                       -(200 + torch.rand(n, generator=g) * 19800)], -1)
+    a, b = make_lens("rf50mm", DEV), make_lens("rf50mm", DEV)
+    b.mask_reduce = lambda m: m                                   # host-verified path
+    ca, cb = torch.empty((n, 2), device=DEV), torch.empty((n, 2), device=DEV)
+    torch.manual_seed(5)
+    La, Ra = a.psf_lr(pts, ks=ks, spp=spp, dp=DP, center_out=ca)
+    torch.manual_seed(5)
+    Lb, Rb = b.psf_lr(pts, ks=ks, spp=spp, dp=DP, center_out=cb)
+    assert torch.equal(ca, cb) or float((ca - cb).abs().max()) < 1e-6
+    assert float((La - Lb).abs().max()) <= 4e-6 and float((Ra - Rb).abs().max()) <= 4e-6
+    for k in (("psf", 0.589, "lean"), ("center", "lean")):
+        assert np.array_equal(a.trips.cache[k], b.trips.cache[k])
+    assert float(La.amax((1, 2)).min()) > 0.99 and torch.isfinite(Ra).all()
