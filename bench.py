@@ -588,6 +588,14 @@ def main():
                          "kernel": "k_psf_lr<R,small-r,Lean,CENTER> (chief-ray pass + primary pass "
                                    "of a point in one workgroup)",
                          "algorithmic_bytes_per_launch": alg_bytes, "valu_issue": valu,
+                         # the committed rocprofv3 --kernel-trace --stats of this command (carried, like the
+                         # counters): its median and its average without the two table-discovery launches a
+                         # process starts with are the figures kernels_ms has to agree with
+                         "rocprof_kernel_trace": None if not counters else {
+                             "file": counters["file"], "stale": bool(counters["stale"]),
+                             "median_ms": (counters.get("kernel_trace_median_us") or 0) / 1e3 or None,
+                             "avg_steady_ms": (counters.get("kernel_trace_avg_steady_us") or 0) / 1e3 or None,
+                             "avg_all_launches_ms": (counters.get("kernel_trace_avg_us") or 0) / 1e3 or None},
                          "note": "scalar-per-ray fp32 math: the kernel is bound by vector-instruction "
                                  "issue by construction (%s VALU instr per traced ray vs %.2f "
                                  "algorithmic bytes), DESIGN.md §3"

@@ -32,6 +32,9 @@ d = {"workload": wl, "commit": commit, "source_hash": bench.source_hash(), "coll
      "command": f"rocprofv3 --pmc <group> -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --workload {wl}",
      "kernel": "k_psf_lr<R, small-r, Lean, CENTER> (last dispatch of each pass)",
      "kernel_trace_median_us": t["median_us"], "kernel_trace_avg_us": t["avg_us"], "kernel_trace_calls": t["calls"],
+     # the first two launches of a process run the cold 10-trip table and the table it reveals (trip-table discovery):
+     # the steady-state average leaves them out
+     "kernel_trace_avg_steady_us": sum(t["per_dispatch_us"][2:]) / max(1, len(t["per_dispatch_us"][2:])),
      # HBM traffic as MI355X_MICROARCH.md prescribes: FETCH_SIZE / WRITE_SIZE are in KB, separate
      # passes, gfx950 reports half of the read bytes
      "FETCH_SIZE_KB": v("FETCH_SIZE"), "WRITE_SIZE_KB": v("WRITE_SIZE"),
