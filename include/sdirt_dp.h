@@ -39,6 +39,8 @@ extern "C" {
 #define SDIRT_NEWTON_MAXITER 10 /* deeplens/surfaces.py:26 */
 #define SDIRT_MAX_WAVELENGTHS 3 /* wavelength slots of one fused launch (psf_rgb) */
 #define SDIRT_MAX_KS 141        /* two ks*ks fp32 tiles + 1 KiB of bookkeeping fit in 160 KiB of LDS */
+#define SDIRT_MAX_KS_STAGED 1024 /* sdirt_forward_integral adds into the grids in HBM: no LDS bound (the reference's
+                                   draw_mtf asks for ks 256, optics.py:2056) */
 
 typedef enum sdirt_status {
     SDIRT_OK = 0,
@@ -197,7 +199,9 @@ int sdirt_center_from_rays(sdirt_rays rays, int64_t spp, int64_t n_points,
 /* forward_integral + assign_points_to_pixels_small_r / _big_r,
  * deeplens/monte_carlo.py:9-68, 135-240, 242-372: sensor-plane rays -> RAW left
  * and right grids [N,ks,ks] (fully overwritten).  r_grid may be NULL.
- * ps = pixel size; center = pointc_ref [N,2]. */
+ * ps = pixel size; center = pointc_ref [N,2].  ks up to SDIRT_MAX_KS_STAGED (the fused sdirt_psf_* entries
+ * keep a point's grids in LDS and stop at SDIRT_MAX_KS; the staged chain sample -> trace -> chief centre ->
+ * forward_integral -> normalize is the path for larger grids). */
 int sdirt_forward_integral(sdirt_rays rays, int64_t spp, int64_t n_points, double ps, int32_t ks,
                            const float* center /*dev [N,2]*/, const sdirt_dp_params* dp /*host*/,
                            float* l_grid /*dev [N,ks,ks]*/, float* r_grid /*dev or NULL*/,

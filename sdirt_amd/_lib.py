@@ -15,6 +15,7 @@ MAX_SURFACES = 64
 MAX_AI = 8
 NEWTON_MAXITER = 10
 MAX_KS = 141
+MAX_KS_STAGED = 1024
 MAX_WAVELENGTHS = 3
 PSF_NORMALIZE = 1
 PSF_STRICT_IEEE = 4

@@ -93,9 +93,9 @@ inline int check_rays(const sdirt_rays& R)
     return SDIRT_OK;
 }
 
-inline int check_ks(int ks)
+inline int check_ks(int ks, int max_ks = SDIRT_MAX_KS)
 {
-    if (ks < 2 || ks > SDIRT_MAX_KS)
-        return fail(SDIRT_ERR_INVALID_ARGUMENT, "ks=%d outside [2,%d]", ks, SDIRT_MAX_KS);
+    if (ks < 2 || ks > max_ks)
+        return fail(SDIRT_ERR_INVALID_ARGUMENT, "ks=%d outside [2,%d]", ks, max_ks);
     return SDIRT_OK;
 }

@@ -531,7 +531,7 @@ int sdirt_forward_integral(sdirt_rays rays, int64_t S, int64_t N, double ps, int
                            float* r_grid, void* stream)
 {
     if (int rc = check_rays(rays)) return rc;
-    if (int rc = check_ks(ks)) return rc;
+    if (int rc = check_ks(ks, SDIRT_MAX_KS_STAGED)) return rc;
     if (!center || !l_grid || S < 0 || N < 0) return fail(SDIRT_ERR_INVALID_ARGUMENT, "bad argument");
     if (dp && !(dp->r > 0.0)) return fail(SDIRT_ERR_INVALID_ARGUMENT, "dp->r must be > 0");
     if (N == 0) return SDIRT_OK;

@@ -725,6 +725,12 @@ class Lensgroup:
         # RNG order of the reference: primary pupil samples first (optics.py:963),
         # then the chief-ray samples inside psf_center (optics.py:969).
         pupilz, pupilr = self.entrance_pupil()
+        if ks > _lib.MAX_KS:
+            # a point's two grids no longer fit in LDS (draw_mtf: ks 256): the staged chain
+            if defer:
+                raise ValueError(f"defer=True needs ks <= {_lib.MAX_KS}")
+            return self._psf_lr_staged(points, po, N, ks, wvln, spp, center, dp, normalize, want_r,
+                                       _default_r_zero, pupil_xy, center_pupil_xy, out, center_out, single_point)
         if (center and not defer and pupil_xy is None and center_pupil_xy is None and N > 0
                 and self.trip_policy == "reference" and self.mask_reduce is None and self.pupil_mapping == "device"
                 and self.kernel_events is None and _lib.lib().sdirt_psf_spp_slices(N, spp) > 1):
@@ -948,6 +954,72 @@ class Lensgroup:
             R = R.squeeze(0) if R is not None else None
         return L, R
 
+    def _psf_lr_staged(self, points, po, N, ks, wvln, spp, center, dp, normalize, want_r, default_r_zero,
+                       pupil_xy, center_pupil_xy, out, center_out, single_point):
+        """psf_lr for SDIRT_MAX_KS < ks <= SDIRT_MAX_KS_STAGED: the reference's own sequence of optics.py:962-987
+        as five library calls -- sample_from_points, psf_center, trace2sensor, forward_integral (adds into the
+        grids in HBM instead of LDS), normalise -- on [spp, N] rays held in HBM (32 bytes per ray).  Same rays,
+        centres and trip tables as the fused kernel; the plots that ask for such grids (draw_mtf) trace a
+        handful of points."""
+        if not 2 <= ks <= _lib.MAX_KS_STAGED:
+            raise _lib.SdirtError(f"ks={ks} outside [2,{_lib.MAX_KS_STAGED}]")
+        pupilz, pupilr = self.entrance_pupil()
+        if pupil_xy is None:
+            x2, y2 = self._pupil_samples(spp, pupilr)                       # optics.py:963 (first two draws)
+        else:
+            x2, y2 = [torch.as_tensor(v).to(self.device, torch.float32).contiguous() for v in pupil_xy]
+            spp = x2.shape[0]
+        ray = Ray.empty((spp, N), wvln, self.device)
+        _lib.check(_lib.lib().sdirt_sample_rays(dptr(po), N, dptr(x2), dptr(y2), spp, float(pupilz), ray.c_rays(),
+                                                stream_ptr(self.device)))
+        if center_out is not None:
+            if not (center_out.is_cuda and center_out.dtype == torch.float32 and center_out.is_contiguous()
+                    and tuple(center_out.shape) == (N, 2)):
+                raise ValueError("center_out must be a contiguous float32 CUDA [N, 2] tensor")
+            cen = center_out
+        else:
+            cen = torch.empty((N, 2), dtype=torch.float32, device=self.device)
+        xc = yc = None
+        if center:
+            pupilz_c, pupilr_c = self.entrance_pupil(shrink_pupil=True)
+            if center_pupil_xy is None:
+                xc, yc = self._pupil_samples(GEO_SPP, pupilr_c)             # optics.py:969 (draws three and four)
+            else:
+                xc, yc = [torch.as_tensor(v).to(self.device, torch.float32).contiguous() for v in center_pupil_xy]
+            self._chief_center(po, xc, yc, pupilz_c, cen)
+        else:
+            pts = points.to(self.device, torch.float32)
+            cen[:, 0] = pts[:, 0] * (self.sensor_size[1] / 2)               # optics.py:973-975
+            cen[:, 1] = pts[:, 1] * (self.sensor_size[0] / 2)
+        self.last_pupil_points = (x2, y2, xc, yc)
+        self.trace(ray, forward=True)
+        ray.propagate_to(self.d_sensor)
+        need_r = want_r and not default_r_zero
+        if out is not None:
+            L, R = out[0], (out[1] if need_r else None)
+            for t_ in (L, R):
+                if t_ is not None and not (t_.is_cuda and t_.dtype == torch.float32 and t_.is_contiguous()
+                                           and tuple(t_.shape) == (N, ks, ks)):
+                    raise ValueError("out tensors must be contiguous float32 CUDA [N, ks, ks]")
+        else:
+            L = torch.empty((N, ks, ks), dtype=torch.float32, device=self.device)
+            R = torch.empty_like(L) if need_r else None
+        dpp = None if (dp is None or default_r_zero) else _lib.DpParams(*[float(v) for v in dp])
+        h, st = _lib.lib(), stream_ptr(self.device)
+        with self._timed("forward_integral"):
+            _lib.check(h.sdirt_forward_integral(ray.c_rays(), spp, N, float(self.pixel_size), int(ks), dptr(cen),
+                                                C.byref(dpp) if dpp is not None else None, dptr(L), dptr(R), st))
+        if normalize:
+            for g in (L, R):
+                if g is not None:
+                    _lib.check(h.sdirt_psf_normalize(dptr(g), N, int(ks), st))
+        if R is None and want_r:
+            R = torch.zeros_like(L)
+        if single_point:
+            L = L.squeeze(0)
+            R = R.squeeze(0) if R is not None else None
+        return L, R
+
     def _psf_call_one(self, points, po, N, ks, wvln, spp, dp, normalize, want_r, default_r_zero, out, center_out,
                       single_point):
         """psf_lr(center=True) for sdirt_psf_spp_slices(N, spp) > 1, synchronous form, through sdirt_psf_call:
@@ -1056,7 +1128,7 @@ class Lensgroup:
         if not torch.is_tensor(points):
             points = torch.tensor(points)
         n_points = points.shape[0] if points.dim() == 2 else 1
-        fused = n_points > 0 and self.device.type == "cuda" and self.mask_reduce is None
+        fused = n_points > 0 and self.device.type == "cuda" and self.mask_reduce is None and ks <= _lib.MAX_KS
         if fused and center:
             return self._psf_rgb_fused(points, ks, spp, param_list, pupil_xy, center_pupil_xy)
         if fused:
@@ -1209,6 +1281,22 @@ class Lensgroup:
         freq = np.fft.fftfreq(k.shape[0], self.pixel_size)
         keep = freq > 0
         return freq[keep], tangential[keep], sagittal[keep]
+
+    # the reference's plotting callers of the path (sdirt_amd/plots.py); each also returns what it drew
+    def draw_psf_map(self, grid=9, depth=DEPTH, ks=51, log_scale=False, quater=False, save_name=None):
+        """optics.py:1884-1931."""
+        from . import plots
+        return plots.draw_psf_map(self, grid, depth, ks, log_scale, quater, save_name)
+
+    def draw_psf_radial(self, M=3, depth=DEPTH, ks=51, log_scale=False, save_name="./psf_radial.png"):
+        """optics.py:1934-1956."""
+        from . import plots
+        return plots.draw_psf_radial(self, M, depth, ks, log_scale, save_name)
+
+    def draw_mtf(self, relative_fov=[0.0, 0.7, 1.0], save_name="./mtf.png", wvlns=DEFAULT_WAVE, depth=DEPTH):
+        """optics.py:2041-2067 (psf_diff at ks 256: the staged chain, _psf_lr_staged)."""
+        from . import plots
+        return plots.draw_mtf(self, relative_fov, save_name, wvlns, depth)
 
     # ------------------------------------------------------- geometrical optics
     def calc_scale_pinhole(self, depth):

@@ -193,6 +193,18 @@ def test_library_exports_every_declared_symbol():
     assert exported == syms, exported ^ syms
 
 
+def test_python_constants_match_the_c_header():
+    """Every numeric SDIRT_* macro the binding mirrors has the header's value."""
+    from sdirt_amd import _lib
+    txt = open(os.path.join(ROOT, "include", "sdirt_dp.h")).read()
+    macros = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define\s+SDIRT_([A-Z0-9_]+)\s+(-?\d+)u?\b", txt)}
+    mirrored = {k: v for k, v in macros.items() if hasattr(_lib, k)}
+    assert {"MAX_SURFACES", "MAX_KS", "MAX_KS_STAGED", "PSF_NORMALIZE", "PSF_ONE_ROUND", "CTL_WORDS",
+            "TRACE_NO_PREFETCH", "NEWTON_MAXITER", "MAX_WAVELENGTHS"} <= set(mirrored)
+    for k, v in mirrored.items():
+        assert getattr(_lib, k) == v, (k, v, getattr(_lib, k))
+
+
 def test_ctypes_structs_match_the_c_header(tmp_path):
     """Compile include/sdirt_dp.h as plain C and compare struct layouts with the ctypes mirror."""
     import subprocess

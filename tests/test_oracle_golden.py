@@ -269,3 +269,58 @@ def test_rms_centre_branch(oracle):
     lg, rg = oracle.forward_integral(g["o"], g["d"], g["ra"], float(g["ps"]), int(g["ks"]), cen, dp=DP)
     assert np.abs(lg - g["grid_l_l"]).max() <= 2e-5 * g["grid_l_l"].max()
     assert np.abs(rg - g["grid_r_l"]).max() <= 2e-5 * g["grid_r_l"].max()
+
+
+def _mtf(psf, pixel_size):
+    """psf2mtf (optics.py:1043-1080) restated: |FFT| of the centre row / column, normalised, positive frequencies."""
+    row, col = psf[psf.shape[0] // 2, :], psf[:, psf.shape[1] // 2]
+    sag, tan = np.abs(np.fft.fft(row)), np.abs(np.fft.fft(col))
+    freq = np.fft.fftfreq(psf.shape[0], pixel_size)
+    keep = freq > 0
+    return freq[keep], (tan / tan.max())[keep], (sag / sag.max())[keep]
+
+
+def test_draw_mtf_grids_of_256(oracle):
+    """F24: the reference's draw_mtf run as it stands (optics.py:2041-2067): three psf_diff(ks=256) calls and
+    their MTF curves.  Oracle on the recorded pupil sets vs the reference's PSFs, trip tables and curves."""
+    st, g = load_state("rf50mm"), load_golden("f24_rf50_draw_mtf")
+    for i, fov in enumerate(g["relative_fov"]):
+        pt = np.asarray([[fov, fov, g["depth"]]], np.float32)
+        lo, _, co, ok, tp, tc = oracle.psf(st, pt, g["pupil_x"][i], g["pupil_y"][i], g["pupil_xc"][i],
+                                           g["pupil_yc"][i], 256, return_trips=True)
+        assert ok and lo.shape == (1, 256, 256)
+        assert np.array_equal(tp, g["trips"][i]) and np.array_equal(tc, g["trips_center"][i])
+        assert np.abs(co[0] - g["center"][i]).max() < 4e-6
+        assert np.abs(lo[0] - g["psf"][i]).max() <= 6e-5
+        # the reference's curves from the reference's PSF: the restated FFT consumer is exact ...
+        f, t, s = _mtf(g["psf"][i], float(g["pixel_size"]))
+        assert np.array_equal(f, g["freq"][i])
+        assert np.allclose(t, g["tangential"][i], rtol=0, atol=1e-12) and np.allclose(s, g["sagittal"][i], rtol=0, atol=1e-12)
+        # ... and the curves of the oracle's PSF are the plot's curves
+        f, t, s = _mtf(lo[0], float(g["pixel_size"]))
+        assert np.abs(t - g["tangential"][i]).max() < 2e-4 and np.abs(s - g["sagittal"][i]).max() < 2e-4
+
+
+def test_draw_psf_radial_fields(oracle):
+    """F25: the list draw_psf_radial (optics.py:1934-1956) hands to make_grid: psf_rgb at three fields on the
+    45-degree diagonal, divided by the maximum over the three colours (and its log-scaled form)."""
+    st, g = load_state("rf50mm"), load_golden("f25_rf50_draw_psf_radial")
+    xs = np.linspace(0, 1, 3).astype(np.float32)
+    for i in range(3):
+        pt = np.asarray([[xs[i], xs[i], g["depth"]]], np.float32)
+        rgb = []
+        for w, wv in enumerate([0.656, 0.589, 0.486]):
+            lo, _, _, ok = oracle.psf(st, pt, g["pupil"][i, w, 0], g["pupil"][i, w, 1], g["pupil_c"][i, w, 0],
+                                      g["pupil_c"][i, w, 1], 51, wvln=wv)
+            assert ok
+            rgb.append(lo[0])
+        rgb = np.stack(rgb)
+        rgb = rgb / rgb.max()
+        assert np.abs(rgb - g["psfs"][i]).max() <= 1e-4          # 4096 rays, the corner field spread over few pixels
+        assert np.median(np.abs(rgb - g["psfs"][i])[g["psfs"][i] > 1e-3]) <= 1e-5
+        lg = np.log(rgb + np.float32(1e-9))
+        lg = (lg - lg.min()) / (lg.max() - lg.min())
+        # log of a max-normalised PSF: compared where the PSF is not at the noise floor
+        lit = g["psfs"][i] > 1e-3
+        assert np.abs(lg - g["psfs_log"][i])[lit].max() < 2e-3
+        assert np.array_equal(lg == 0, g["psfs_log"][i] == 0)
