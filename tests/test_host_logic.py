@@ -404,3 +404,28 @@ def test_psf2mtf_matches_the_reference():
     assert np.array_equal(freq, g["freq"])
     np.testing.assert_allclose(tan, g["tangential"], rtol=1e-6, atol=1e-7)
     np.testing.assert_allclose(sag, g["sagittal"], rtol=1e-6, atol=1e-7)
+
+
+def test_plot_helpers_restate_make_grid_and_save_image(tmp_path):
+    """sdirt_amd/plots.py: tile_grid = torchvision make_grid for equal tiles (padding on the top / left of every
+    tile and once more at the bottom / right), save_normalised = save_image(normalize=True)."""
+    import matplotlib
+    matplotlib.use("Agg")
+    import matplotlib.pyplot as plt
+    from sdirt_amd import plots
+    g = torch.Generator().manual_seed(0)
+    tiles = [torch.rand(3, 5, 4, generator=g) for _ in range(5)]
+    img = plots.tile_grid(tiles, nrow=3, padding=1, pad_value=0.25)
+    assert img.shape == (3, 2 * 6 + 1, 3 * 5 + 1)
+    assert np.array_equal(img[:, 1:6, 1:5], tiles[0].numpy()) and np.array_equal(img[:, 7:12, 6:10], tiles[4].numpy())
+    assert np.all(img[:, 0] == 0.25) and np.all(img[:, 6] == 0.25) and np.all(img[:, :, 5] == 0.25)
+    assert np.all(img[:, 7:12, 11:15] == 0.25)                     # the empty sixth cell
+    one = plots.tile_grid(tiles[:2], nrow=8, padding=0)
+    assert one.shape == (3, 5, 8) and np.array_equal(one[:, :, 4:], tiles[1].numpy())
+    path = str(tmp_path / "t.png")
+    rgb = plots.save_normalised(img, path)
+    lo, hi = float(img.min()), float(img.max())
+    want = np.clip((img - lo) / (hi - lo + 1e-5) * 255 + 0.5, 0, 255).astype(np.uint8).transpose(1, 2, 0)
+    assert np.array_equal(rgb, want)
+    back = (plt.imread(path)[..., :3] * 255 + 0.5).astype(np.uint8)
+    assert np.array_equal(back, want)
