@@ -52,6 +52,8 @@ WORKLOADS = {
     "c3": dict(lens="rf50mm", ks=21, spp=8192, grid_z=64, sensor_z=62.25,
                desc="rf50mm dense PSFNet grid 32x32x{gz}, Gaussian-warped depth planes around the 1 m "
                     "focal plane (psfnet.py:229-232) (8 shards of 8192 points on a node)"),
+    "c3k65": dict(lens="rf50mm", ks=65, spp=8192, grid_z=64, sensor_z=62.25,
+                  desc="rf50mm dense PSFNet grid 32x32x{gz} as c3, 65x65 grids (config 3's second kernel size)"),
     "c4": dict(lens="rf35mm", ks=65, spp=4096, grid_z=16, sensor_z=80.447,
                desc="rf35mm (21 surfaces) 32x32x{gz} PSF volume"),
 }
@@ -86,10 +88,11 @@ def volume_points(world, workload="c2"):
     reference's Gaussian-warped spacing around the focal plane (psfnet.py:229-232,
     foc_z = foc_z_arr[1]) -- planes crowd around 1 m, where the PSF changes fastest."""
     g = GRID_XY
-    nz = (8 if workload == "c3" else WORKLOADS[workload]["grid_z"]) * world
+    dense = workload.startswith("c3")
+    nz = (8 if dense else WORKLOADS[workload]["grid_z"]) * world
     x, y = torch.meshgrid(torch.linspace(-1 + 1 / (2 * g), 1 - 1 / (2 * g), g),
                           torch.linspace(1 - 1 / (2 * g), -1 + 1 / (2 * g), g), indexing="xy")
-    if workload == "c3":
+    if dense:
         z_gauss = torch.linspace(-3, 3, nz)
         z = torch.zeros_like(z_gauss)
         z[z_gauss > 0] = (1 - FOC_Z_RF50) * z_gauss[z_gauss > 0] / 3 + FOC_Z_RF50
@@ -351,7 +354,7 @@ def main():
                          "ms_per_step_sustained (0 = skip); long enough for a 5-second GPU-activity "
                          "sampler to see the GPU phase of the run")
     ap.add_argument("--workload", choices=sorted(WORKLOADS) + list(EXTRA_WORKLOADS), default="c2",
-                    help="c2 (default, the headline) / c3 / c4: PSF-volume renders; f1: per-pixel DP-PSF "
+                    help="c2 (default, the headline) / c3 / c3k65 / c4: PSF-volume renders; f1: per-pixel DP-PSF "
                          "convolution of a 512x768 frame (render_psf.py:120-155); tcp: the reference's own "
                          "timing harness PSFNet.time_compare_psf (psfnet.py:570-586)")
     args = ap.parse_args()
@@ -364,7 +367,7 @@ def main():
     wl = WORKLOADS[args.workload]
     KS, SPP = wl["ks"], wl["spp"]
     # c3 is a 65536-point grid meant for 8 GPUs: per-GPU slab = 8 depth planes
-    GRID_Z = wl["grid_z"] if args.workload != "c3" else 8
+    GRID_Z = wl["grid_z"] if not args.workload.startswith("c3") else 8
 
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -22,10 +22,11 @@ CASES = {
     "c2": ("rf50mm", "c2", 65, 4096),       # 32x32x16 volume: 16384 points, 67.1 M primary rays
     "c4": ("rf35mm", "c4", 65, 4096),       # the same volume through the 21-surface lens
     "c3": ("rf50mm", "c3", 21, 8192),       # one GPU's share of the dense grid: 8192 points x 8192 spp
+    "c3k65": ("rf50mm", "c3k65", 65, 8192),  # the same share on 65x65 grids (config 3 names both kernel sizes)
 }
 
 
-@pytest.mark.parametrize("case", ["c2", "c4", "c3"])
+@pytest.mark.parametrize("case", ["c2", "c4", "c3", "c3k65"])
 def test_whole_batch_against_the_oracle(oracle, case):
     import bench
     lens_name, workload, ks, spp = CASES[case]
@@ -33,7 +34,7 @@ def test_whole_batch_against_the_oracle(oracle, case):
     lens = make_lens(lens_name, DEV, st)
     pts = bench.volume_points(1, workload)
     N = pts.shape[0]
-    assert N == (8192 if case == "c3" else 16384)
+    assert N == (8192 if case.startswith("c3") else 16384)
     g = torch.Generator().manual_seed(303)
     u = torch.rand(2, spp, generator=g).numpy()
     uc = torch.rand(2, 2048, generator=g).numpy()

@@ -144,9 +144,12 @@ def test_edge_cases(lens):
     for ks in (2, 8, 141):
         L, _ = lens.psf_lr(torch.tensor([[0.0, 0.0, -1000.0]]), ks=ks, spp=128, dp=DP)
         assert L.shape == (1, ks, ks) and torch.isfinite(L).all()
-    from sdirt_amd import SdirtError
+    # one pixel more no longer fits a workgroup's LDS: the staged chain takes over (tests/test_gpu_callers.py)
+    from sdirt_amd import SdirtError, _lib
+    big = lens.psf(torch.tensor([[0.0, 0.0, -1000.0]]), ks=142, spp=64)
+    assert big.shape == (1, 142, 142) and float(big.max()) > 0.99
     with pytest.raises(SdirtError):
-        lens.psf(torch.tensor([[0.0, 0.0, -1000.0]]), ks=142, spp=64)
+        lens.psf(torch.tensor([[0.0, 0.0, -1000.0]]), ks=_lib.MAX_KS_STAGED + 1, spp=64)
     # center=False uses the pinhole centre (optics.py:971-976)
     L = lens.psf(torch.tensor([[0.0, 0.0, -1000.0]]), ks=21, spp=256, center=False)
     assert L.shape == (1, 21, 21) and float(L.max()) > 0.99
