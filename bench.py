@@ -249,6 +249,14 @@ def pmc_counters(workload):
     return None
 
 
+def _issue_bound(n_valu, n_trans, simd_cycles):
+    if not n_trans:
+        return None
+    need = (n_valu - n_trans) * 2.25 + n_trans * 8.2
+    return {"plain_cycles": 2.25, "transcendental_cycles": 8.2, "transcendental_instructions_per_launch": n_trans,
+            "issue_cycles_needed": need, "simd_cycles_available": simd_cycles, "frac": need / simd_cycles}
+
+
 def _hip_ms(fn, steps, warmup, device):
     """steps calls of fn between two synchronisations -> (wall ms per call, mean HIP-event ms per call)."""
     for _ in range(warmup):
@@ -553,6 +561,11 @@ def main():
                         "plain_fp32_cycles_per_instruction": 2.25,
                         "achieved_per_s": n_instr / (k_ms[dom] * 1e-3), "peak_per_s": peak,
                         "frac": n_instr / (k_ms[dom] * 1e-3) / peak,
+                        # what THIS instruction stream can reach: measured issue costs per SIMD at 8 waves
+                        # (profiles/r02/form_bench.txt: v_fma / v_mul / v_add 2.25 cycles, v_rcp / v_rsq / v_sqrt
+                        # 8.2) x the counted instructions, over the SIMD cycles the launch had
+                        "issue_bound": _issue_bound(n_instr, counters.get("trans_f32_instructions_per_launch"),
+                                                    k_ms[dom] * 1e-3 * clk * 1e9 * 1024),
                         "stale": bool(counters["stale"]),
                         "source": {"kind": "carried: SQ_INSTS_VALU of a separate rocprofv3 --pmc run "
                                            "of this command, divided by THIS run's kernel time",
