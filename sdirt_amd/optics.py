@@ -122,6 +122,10 @@ class Lensgroup:
         #: where the uniform -> pupil-disc mapping runs: 'device' (default) or 'host' (the
         #: reference's own torch CPU expressions; see _pupil_samples)
         self.pupil_mapping = "device"
+        #: generator device of Lensgroup.sample_pupil (the per-source pupil samples of sample_point_source, analysis_rms,
+        #: calc_magnification3): None = the lens's device, as the reference draws them; 'cpu' = the CPU generator
+        #: (what a CPU run of the reference uses: seeds then reproduce its sample points)
+        self.sample_rng_device = None
         #: when a dict, kernel launches are bracketed with HIP events on the launch
         #: stream: {'psf_lr': [(start, end), ...], 'chief_center': [...]}  (bench.py)
         self.kernel_events = None
@@ -1298,6 +1302,14 @@ class Lensgroup:
         from . import plots
         return plots.draw_mtf(self, relative_fov, save_name, wvlns, depth)
 
+    # the lens report of the reference's fitting script and the samplers / measures under it (sdirt_amd/analysis.py)
+    def analysis(self, save_name="./test", ks=None, render=False, multi_plot=False, plot_invalid=True,
+                 zmx_format=False, depth=DEPTH, render_unwarp=False, lens_title=None):
+        """optics.py:1663-1684."""
+        from . import analysis as an
+        return an.analysis(self, save_name, ks, render, multi_plot, plot_invalid, zmx_format, depth, render_unwarp,
+                           lens_title)
+
     # ------------------------------------------------------- geometrical optics
     def calc_scale_pinhole(self, depth):
         """optics.py:1302-1306."""
@@ -1401,6 +1413,21 @@ class Lensgroup:
         avg_r = torch.abs((torch.mean(P[:, 0])) / delta_r * aper_r).item()
         avg_z = torch.mean(P[:, 1]).item()
         return avg_z, avg_r
+
+
+def _bind_analysis(name):
+    def method(self, *args, **kwargs):
+        from . import analysis as an
+        return getattr(an, name)(self, *args, **kwargs)
+    method.__name__ = name
+    method.__doc__ = f"sdirt_amd.analysis.{name} (the arguments of the reference's Lensgroup.{name})."
+    return method
+
+
+for _name in ("sample_parallel_2D", "sample_point_source_2D", "sample_pupil", "sample_point_source",
+              "calc_magnification3", "calc_scale_ray", "analysis_rms", "calc_eqfl", "plot_setup2D", "plot_raytraces",
+              "plot_setup2D_with_trace"):
+    setattr(Lensgroup, _name, _bind_analysis(_name))
 
 
 def intersect_lines_2d_lstsq_fp32(origins, directions):

@@ -128,7 +128,8 @@ class PSFNet(Lensgroup):
         """psfnet.py:101-168: fit the network to PSFs ray-traced on the fly.  AdamW, cosine
         schedule over iters//3, MSE on max-normalised kernels, fp16 autocast + loss scaling on
         the GPU.  Every `evaluate_every` steps: checkpoint + L1/L2 of sum-normalised kernels
-        on the 1024-point test set (logged; the reference also writes a matplotlib figure).
+        on the 1024-point test set (logged) and the figure of five target / prediction pairs of the
+        current batch (the prediction re-evaluated with the weights after the step).
         Returns the list of per-step training losses.
 
         pipelined (default: on for CUDA devices): the loop is launch-bound at the reference's
@@ -148,9 +149,20 @@ class PSFNet(Lensgroup):
         scaler = torch.amp.GradScaler("cuda", enabled=on_gpu)
         amp = lambda: torch.autocast("cuda", dtype=torch.float16, enabled=on_gpu)  # noqa: E731
 
-        def evaluate(i):
+        def evaluate(i, batch_inp, batch_psf):
             with torch.no_grad(), amp():
                 psfnet.eval()
+                # psfnet.py:131-146: five (target, prediction) pairs of the current batch
+                from .plots import _pyplot
+                plt = _pyplot()
+                shown = psfnet(batch_inp[:5]).float().cpu()
+                fig, axs = plt.subplots(5, 2)
+                for j in range(min(5, shown.shape[0])):
+                    axs[j, 0].imshow(batch_psf[j].float().cpu())
+                    axs[j, 1].imshow(shown[j])
+                fig.suptitle(f"GT/Pred PSFs at iter {i + 1}")
+                fig.savefig(os.path.join(result_dir, f"iter{i + 1}.png"), dpi=300)
+                plt.close(fig)
                 torch.save(psfnet.state_dict(),
                            os.path.join(result_dir, f"iter{i + 1}_PSFNet_{self.model_name}.pkl"))
                 inp, psf = self.get_test_data()
@@ -175,7 +187,7 @@ class PSFNet(Lensgroup):
                 sche.step()
                 losses.append(loss.detach())
                 if (i + 1) % evaluate_every == 0:
-                    evaluate(i)
+                    evaluate(i, inp, psf)
         else:
             main = torch.cuda.current_stream(self.device)
             side = torch.cuda.Stream(self.device)
@@ -247,7 +259,7 @@ class PSFNet(Lensgroup):
                 sche.step()
                 losses.append(static_loss.detach().clone())
                 if (i + 1) % evaluate_every == 0:
-                    evaluate(i)
+                    evaluate(i, static_inp, static_psf)
                     evals_done[0] += 1
                     refill()
         torch.save(psfnet.state_dict(), os.path.join(result_dir, f"PSFNet_{self.model_name}.pkl"))
@@ -419,9 +431,10 @@ class PSFNet(Lensgroup):
         assert psfl.shape == (24576, self.kernel_size, self.kernel_size) and psf2.shape[-3:] == (2, self.kernel_size, self.kernel_size)
         return t_trace, t_net
 
-    def compare_psf(self, spp=None):
-        """psfnet.py:529-568 without the figures: ray-traced vs predicted (L, R) kernels at three
-        field points and two depths -> {depth: (traced [3,2,ks,ks], predicted [3,2,ks,ks])}."""
+    def compare_psf(self, spp=None, save_dir=".", figures=True):
+        """psfnet.py:529-568: ray-traced vs predicted (L, R) kernels at three field points (0, 0.4, 0.8 of the
+        diagonal) and two depths, each pair written as `rt_<depth>_v0x.png` / `pred_<depth>_v0x.png` into
+        `save_dir` (the reference: the working directory) -> {depth: (traced [3,2,ks,ks], predicted [3,2,ks,ks])}."""
         from .basics import GEO_SPP
         spp = spp or GEO_SPP * 100
         x = torch.tensor([0, 0.4, 0.8])
@@ -435,5 +448,33 @@ class PSFNet(Lensgroup):
                               dims=[-1])
             z = self.depth2z(torch.tensor(depth))
             inp = torch.stack((x, x, torch.full_like(x, z)), dim=-1).to(self.device)
-            out[int(d_ori)] = (torch.stack((psfl, psfr), dim=1), self.pred(inp).detach())
+            traced, pred = torch.stack((psfl, psfr), dim=1), self.pred(inp).detach()
+            out[int(d_ori)] = (traced, pred)
+            if figures:
+                for j, tag in enumerate(("v00", "v04", "v08")):
+                    self.vis_psf_map(traced[j].cpu(), filename=os.path.join(save_dir, f"rt_{int(d_ori)}_{tag}.png"))
+                    self.vis_psf_map(pred[j].cpu(), filename=os.path.join(save_dir, f"pred_{int(d_ori)}_{tag}.png"))
         return out
+
+    def vis_psf_map(self, psf, filename=None, normal=True):
+        """psfnet.py:728-762: [N,k,k] kernels side by side in grey (each over its own maximum when `normal`), or a
+        [N,C,k,k] field as a C x N (N x N when square) mosaic on a 0 ... 0.1 scale; saved at 300 dpi."""
+        from .plots import _pyplot
+        plt = _pyplot()
+        psf = psf.detach().cpu().float()
+        if psf.dim() == 4:
+            N, C = psf.shape[:2]
+            rows = N if N == C else C
+            fig, axs = plt.subplots(rows, N, squeeze=False)
+            for i in range(rows):
+                for j in range(N):
+                    axs[i, j].imshow(psf[i, j] if N == C else psf[j, i], vmin=0.0, vmax=0.1)
+        else:
+            fig, axs = plt.subplots(1, psf.shape[0], squeeze=False)
+            for i in range(psf.shape[0]):
+                k = psf[i] / psf[i].max() if normal else psf[i]
+                axs[0, i].imshow(k, vmin=0.0, vmax=1, cmap="gray")
+                axs[0, i].axis("off")
+        if filename is not None:
+            fig.savefig(filename, dpi=300)
+        plt.close(fig)

@@ -56,6 +56,30 @@ class Aspheric:
         s.n2 = float(self.mat2.ior(wvln))
         return s
 
+    def surface(self, x, y):
+        """surfaces.py:766-771 with :787-808, on the host in fp32 numpy: the sag z(x, y) of the surface about its
+        vertex, evaluated at the apex where (x, y) lies outside the conic's domain (_valid_loose, :735-743).  For
+        drawing and for setting up rays; the tracing kernels carry their own evaluation (sdirt_device.hpp)."""
+        x, y = np.asarray(x, np.float32), np.asarray(y, np.float32)
+        rr = x * x + y * y
+        if float(self.c) == 0.0:
+            inside = np.ones_like(rr, dtype=bool)
+        elif float(self.k) > -1:
+            with np.errstate(divide="ignore"):
+                inside = rr < np.float32((1 - 1e-9) / float(self.c) ** 2 / (1 + float(self.k)))
+        else:
+            inside = rr > 0
+        r2 = np.where(inside, rr, np.float32(0))
+        z = r2 * self.c / (1 + np.sqrt(1 - (1 + self.k) * r2 * self.c ** 2, dtype=np.float32))
+        if self.ai is not None:
+            for i, a in enumerate(self.ai):
+                z = z + a * r2 ** (i + 1)
+        return z.astype(np.float32)
+
+    def surface_with_offset(self, x, y):
+        """surfaces.py:172-175: the surface's z in lens coordinates."""
+        return self.surface(x, y) + self.d
+
     def surf_dict(self):
         """Same keys as the reference's JSON surfaces (optics.py:2155-2167)."""
         kind = self.kind

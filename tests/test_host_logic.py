@@ -5,6 +5,7 @@ import ctypes
 import json
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -429,3 +430,60 @@ def test_plot_helpers_restate_make_grid_and_save_image(tmp_path):
     assert np.array_equal(rgb, want)
     back = (plt.imread(path)[..., :3] * 255 + 0.5).astype(np.uint8)
     assert np.array_equal(back, want)
+
+
+def test_import_aliases_and_script_helpers(tmp_path):
+    """sdirt_amd/compat: `deeplens.*` as the reference's scripts import it resolves to this package; set_seed /
+    set_logger behave as the reference's (utils.py:136-164)."""
+    import subprocess
+    from sdirt_amd import compat
+    code = ("import deeplens, sdirt_amd\n"
+            "from deeplens.psfnet import *\n"
+            "from deeplens.utils import set_logger, set_seed\n"
+            "from deeplens.optics import Lensgroup\n"
+            "from deeplens.monte_carlo import forward_integral, assign_points_to_pixels_small_r\n"
+            "from deeplens.render_psf import local_psf_render_fast, local_dp_psf_render\n"
+            "assert PSFNet is sdirt_amd.PSFNet and Lensgroup is sdirt_amd.Lensgroup and deeplens.Ray is sdirt_amd.Ray\n"
+            "assert DMIN == 200 and DMAX == 20000 and GEO_SPP == 2048 and nn is torch.nn\n"
+            "print('ok')\n")
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([compat.path(), ROOT]))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip() == "ok", out.stderr[-2000:]
+    import logging
+    import random
+    from sdirt_amd.utils import set_logger, set_seed
+    set_seed(5)
+    a = (random.random(), np.random.rand(), torch.rand(3))
+    set_seed(5)
+    b = (random.random(), np.random.rand(), torch.rand(3))
+    assert a[0] == b[0] and a[1] == b[1] and torch.equal(a[2], b[2])
+    root = logging.getLogger()
+    before = list(root.handlers)
+    try:
+        set_logger(str(tmp_path))
+        logging.info("hello from the test")
+        for h in root.handlers:
+            h.flush()
+        assert "INFO:hello from the test" in open(tmp_path / "output.log").read()
+    finally:
+        for h in [h for h in root.handlers if h not in before]:
+            root.removeHandler(h)
+            h.close()
+
+
+def test_host_sag_for_drawing():
+    """Aspheric.surface / surface_with_offset (surfaces.py:172-175, 766-771): sphere sag in closed form, apex
+    value outside the conic's domain, polynomial terms."""
+    from sdirt_amd.surfaces import Aspheric
+    s = Aspheric(8.0, 2.5, c=1 / 20.0)
+    r = np.linspace(-8, 8, 9, dtype=np.float32)
+    want = 20.0 - np.sqrt(400.0 - r.astype(np.float64) ** 2)
+    assert np.abs(s.surface(r, np.zeros_like(r)) - want).max() < 2e-6
+    assert np.abs(s.surface_with_offset(r, np.zeros_like(r)) - (want + 2.5)).max() < 2e-6
+    assert s.surface(np.float32(25.0), np.float32(0.0)) == 0.0          # outside the sphere: evaluated at the apex
+    a = Aspheric(5.0, 0.0, c=0.05, k=-1.5, ai=[1e-3, 2e-5])
+    r2 = 9.0
+    want = r2 * 0.05 / (1 + np.sqrt(1 - (1 - 1.5) * r2 * 0.05 ** 2)) + 1e-3 * r2 + 2e-5 * r2 ** 2
+    assert abs(float(a.surface(np.float32(3.0), np.float32(0.0))) - want) < 1e-6
+    flat = Aspheric(5.0, 1.0, c=0.0)
+    assert np.all(flat.surface_with_offset(r, r) == 1.0)
