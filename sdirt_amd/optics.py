@@ -187,6 +187,39 @@ class Lensgroup:
         with open(filename, "w") as f:
             json.dump(data, f, indent=4)
 
+    # nn.Module-style switches: the reference's Lensgroup / PSFNet inherit them from DeepObj(nn.Module)
+    # (basics.py:165-213) and its scripts call them (dfdp/factory.py:15,31-32: lens.to(device), lens.eval())
+    _DEVICE_CACHES = ("_stage_ring", "_sample_stream", "_readback_stream", "_ctl_pools", "_p2o_cache", "_ctl_host",
+                      "_right_streak")
+
+    def train(self, mode=True):
+        """The PSF network (if this lens carries one) in training / evaluation mode; -> self."""
+        net = getattr(self, "psfnet", None)
+        if net is not None:
+            net.train(mode)
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    def to(self, device):
+        """basics.py:180-201: use `device` from now on.  The device-side lens tables, streams and staging buffers
+        belong to the old device and are dropped (rebuilt on first use); the PSF network moves with the lens."""
+        device = _as_device(device)
+        if device != self.device:
+            self.device = device
+            self._invalidate()
+            for name in list(self.__dict__):
+                if name in self._DEVICE_CACHES or name.endswith("_stream"):
+                    del self.__dict__[name]
+            self.last_pupil_points = None
+        net = getattr(self, "psfnet", None)
+        if net is not None:
+            net.to(device)
+            if hasattr(net, "invalidate_packed"):
+                net.invalidate_packed()
+        return self
+
     def _invalidate(self):
         self._dev.clear()
         self._pupil_cache.clear()

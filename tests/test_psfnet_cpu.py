@@ -113,3 +113,17 @@ def test_render_rejects_what_the_reference_cannot_run():
     m = make_psfnet(7)
     with pytest.raises(ValueError):
         m.render(torch.zeros(3, 8, 12), torch.zeros(8, 12), -1000.0)
+
+
+def test_module_style_switches():
+    """train / eval / to as the reference's objects inherit them from nn.Module (basics.py:165-201; called by
+    dfdp/factory.py:15,31-32): they reach the PSF network and return the lens."""
+    m = make_psfnet(21)
+    assert m.eval() is m and not m.psfnet.training
+    assert m.train() is m and m.psfnet.training
+    assert m.train(False) is m and not m.psfnet.training
+    assert m.to("cpu") is m and m.device == torch.device("cpu")
+    assert next(m.psfnet.parameters()).device == torch.device("cpu")
+    from sdirt_amd import Lensgroup
+    bare = Lensgroup(os.path.join(DATA, "rf50mm.json"), sensor_res=(512, 768), post_computation=False, device="cpu")
+    assert bare.eval() is bare and bare.train() is bare and bare.to("cpu") is bare
