@@ -18,7 +18,6 @@ import sys
 import tempfile
 
 import numpy as np
-import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)

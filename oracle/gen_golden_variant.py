@@ -10,7 +10,6 @@ TEST INFRASTRUCTURE ONLY -- build container only.  Writes, next to the other fix
   f11_rf50_variant_pts4.npz        one psf_diff call with every per-surface checkpoint
 """
 import argparse
-import copy
 import json
 import os
 import sys

@@ -16,7 +16,6 @@ reference call over the whole grid is
 
 Nothing here touches the data path on a single GPU.
 """
-import numpy as np
 import torch
 import torch.distributed as dist
 

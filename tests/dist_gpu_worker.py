@@ -9,7 +9,6 @@ import json
 import os
 import sys
 
-import numpy as np
 import torch
 import torch.distributed as dist
 

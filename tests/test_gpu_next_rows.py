@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import DATA, load_golden, load_state, make_lens
+from conftest import DATA, load_golden, load_state
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"

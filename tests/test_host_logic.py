@@ -2,7 +2,6 @@
 trip-table speculation/verification, the C-ABI surface of libsdirt_dp.so, error
 behaviour without a device."""
 import ctypes
-import json
 import os
 import re
 import sys

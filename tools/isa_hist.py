@@ -28,7 +28,6 @@ the innermost loops of the surface loop; their rows are what VERDICT r01 item 3 
 import argparse
 import json
 import re
-import sys
 from collections import OrderedDict, defaultdict
 
 TRANS = re.compile(r"^v_(rcp|rsq|sqrt|sin|cos|exp|log)_(f32|f16|legacy)")

@@ -1,4 +1,4 @@
-import os, sys, time, torch
+import sys, time, torch
 sys.path.insert(0, ".")
 import bench
 lens = bench.build_lens(torch.device("cuda:0"), "rf50mm", 62.25)

@@ -1,4 +1,4 @@
-import sys, torch, numpy as np
+import sys, torch
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
 from conftest import make_lens, load_golden
 lens = make_lens("rf50mm", "cuda:0")

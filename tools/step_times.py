@@ -1,4 +1,4 @@
-import sys, time, torch, numpy as np
+import sys, time, torch
 sys.path.insert(0, ".")
 import bench
 dev = torch.device("cuda:0")

@@ -17,7 +17,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 def main():
     from conftest import load_state, make_lens
     from sdirt_amd import _lib
-    from sdirt_amd.basics import Ray, dptr, stream_ptr
+    from sdirt_amd.basics import stream_ptr
     import bench
     dev = torch.device("cuda:0")
     st = load_state("rf50mm")
