@@ -741,3 +741,29 @@ def test_split_path_shapes_agree_with_the_host_verified_path(n, spp, ks):
     for k in (("psf", 0.589, "lean"), ("center", "lean")):
         assert np.array_equal(a.trips.cache[k], b.trips.cache[k])
     assert float(La.amax((1, 2)).min()) > 0.99 and torch.isfinite(Ra).all()
+
+
+def test_ownership_and_mutation_follow_the_reference(lens):
+    """SURVEY §8b: psf_diff leaves its `points` alone (it clones, optics.py:958) whatever device they live on;
+    trace / trace2sensor change the Ray in place AND return it (optics.py:662-664); sample_from_points and
+    psf return fresh tensors on the lens's device.  (PSFNet.pred's in-place negation of inp[..., 0], psfnet.py:328,
+    is checked in tests/test_gpu_next_rows.py and tests/test_psfnet_cpu.py.)"""
+    from sdirt_amd import Ray
+    for dev in ("cpu", DEV):
+        pts = torch.tensor([[0.3, -0.2, -1500.0], [-0.7, 0.6, -800.0]], device=dev)
+        before = pts.clone()
+        a = lens.psf(pts, ks=21, spp=256)
+        b = lens.psf_diff(pts, ks=21, spp=256, param_list=list(DP) + ["r"])
+        c = lens.psf_rgb(pts, ks=21, spp=256)
+        assert torch.equal(pts, before) and pts.device.type == torch.device(dev).type
+        assert a.device == torch.device(DEV) and b.device == a.device and c.shape == (2, 3, 21, 21)
+    ray = lens.sample_from_points(o=[[0.0, 0.0, -1000.0], [5.0, 0.0, -1000.0]], spp=64)
+    assert isinstance(ray, Ray) and ray.shape == (64, 2)
+    o_before = ray.o.clone()
+    out, valid, oss = lens.trace(ray)
+    assert out is ray and oss is None and valid.shape == (64, 2)
+    assert not torch.equal(ray.o, o_before)                      # moved to the last surface
+    ray2 = lens.sample_from_points(o=[[0.0, 0.0, -1000.0], [5.0, 0.0, -1000.0]], spp=64)
+    assert lens.trace2sensor(ray2) is ray2
+    assert float(ray2.ra.sum()) > 0
+    assert torch.allclose(ray2.o[..., 2][ray2.ra > 0], torch.tensor(float(lens.d_sensor), device=DEV))
