@@ -95,3 +95,13 @@ def test_bench_config3_with_eight_ranks_on_one_gpu():
     if log:
         with open(os.path.join(log, "bench_gpus8_dryrun_c3.log"), "w") as f:
             f.write(lines[0] + "\n")
+
+
+@pytest.mark.gpu
+def test_rccl_backend_accepts_the_collectives_of_the_multi_gpu_path():
+    """tests/rccl_single_rank_worker.py: backend "nccl" (= RCCL) with one rank on the one GPU."""
+    env = _env(MASTER_PORT=str(_free_port()))
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rccl_single_rank_worker.py")], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert "rccl single-rank collectives ok" in p.stdout
