@@ -158,8 +158,8 @@ class PSFNet(Lensgroup):
                 shown = psfnet(batch_inp[:5]).float().cpu()
                 fig, axs = plt.subplots(5, 2)
                 for j in range(min(5, shown.shape[0])):
-                    axs[j, 0].imshow(batch_psf[j].float().cpu())
-                    axs[j, 1].imshow(shown[j])
+                    axs[j, 0].imshow(batch_psf[j].float().cpu().numpy())
+                    axs[j, 1].imshow(shown[j].numpy())
                 fig.suptitle(f"GT/Pred PSFs at iter {i + 1}")
                 fig.savefig(os.path.join(result_dir, f"iter{i + 1}.png"), dpi=300)
                 plt.close(fig)
@@ -468,12 +468,12 @@ class PSFNet(Lensgroup):
             fig, axs = plt.subplots(rows, N, squeeze=False)
             for i in range(rows):
                 for j in range(N):
-                    axs[i, j].imshow(psf[i, j] if N == C else psf[j, i], vmin=0.0, vmax=0.1)
+                    axs[i, j].imshow((psf[i, j] if N == C else psf[j, i]).numpy(), vmin=0.0, vmax=0.1)
         else:
             fig, axs = plt.subplots(1, psf.shape[0], squeeze=False)
             for i in range(psf.shape[0]):
                 k = psf[i] / psf[i].max() if normal else psf[i]
-                axs[0, i].imshow(k, vmin=0.0, vmax=1, cmap="gray")
+                axs[0, i].imshow(k.numpy(), vmin=0.0, vmax=1, cmap="gray")
                 axs[0, i].axis("off")
         if filename is not None:
             fig.savefig(filename, dpi=300)

@@ -208,8 +208,11 @@ def test_psfnet_fits_ray_traced_psfs_on_the_gpu(tmp_path):
     m.psfnet.apply(initialize_weights)
     m.load_net(str(tmp_path / "PSFNet_mlp.pkl"))
     assert all(torch.equal(w[k], v) for k, v in m.psfnet.state_dict().items())
-    cmp = m.compare_psf(spp=4096)
+    cmp = m.compare_psf(spp=4096, save_dir=str(tmp_path))
     assert set(cmp) == {-500, -20000}
+    assert all(os.path.getsize(tmp_path / f"{kind}_{d}_{v}.png") > 1000
+               for kind in ("rt", "pred") for d in (-500, -20000) for v in ("v00", "v04", "v08"))
+    assert m.compare_psf(spp=1024, figures=False).keys() == cmp.keys()
     traced, predicted = cmp[-500]
     assert traced.shape == (3, 2, 11, 11) and predicted.shape == (3, 2, 11, 11)
 
