@@ -717,6 +717,28 @@ class Lensgroup:
             return PendingPSF(lambda: pick(res.wait()))
         return pick(res)
 
+    def _centre_buffer(self, center_out, N):
+        """The [N, 2] centre tensor of a psf call: the caller's (checked) or a fresh one."""
+        if center_out is None:
+            return torch.empty((N, 2), dtype=torch.float32, device=self.device)
+        if not (center_out.is_cuda and center_out.dtype == torch.float32 and center_out.is_contiguous()
+                and tuple(center_out.shape) == (N, 2)):
+            raise ValueError("center_out must be a contiguous float32 CUDA [N, 2] tensor")
+        return center_out
+
+    def _psf_buffers(self, out, N, ks, need_r):
+        """(L, R) [N, ks, ks] of a psf call: the caller's `out` pair (checked) or fresh tensors; R is None when
+        the call fills no right grid."""
+        if out is None:
+            L = torch.empty((N, ks, ks), dtype=torch.float32, device=self.device)
+            return L, (torch.empty_like(L) if need_r else None)
+        L, R = out[0], (out[1] if need_r else None)
+        for t_ in (L, R):
+            if t_ is not None and not (t_.is_cuda and t_.dtype == torch.float32 and t_.is_contiguous()
+                                       and tuple(t_.shape) == (N, ks, ks)):
+                raise ValueError("out tensors must be contiguous float32 CUDA [N, ks, ks]")
+        return L, R
+
     @torch.no_grad()
     def psf_lr(self, points, ks=31, wvln=DEFAULT_WAVE, spp=GEO_SPP, center=True,
                dp=(0.78, 1.44, 0.3, 0.5), normalize=True, want_r=True, _default_r_zero=False,
@@ -787,13 +809,7 @@ class Lensgroup:
             x2, y2 = [torch.as_tensor(v).to(self.device, torch.float32).contiguous()
                       for v in pupil_xy]
             spp = x2.shape[0]
-        if center_out is not None:
-            if not (center_out.is_cuda and center_out.dtype == torch.float32 and center_out.is_contiguous()
-                    and tuple(center_out.shape) == (N, 2)):
-                raise ValueError("center_out must be a contiguous float32 CUDA [N, 2] tensor")
-            cen = center_out
-        else:
-            cen = torch.empty((N, 2), dtype=torch.float32, device=self.device)
+        cen = self._centre_buffer(center_out, N)
         xc = yc = None
         if center:
             _, pupilr_c = self.entrance_pupil(shrink_pupil=True)
@@ -811,15 +827,7 @@ class Lensgroup:
         #: the pupil sample points of the most recent psf_lr call (x2, y2, xc, yc), device tensors
         self.last_pupil_points = (x2, y2, xc, yc)
         need_r = want_r and not _default_r_zero
-        if out is not None:
-            L, R = out[0], (out[1] if need_r else None)
-            for t_ in (L, R):
-                if t_ is not None and not (t_.is_cuda and t_.dtype == torch.float32 and t_.is_contiguous()
-                                           and tuple(t_.shape) == (N, ks, ks)):
-                    raise ValueError("out tensors must be contiguous float32 CUDA [N, ks, ks]")
-        else:
-            L = torch.empty((N, ks, ks), dtype=torch.float32, device=self.device)
-            R = torch.empty_like(L) if need_r else None
+        L, R = self._psf_buffers(out, N, ks, need_r)
         dpp = None if (dp is None or _default_r_zero) else _lib.DpParams(*[float(v) for v in dp])
         dp_ref = C.byref(dpp) if dpp is not None else None
         handle = self.dev_lens(wvln)
@@ -1009,13 +1017,7 @@ class Lensgroup:
         ray = Ray.empty((spp, N), wvln, self.device)
         _lib.check(_lib.lib().sdirt_sample_rays(dptr(po), N, dptr(x2), dptr(y2), spp, float(pupilz), ray.c_rays(),
                                                 stream_ptr(self.device)))
-        if center_out is not None:
-            if not (center_out.is_cuda and center_out.dtype == torch.float32 and center_out.is_contiguous()
-                    and tuple(center_out.shape) == (N, 2)):
-                raise ValueError("center_out must be a contiguous float32 CUDA [N, 2] tensor")
-            cen = center_out
-        else:
-            cen = torch.empty((N, 2), dtype=torch.float32, device=self.device)
+        cen = self._centre_buffer(center_out, N)
         xc = yc = None
         if center:
             pupilz_c, pupilr_c = self.entrance_pupil(shrink_pupil=True)
@@ -1032,15 +1034,7 @@ class Lensgroup:
         self.trace(ray, forward=True)
         ray.propagate_to(self.d_sensor)
         need_r = want_r and not default_r_zero
-        if out is not None:
-            L, R = out[0], (out[1] if need_r else None)
-            for t_ in (L, R):
-                if t_ is not None and not (t_.is_cuda and t_.dtype == torch.float32 and t_.is_contiguous()
-                                           and tuple(t_.shape) == (N, ks, ks)):
-                    raise ValueError("out tensors must be contiguous float32 CUDA [N, ks, ks]")
-        else:
-            L = torch.empty((N, ks, ks), dtype=torch.float32, device=self.device)
-            R = torch.empty_like(L) if need_r else None
+        L, R = self._psf_buffers(out, N, ks, need_r)
         dpp = None if (dp is None or default_r_zero) else _lib.DpParams(*[float(v) for v in dp])
         h, st = _lib.lib(), stream_ptr(self.device)
         with self._timed("forward_integral"):
@@ -1069,22 +1063,8 @@ class Lensgroup:
         pupilz, pupilr = self.entrance_pupil()
         pupilr_c = self.entrance_pupil(shrink_pupil=True)[1]
         need_r = want_r and not default_r_zero
-        if center_out is not None:
-            if not (center_out.is_cuda and center_out.dtype == torch.float32 and center_out.is_contiguous()
-                    and tuple(center_out.shape) == (N, 2)):
-                raise ValueError("center_out must be a contiguous float32 CUDA [N, 2] tensor")
-            cen = center_out
-        else:
-            cen = torch.empty((N, 2), dtype=torch.float32, device=self.device)
-        if out is not None:
-            L, R = out[0], (out[1] if need_r else None)
-            for t_ in (L, R):
-                if t_ is not None and not (t_.is_cuda and t_.dtype == torch.float32 and t_.is_contiguous()
-                                           and tuple(t_.shape) == (N, ks, ks)):
-                    raise ValueError("out tensors must be contiguous float32 CUDA [N, ks, ks]")
-        else:
-            L = torch.empty((N, ks, ks), dtype=torch.float32, device=self.device)
-            R = torch.empty_like(L) if need_r else None
+        cen = self._centre_buffer(center_out, N)
+        L, R = self._psf_buffers(out, N, ks, need_r)
         dpp = None if (dp is None or default_r_zero) else _lib.DpParams(*[float(v) for v in dp])
         dp_ref = C.byref(dpp) if dpp is not None else None
         handle, handle_c = self.dev_lens(wvln), self.dev_lens(DEFAULT_WAVE)
