@@ -357,7 +357,7 @@ def main():
                          "beside `value` either way)")
     ap.add_argument("--gather", action="store_true", help="(default; kept for older scripts)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--sustain-seconds", type=float, default=15.0,
+    ap.add_argument("--sustain-seconds", type=float, default=20.0,
                     help="after the K timed steps, keep stepping for this long and report "
                          "ms_per_step_sustained (0 = skip); long enough for a 5-second GPU-activity "
                          "sampler to see the GPU phase of the run")
