@@ -25,6 +25,11 @@ pts[:, 2] = -200 - 19800 * pts[:, 2]
 ptd = pts.cuda()
 for _ in range(50):
     m.psf(ptd, ks=21, spp=20000)
+if "--no-freeze" not in sys.argv:
+    # a full garbage collection of torch's heap takes 40-55 ms: keep it out of the 0.3-second loops timed below
+    import gc
+    gc.collect()
+    gc.freeze()
 
 
 def timed(fn, n):
