@@ -84,38 +84,40 @@ def test_magnification_and_rms_against_the_reference():
 
 
 SCRIPT = r'''
-# the call sequence of the reference's 1_fit_psfnet.py (its lines in brackets), shortened: 40 iterations
-# instead of 90000, and a checkpoint written here because the reference's ./ckpt file is not distributed
-import os, sys
+# What the reference's fitting script does with the package (1_fit_psfnet.py:9-40), as a user of the import
+# aliases would write it: build the lens + network object, refocus to 1 m, dump the prescription, two lens reports
+# (near and far object), load a checkpoint, fit, compare.  Shortened: 40 iterations instead of 90000; the checkpoint
+# is written here first because the reference's ./ckpt file is not distributed.
+import os
+import sys
+
 import torch
-from deeplens.psfnet import PSFNet                                   # [9]
-from deeplens.utils import set_logger, set_seed                      # [10]
+from deeplens.psfnet import PSFNet
+from deeplens.utils import set_logger, set_seed
 
-result_dir, lens_file = sys.argv[1], sys.argv[2]
-os.makedirs(result_dir, exist_ok=True)                               # [15]
-set_logger(result_dir)                                               # [16]
-set_seed(0)                                                          # [17]
+out_dir, prescription = sys.argv[1:3]
+os.makedirs(out_dir, exist_ok=True)
+set_logger(out_dir)
+set_seed(0)
 
-ks = 21                                                              # [20]
-psfnet = PSFNet(filename=lens_file, sensor_res=(512, 768), kernel_size=ks, device='cuda')   # [21]
-d_sensor = psfnet.d_sensor                                           # [23]
-infocus = -1000 + d_sensor
-psfnet.refocus(infocus)                                              # [25]
-psfnet.write_lens_json(f'{result_dir}/lens.json')                    # [27]
-print(psfnet.d_sensor)
+KS = 21
+net = PSFNet(filename=prescription, sensor_res=(512, 768), kernel_size=KS, device="cuda")
+sensor_z = net.d_sensor
+net.refocus(-1000 + sensor_z)
+net.write_lens_json(os.path.join(out_dir, "lens.json"))
+print(net.d_sensor)
 
-near_depth = -500 + d_sensor                                         # [30]
-psfnet.analysis(save_name=f'{result_dir}/{int(near_depth)}', depth=near_depth, ks=ks)
-far_depth = -20000 + d_sensor
-psfnet.analysis(save_name=f'{result_dir}/{int(far_depth)}', depth=far_depth, ks=ks)
+for object_z in (-500 + sensor_z, -20000 + sensor_z):
+    net.analysis(save_name=os.path.join(out_dir, str(int(object_z))), depth=object_z, ks=KS)
 
-torch.save(psfnet.psfnet.state_dict(), f'{result_dir}/start.pkl')
-psfnet.load_net(f'{result_dir}/start.pkl')                           # [35]
-psfnet.train_psfnet(iters=40, bs=64, lr=1e-4, spp=20000, evaluate_every=20, result_dir=result_dir)   # [36]
+checkpoint = os.path.join(out_dir, "start.pkl")
+torch.save(net.psfnet.state_dict(), checkpoint)
+net.load_net(checkpoint)
+net.train_psfnet(iters=40, bs=64, lr=1e-4, spp=20000, evaluate_every=20, result_dir=out_dir)
 
-os.chdir(result_dir)
-psfnet.compare_psf()                                                 # [38]
-print('Finish PSF net fitting.')
+os.chdir(out_dir)
+net.compare_psf()
+print("Finish PSF net fitting.")
 '''
 
 
