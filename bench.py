@@ -60,7 +60,7 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s HBM3E
 VALU_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: vector fp32 (FMA counted as 2; the parity contract forbids contraction)
 # the two workloads either side of the hot path: not PSF-volume renders
-EXTRA_WORKLOADS = ("f1", "tcp")
+EXTRA_WORKLOADS = ("f1", "tcp", "staged")
 
 
 def source_hash():
@@ -278,7 +278,7 @@ def _hip_ms(fn, steps, warmup, device):
     return wall, float(np.mean([a.elapsed_time(b) for a, b in ev]))
 
 
-def bench_f1(args):
+def bench_f1(args, emit=True):
     """local_psf_render_fast (render_psf.py:120-155) -- per-pixel left/right PSF
     convolution of one 512 x 768 RGB frame with ks 21 kernels, the image-simulation step of
     2_dfdp_net.py.  HBM-bound: every pixel's [2, 21, 21] fp32 kernels are read exactly once."""
@@ -308,7 +308,137 @@ def bench_f1(args):
                         "algorithmic_bytes_per_launch": alg_bytes}}
     if sus is not None:
         res["ms_per_step_sustained"] = sus
-    print(json.dumps(res), flush=True)
+    if emit:
+        print(json.dumps(res), flush=True)
+    return res
+
+
+STAGED_N, STAGED_SPP = 2048, 4096
+
+
+def bench_staged(args, emit=True, lens=None, ks_list=(65, 21)):
+    """The API-compatible STAGED sequence of the reference (optics.py:460-494 sample_from_points, :889-904 psf_center,
+    :638-664 trace2sensor, monte_carlo.py:9-68 forward_integral, optics.py:983-987 normalise) as the library calls a
+    caller of those functions makes, rays held in HBM as SoA [spp, N] (8 arrays of 4 bytes per ray):
+        sdirt_sample_rays -> sdirt_chief_center -> sdirt_trace -> sdirt_propagate_to -> sdirt_forward_integral ->
+        sdirt_psf_normalize (L, R)
+    on 2048 points of the config-2 volume (every 8th: all 16 depth planes) x 4096 spp, for 65x65 and 21x21 grids.
+    One "step" = the whole chain once; every call is bracketed by HIP events on the stream it is launched on.
+    Algorithmic bytes per ray: sampler write o, d, ra = 28 B; trace read 28 + write 28; propagate read
+    o, d_xyz = 24 + write o = 12; forward_integral read ox, oy, dx, dz, ra = 20 + the grids written once."""
+    import ctypes as C
+    from sdirt_amd import _lib
+    from sdirt_amd.basics import Ray, dptr, stream_ptr
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback exists)"
+    dev = torch.device("cuda", torch.cuda.current_device())
+    if lens is None:
+        lens = build_lens(dev)
+    h, st = _lib.lib(), stream_ptr(dev)
+    N, S = STAGED_N, STAGED_SPP
+    M = N * S
+    K = len(lens.surfaces)
+    pts_all = volume_points(1, "c2")
+    pts = pts_all[:: len(pts_all) // N][:N].contiguous()
+    po = lens._points_to_object(pts)
+    torch.manual_seed(0)
+    # discovery through the package's own calls: the verified Newton trip tables become lens state
+    ray = Ray.empty((S, N), 0.589, dev)
+    pupilz, pupilr = lens.entrance_pupil()
+    x2, y2 = lens._pupil_samples(S, pupilr)
+    pupilz_c, pupilr_c = lens.entrance_pupil(shrink_pupil=True)
+    xc, yc = lens._pupil_samples(2048, pupilr_c)
+    cen = torch.empty((N, 2), dtype=torch.float32, device=dev)
+    lens._chief_center(po, xc, yc, pupilz_c, cen)
+    _lib.check(h.sdirt_sample_rays(dptr(po), N, dptr(x2), dptr(y2), S, float(pupilz), ray.c_rays(), st))
+    lens.trace(ray, forward=True)
+    t_trace = lens.trips.cache[("trace", round(float(ray.wvln), 6), 0, K, True, lens.precision)]
+    t_cen = lens.trips.cache[("center", lens.precision)]
+    trips_t = (C.c_int32 * K)(*[int(v) for v in t_trace])
+    trips_c = (C.c_int32 * K)(*[int(v) for v in t_cen])
+    handle = lens.dev_lens(0.589)
+    mask_t, mask_c = lens._mask_buffer(), lens._mask_buffer()
+    anyv = torch.zeros(1, dtype=torch.int32, device=dev)
+    dp = _lib.DpParams(*DP)
+    flags = lens._math_flags()
+    stream = torch.cuda.current_stream(dev)
+    out = {}
+    for ks in ks_list:
+        L = torch.empty((N, ks, ks), dtype=torch.float32, device=dev)
+        R = torch.empty_like(L)
+        calls = [
+            ("sample_rays", lambda: h.sdirt_sample_rays(dptr(po), N, dptr(x2), dptr(y2), S, float(pupilz), ray.c_rays(), st)),
+            ("chief_center", lambda: h.sdirt_chief_center(handle, dptr(po), N, dptr(xc), dptr(yc), 2048, float(pupilz_c),
+                                                          float(lens.d_sensor), trips_c, flags, dptr(cen), dptr(anyv),
+                                                          dptr(mask_c), st)),
+            ("trace", lambda: h.sdirt_trace(handle, 0, K, 0, trips_t, flags, ray.c_rays(), M, dptr(mask_t), st)),
+            ("propagate_to", lambda: h.sdirt_propagate_to(float(lens.d_sensor), ray.c_rays(), M, st)),
+            ("forward_integral", lambda: h.sdirt_forward_integral(ray.c_rays(), S, N, float(lens.pixel_size), ks, dptr(cen),
+                                                                  C.byref(dp), dptr(L), dptr(R), st)),
+            ("psf_normalize", lambda: (h.sdirt_psf_normalize(dptr(L), N, ks, st) or h.sdirt_psf_normalize(dptr(R), N, ks, st))),
+        ]
+
+        def chain(ev=None):
+            for name, fn in calls:
+                if ev is not None:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(stream)
+                _lib.check(fn())
+                if ev is not None:
+                    e1.record(stream)
+                    ev.setdefault(name, []).append((e0, e1))
+        for _ in range(max(args.warmup, 2)):
+            mask_t.zero_(); mask_c.zero_()
+            chain()
+        torch.cuda.synchronize(dev)
+        # the tables the timed chain runs are the reference's for this batch
+        from sdirt_amd import newton
+        for tab, m in ((t_trace, mask_t), (t_cen, mask_c)):
+            ok, _ = newton.verify(tab, lens._read_masks(m), list(range(K)), lens._curved())
+            assert ok, "staged chain: speculated Newton trip table is not the reference's"
+        steps = max(args.steps, 3)
+        ev = {}
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            chain(ev)
+        torch.cuda.synchronize(dev)
+        wall = (time.perf_counter() - t0) / steps * 1e3
+        ms = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in ev.items()}
+        grids = 2 * N * ks * ks * 4
+        alg = {"sample_rays": 28 * M + 12 * N + 8 * S,
+               "trace": 56 * M,
+               "propagate_to": 36 * M,
+               "forward_integral": 20 * M + 8 * N + grids,
+               "psf_normalize": 2 * grids}
+        kern = {}
+        for name, t in ms.items():
+            k = {"ms": t}
+            if name in alg:
+                gbs = alg[name] / (t * 1e-3) / 1e9
+                k.update({"algorithmic_bytes": alg[name], "achieved_GBps": gbs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS})
+            kern[name] = k
+        kern["trace"]["bound"] = kern["chief_center"]["bound"] = "valu"
+        out[f"ks{ks}"] = {"ms_per_step": wall, "rays_per_s": M / (wall * 1e-3), "psfs_per_s": N / (wall * 1e-3),
+                          "kernels": kern, "sum_of_kernels_ms": float(sum(ms.values()))}
+    first = out[f"ks{ks_list[0]}"]
+    dom = max(("sample_rays", "propagate_to", "forward_integral"), key=lambda k: first["kernels"][k]["ms"])
+    kd = first["kernels"][dom]
+    res = {"metric": f"rays/sec rf50mm staged SoA pipeline {ks_list[0]}x{ks_list[0]} DP-PSF @{S}spp",
+           "value": first["rays_per_s"], "unit": "rays/s", "n_gpus": 1, "steps": max(args.steps, 3), "warmup": max(args.warmup, 2),
+           "ms_per_step": first["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"rf50mm, {N} points of the config-2 volume (every 8th) x {S} spp (+2048 chief-ray rays/point), "
+                                  "rays staged in HBM as SoA [spp, N]: sample -> chief centre -> trace -> propagate -> "
+                                  "forward_integral -> normalise, L+R grids", "name": "staged", "points_per_gpu": N, "spp": S,
+                      "ks": list(ks_list), "newton_trip_policy": "reference (tables verified before the timed steps)"},
+           "staged": out,
+           "roofline": {"bound": "hbm", "achieved": kd["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": kd["frac_of_hbm_peak"], "traffic": None, "kernel": dom,
+                        "algorithmic_bytes_per_launch": kd["algorithmic_bytes"],
+                        "note": "the slowest of the chain's HBM-bound kernels; k_trace and k_chief_center are bound by vector "
+                                "ALU time like the fused kernel (per-kernel figures under `staged`)"}}
+    if emit:
+        print(json.dumps(res), flush=True)
+    return res
 
 
 def bench_tcp(args):
@@ -367,11 +497,12 @@ def main():
     ap.add_argument("--workload", choices=sorted(WORKLOADS) + list(EXTRA_WORKLOADS), default="c2",
                     help="c2 (default, the headline) / c3 / c3k65 / c4: PSF-volume renders; f1: per-pixel DP-PSF "
                          "convolution of a 512x768 frame (render_psf.py:120-155); tcp: the reference's own "
-                         "timing harness PSFNet.time_compare_psf (psfnet.py:570-586)")
+                         "timing harness PSFNet.time_compare_psf (psfnet.py:570-586); staged: the reference's own "
+                         "call sequence sample -> trace -> propagate -> forward_integral on SoA rays in HBM")
     args = ap.parse_args()
     if args.workload in EXTRA_WORKLOADS:
         assert args.gpus == 1, f"--workload {args.workload} is a single-GPU measurement"
-        return bench_f1(args) if args.workload == "f1" else bench_tcp(args)
+        return {"f1": bench_f1, "tcp": bench_tcp, "staged": bench_staged}[args.workload](args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
     global KS, SPP, GRID_Z

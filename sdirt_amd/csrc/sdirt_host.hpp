@@ -41,6 +41,29 @@ inline int fail(int code, const char* fmt, ...)
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Compute units of the CURRENT device (the binding makes the stream's device current for every call): 256 on an
+// MI355X in SPX mode, 32 per XCD of a partitioned one.  Asked once per device, launch geometry is sized from it.
+constexpr int kMaxDevices = 64;
+inline int device_cus(int* out)
+{
+    static int cached[kMaxDevices] = {};
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev >= 0 && dev < kMaxDevices && cached[dev] > 0) { *out = cached[dev]; return SDIRT_OK; }
+    int n = 0;
+    HIP_TRY(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
+    if (n < 1) return fail(SDIRT_ERR_HIP, "device %d reports %d compute units", dev, n);
+    if (dev >= 0 && dev < kMaxDevices) cached[dev] = n;
+    *out = n;
+    return SDIRT_OK;
+}
+// for the pure sizing helpers that may be asked before any device exists (sdirt_psf_spp_slices): MI355X's 256
+inline int device_cus_or_default()
+{
+    int n = 0;
+    return device_cus(&n) == SDIRT_OK ? n : 256;
+}
+
 
 // A prescription at one wavelength: the device table the kernels read and its host mirror.
 struct sdirt_lens {
@@ -91,6 +114,14 @@ inline int check_rays(const sdirt_rays& R)
     if (!R.ox || !R.oy || !R.oz || !R.dx || !R.dy || !R.dz || !R.ra)
         return fail(SDIRT_ERR_INVALID_ARGUMENT, "sdirt_rays has a null array");
     return SDIRT_OK;
+}
+
+// every component array on a 16-byte boundary (dwordx4 access)
+inline bool rays_aligned16(const sdirt_rays& R)
+{
+    const uintptr_t a = (uintptr_t)R.ox | (uintptr_t)R.oy | (uintptr_t)R.oz | (uintptr_t)R.dx | (uintptr_t)R.dy |
+                        (uintptr_t)R.dz | (uintptr_t)R.ra | (uintptr_t)R.obliq;
+    return (a & 15) == 0;
 }
 
 inline int check_ks(int ks, int max_ks = SDIRT_MAX_KS)

@@ -73,14 +73,14 @@ static SplatBlock make_splat_block(const SplatGeom& g, const DevDpParams& p)
     return b;
 }
 
-// forward_integral on SoA [S,N] rays: one thread per ray (coalesced reads),
-// contributions added to the pre-zeroed [N,ks,ks] grids with global float
-// atomics -- consecutive lanes are consecutive POINTS, so the 64 atomics of a
-// wave instruction go to 64 different tiles.
+// forward_integral on SoA [S,N] rays, grids too large for LDS (ks > SDIRT_MAX_KS; the one caller is a plot that
+// traces three points): one thread per ray, contributions added to the pre-zeroed [N,ks,ks] grids in HBM with
+// global float atomics.  Consecutive lanes are consecutive POINTS, the worst shape for these atomics (64 tiles
+// per wave instruction) -- every grid that fits LDS takes k_forward_integral_tiles below instead.
 __global__ void __launch_bounds__(kBlock)
-k_forward_integral(sdirt_rays R, int64_t S, int64_t N, SplatGeom gm, DevDpParams dp,
-                   const float* __restrict__ center, float* __restrict__ lg,
-                   float* __restrict__ rg)
+k_forward_integral_hbm(sdirt_rays R, int64_t S, int64_t N, SplatGeom gm, DevDpParams dp,
+                       const float* __restrict__ center, float* __restrict__ lg,
+                       float* __restrict__ rg)
 {
     const int64_t M = S * N;
     const int64_t tile = (int64_t)gm.ks * gm.ks;
@@ -105,6 +105,107 @@ k_forward_integral(sdirt_rays R, int64_t S, int64_t N, SplatGeom gm, DevDpParams
             atomicAdd(Rr + tp.i_tr, tp.w_tr * sr);
             atomicAdd(Rr + tp.i_bl, tp.w_bl * sr);
             atomicAdd(Rr + tp.i_br, tp.w_br * sr);
+        }
+    }
+}
+
+// forward_integral on SoA [S,N] rays with the grids in LDS (monte_carlo.py:9-68 for every ks <= SDIRT_MAX_KS).
+//
+// A workgroup OWNS P consecutive points (a power of two, chosen by the launcher: as many as LDS holds while the
+// grid still covers the chip) and a slice of the spp axis: their L/R tiles live in LDS for the whole kernel
+// (ds_add_f32; no global atomics, no memset, each tile stored once, coalesced) -- or, when the few points of a
+// call are cut along spp (nsplit > 1), added once per workgroup to the zeroed output.  Thread t works on
+// point t % P of row t / P: a wave instruction reads 64 / P rows x (P x 4) contiguous bytes per component.
+// What one workgroup uses of a 128-byte line is P x 4 bytes; the rest belongs to the 32 / P neighbouring
+// workgroups, which the block index -> point-group map below places on the SAME XCD at the same time, so the
+// line comes out of HBM once and the neighbours read it from that XCD's L2 (blocks b, b + 8, b + 16 ... share
+// an XCD).  The rays of the next pass are loaded before the current pass is splatted.
+constexpr int kFiThreads = 1024;
+struct FiLaunch {
+    int P, logP;          // points per workgroup
+    int ngroups;          // ceil(N / P)
+    int nsplit;           // slices of the spp axis
+    int64_t chunk;        // rows per slice, a multiple of kFiThreads / P
+    int stride;           // floats per point in LDS: (ntile * ks * ks) | 1, odd -> the same pixel of different
+                          // points never shares a bank
+};
+template <bool HAVE_R, bool BIG>
+__global__ void __launch_bounds__(kFiThreads)
+k_forward_integral_tiles(sdirt_rays R, int64_t S, int64_t N, SplatGeom gm, DevDpParams dp, FiLaunch fl,
+                         const float* __restrict__ center, float* __restrict__ lg, float* __restrict__ rg)
+{
+    extern __shared__ __attribute__((aligned(16))) float fi_tiles[];
+    const int tile = gm.ks * gm.ks;
+    // XCD-aware block -> work map: XCD x = b % 8 gets the contiguous range of logical ids
+    // [x q + min(x, r), ...) (q, r = nblocks / 8, nblocks % 8: bijective for every grid size)
+    const uint32_t nb = gridDim.x, b = blockIdx.x;
+    const uint32_t q = nb >> 3, rem = nb & 7u, x = b & 7u;
+    const uint32_t lb = x * q + min(x, rem) + (b >> 3);
+    const int g = (int)(lb / (uint32_t)fl.nsplit), j = (int)(lb - (uint32_t)g * fl.nsplit);
+    const int p = threadIdx.x & (fl.P - 1), row = threadIdx.x >> fl.logP, rp = kFiThreads >> fl.logP;
+    const int64_t n = (int64_t)g * fl.P + p;
+    const bool have_pt = n < N;
+    for (int i = threadIdx.x; i < fl.P * fl.stride; i += kFiThreads) fi_tiles[i] = 0.0f;
+    __syncthreads();
+
+    const float cx = have_pt ? center[2 * n] : 0.0f, cy = have_pt ? center[2 * n + 1] : 0.0f;
+    float* __restrict__ tl_ = fi_tiles + p * fl.stride;
+    float* __restrict__ trr = tl_ + tile;
+    const auto div_dy = UDiv<Lean>::make(gm.dy_rng), div_dx = UDiv<Lean>::make(gm.dx_rng);
+    const auto div_fmh = UDiv<Lean>::make(dp.fmh);
+    const int64_t s_begin = (int64_t)j * fl.chunk, s_end = min(S, s_begin + fl.chunk);
+    const int npass = (int)((s_end - s_begin + rp - 1) / rp);     // the same for every thread: no vote, no barrier
+    int64_t s = s_begin + row;
+    int64_t i = s * N + n;
+    const int64_t di = (int64_t)rp * N;
+    float ox = 0.f, oy = 0.f, dx = 0.f, dz = 1.f, ra = 0.f;
+    bool cur = have_pt && s < s_end;
+    if (cur) { ox = R.ox[i]; oy = R.oy[i]; dx = R.dx[i]; dz = R.dz[i]; ra = R.ra[i]; }
+    for (int pass = 0; pass < npass; ++pass) {
+        s += rp; i += di;
+        const bool nxt = have_pt && s < s_end;
+        float nox = 0.f, noy = 0.f, ndx = 0.f, ndz = 1.f, nra = 0.f;
+        if (nxt) { nox = R.ox[i]; noy = R.oy[i]; ndx = R.dx[i]; ndz = R.dz[i]; nra = R.ra[i]; }
+        SplatTaps tp;
+        if (cur && splat_taps(gm, div_dy, div_dx, ox, oy, cx, cy, ra, tp)) {
+            const float x_tan = (-dx) / dz;              // monte_carlo.py:48
+            float sl, sr;
+            if (BIG) dp_weights_big(dp, x_tan, sl, sr);
+            else dp_weights_small(dp, div_fmh, x_tan, sl, sr);
+            atomicAdd(&tl_[tp.i_tl], tp.w_tl * sl);
+            atomicAdd(&tl_[tp.i_tr], tp.w_tr * sl);
+            atomicAdd(&tl_[tp.i_bl], tp.w_bl * sl);
+            atomicAdd(&tl_[tp.i_br], tp.w_br * sl);
+            if (HAVE_R) {
+                atomicAdd(&trr[tp.i_tl], tp.w_tl * sr);
+                atomicAdd(&trr[tp.i_tr], tp.w_tr * sr);
+                atomicAdd(&trr[tp.i_bl], tp.w_bl * sr);
+                atomicAdd(&trr[tp.i_br], tp.w_br * sr);
+            }
+        }
+        ox = nox; oy = noy; dx = ndx; dz = ndz; ra = nra; cur = nxt;
+    }
+    __syncthreads();
+    // the P tiles of this workgroup are P * ks * ks consecutive floats of the [N, ks, ks] output
+    const int np = (int)min((int64_t)fl.P, N - (int64_t)g * fl.P);
+    for (int pp = 0; pp < np; ++pp) {
+        const float* __restrict__ src = fi_tiles + pp * fl.stride;
+        float* __restrict__ Lg = lg + ((int64_t)g * fl.P + pp) * tile;
+        float* __restrict__ Rg = HAVE_R ? rg + ((int64_t)g * fl.P + pp) * tile : nullptr;
+        if (fl.nsplit == 1) {
+            for (int e = threadIdx.x; e < tile; e += kFiThreads) {
+                Lg[e] = src[e];
+                if (HAVE_R) Rg[e] = src[tile + e];
+            }
+        } else {
+            for (int e = threadIdx.x; e < tile; e += kFiThreads) {
+                const float a = src[e];
+                if (a != 0.0f) atomicAdd(&Lg[e], a);
+                if (HAVE_R) {
+                    const float c = src[tile + e];
+                    if (c != 0.0f) atomicAdd(&Rg[e], c);
+                }
+            }
         }
     }
 }
@@ -526,21 +627,76 @@ k_psf_lr(SplatBlock sb /* kernarg offset 0 */, TripSet trips /* 64 */, TripSet t
 // ---------------------------------------------------------------------------
 extern "C" {
 
+// How k_forward_integral_tiles is launched for N points x S rows on grids of ks x ks (ntile of them per point).
+// false: the grids do not fit LDS (k_forward_integral_hbm).
+static bool plan_forward_integral(int64_t N, int64_t S, int ks, int ntile, int ncu, FiLaunch& fl)
+{
+    const size_t lds_max = 160 * 1024 - 1024;
+    fl.stride = (ntile * ks * ks) | 1;
+    const size_t per_point = sizeof(float) * (size_t)fl.stride;
+    if (per_point > lds_max) return false;
+    int P = 1;
+    while (P < 64 && (size_t)(2 * P) * per_point <= lds_max) P *= 2;
+    // fewer points per workgroup while the grid would leave CUs without one
+    while (P > 1 && (N + P - 1) / P < ncu) P /= 2;
+    fl.P = P;
+    fl.logP = 0;
+    while ((1 << fl.logP) < P) ++fl.logP;
+    fl.ngroups = (int)((N + P - 1) / P);
+    const int rp = kFiThreads / P;
+    // few points: cut the spp axis as well, at least two passes per slice
+    int64_t nsplit = 1;
+    if (fl.ngroups < ncu) nsplit = std::min<int64_t>((ncu + fl.ngroups - 1) / fl.ngroups, std::max<int64_t>(1, S / (2 * rp)));
+    int64_t chunk = (S + nsplit - 1) / nsplit;
+    chunk = std::max<int64_t>(rp, (chunk + rp - 1) / rp * rp);
+    fl.chunk = chunk;
+    fl.nsplit = (int)std::max<int64_t>(1, (S + chunk - 1) / chunk);
+    return true;
+}
+
 int sdirt_forward_integral(sdirt_rays rays, int64_t S, int64_t N, double ps, int32_t ks,
                            const float* center, const sdirt_dp_params* dp, float* l_grid,
                            float* r_grid, void* stream)
 {
     if (int rc = check_rays(rays)) return rc;
     if (int rc = check_ks(ks, SDIRT_MAX_KS_STAGED)) return rc;
-    if (!center || !l_grid || S < 0 || N < 0) return fail(SDIRT_ERR_INVALID_ARGUMENT, "bad argument");
+    if (!center || !l_grid || S < 0 || N < 0 || N > (1ll << 30)) return fail(SDIRT_ERR_INVALID_ARGUMENT, "bad argument");
     if (dp && !(dp->r > 0.0)) return fail(SDIRT_ERR_INVALID_ARGUMENT, "dp->r must be > 0");
     if (N == 0) return SDIRT_OK;
+    hipStream_t st = as_stream(stream);
     const size_t bytes = sizeof(float) * (size_t)N * ks * ks;
-    HIP_TRY(hipMemsetAsync(l_grid, 0, bytes, as_stream(stream)));
-    if (r_grid) HIP_TRY(hipMemsetAsync(r_grid, 0, bytes, as_stream(stream)));
+    const DevDpParams dpp = make_dp(dp);
+    const bool both = r_grid != nullptr && dpp.have_r;
+    FiLaunch fl;
+    int ncu = 0;
+    if (int rc = device_cus(&ncu)) return rc;
+    const bool tiles = S > 0 && plan_forward_integral(N, S, ks, both ? 2 : 1, ncu, fl);
+    // param_list=None leaves the R grid all-zero (monte_carlo.py:230-235); grids that are added to start at zero
+    if (!tiles || fl.nsplit > 1) HIP_TRY(hipMemsetAsync(l_grid, 0, bytes, st));
+    if (r_grid && (!tiles || fl.nsplit > 1 || !both)) HIP_TRY(hipMemsetAsync(r_grid, 0, bytes, st));
     if (S == 0) return SDIRT_OK;
-    k_forward_integral<<<grid_for(S * N, kBlock), kBlock, 0, as_stream(stream)>>>(
-        rays, S, N, make_geom(ps, ks), make_dp(dp), center, l_grid, r_grid);
+    if (!tiles) {
+        k_forward_integral_hbm<<<grid_for(S * N, kBlock), kBlock, 0, st>>>(
+            rays, S, N, make_geom(ps, ks), dpp, center, l_grid, r_grid);
+        LAUNCH_CHECK();
+        return SDIRT_OK;
+    }
+    const size_t lds_bytes = sizeof(float) * (size_t)fl.P * fl.stride;
+    const unsigned grid = (unsigned)fl.ngroups * (unsigned)fl.nsplit;
+#define SDIRT_LAUNCH_FI(HR, BG)                                                                   \
+    do {                                                                                          \
+        if (lds_bytes > 48 * 1024)                                                                \
+            HIP_TRY(hipFuncSetAttribute((const void*)k_forward_integral_tiles<HR, BG>,            \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024)); \
+        k_forward_integral_tiles<HR, BG><<<grid, kFiThreads, lds_bytes, st>>>(                    \
+            rays, S, N, make_geom(ps, ks), dpp, fl, center, l_grid, both ? r_grid : nullptr);     \
+    } while (0)
+    if (both) {
+        if (dpp.big) SDIRT_LAUNCH_FI(true, true); else SDIRT_LAUNCH_FI(true, false);
+    } else {
+        if (dpp.big) SDIRT_LAUNCH_FI(false, true); else SDIRT_LAUNCH_FI(false, false);
+    }
+#undef SDIRT_LAUNCH_FI
     LAUNCH_CHECK();
     return SDIRT_OK;
 }
@@ -597,7 +753,7 @@ static int spp_split(int64_t N, int64_t S, int* chunk_out)
     // Fill the chip: at least ~4 workgroups per CU; split the spp axis when the
     // number of points alone cannot (e.g. PSFNet training: N=64, S=20000).
     int nsplit = 1;
-    const int64_t want_blocks = 256 * 4;
+    const int64_t want_blocks = (int64_t)device_cus_or_default() * 4;
     if (N < want_blocks && S > 2 * kFused) {
         nsplit = (int)((want_blocks + N - 1) / N);
         const int max_split = (int)((S + 2 * kFused - 1) / (2 * kFused));
@@ -624,7 +780,8 @@ struct VerifiedRequest {
 // one ray per lane and slice.
 static int chief_slices(int64_t N, int64_t Sc, int* chunk_out)
 {
-    int64_t ns = std::min<int64_t>((Sc + kFused - 1) / kFused, (256 + N - 1) / std::max<int64_t>(N, 1));
+    int64_t ns = std::min<int64_t>((Sc + kFused - 1) / kFused,
+                                   (device_cus_or_default() + N - 1) / std::max<int64_t>(N, 1));
     if (ns < 1) ns = 1;
     int chunk = (int)((Sc + ns - 1) / ns);
     chunk = (chunk + 63) / 64 * 64;

@@ -84,15 +84,44 @@ __global__ void k_pupil_samples(const float* __restrict__ ut, const float* __res
     y2[s] = r * (float)__ocml_sin_f64((double)theta);
 }
 
-__global__ void k_sample_rays(const float* __restrict__ po, int64_t N, const float* __restrict__ x2,
-                              const float* __restrict__ y2, int64_t S, float pz, sdirt_rays R)
+// sample_from_points (optics.py:486-494) into SoA [S,N] rays: a pure streaming WRITE (32 bytes per ray against
+// 12 / N + 8 / S read), so the kernel is shaped for the store path.  VEC: every thread makes FOUR consecutive
+// points of one pupil sample (N % 4 == 0, arrays 16-byte aligned) and stores each component as one dwordx4 --
+// a wave instruction writes 1 KiB contiguous; the (s, n) pair is divided out once per thread and then stepped.
+template <bool VEC>
+__global__ void __launch_bounds__(kBlock)
+k_sample_rays(const float* __restrict__ po, int64_t N, const float* __restrict__ x2,
+              const float* __restrict__ y2, int64_t S, float pz, sdirt_rays R)
 {
-    const int64_t M = S * N;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t s = i / N, n = i - s * N;
-        Ray r = make_ray(po[3 * n], po[3 * n + 1], po[3 * n + 2], x2[s], y2[s], pz);
-        store_ray(R, i, r);
+    constexpr int W = VEC ? 4 : 1;
+    const int64_t NQ = N / W, MQ = S * NQ;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= MQ) return;
+    int64_t s = q / NQ, nq = q - s * NQ;
+    const int64_t ds = stride / NQ, dn = stride - ds * NQ;
+    for (; q < MQ; q += stride) {
+        const float xs = x2[s], ys = y2[s];
+        const int64_t i = s * N + nq * W;
+        if (VEC) {
+            // four points = 48 contiguous bytes of the [N,3] table
+            const float4* pp = reinterpret_cast<const float4*>(po + 12 * nq);
+            const float4 a = pp[0], b = pp[1], c = pp[2];
+            const Ray r0 = make_ray(a.x, a.y, a.z, xs, ys, pz), r1 = make_ray(a.w, b.x, b.y, xs, ys, pz),
+                      r2 = make_ray(b.z, b.w, c.x, xs, ys, pz), r3 = make_ray(c.y, c.z, c.w, xs, ys, pz);
+            *reinterpret_cast<float4*>(R.ox + i) = make_float4(r0.ox, r1.ox, r2.ox, r3.ox);
+            *reinterpret_cast<float4*>(R.oy + i) = make_float4(r0.oy, r1.oy, r2.oy, r3.oy);
+            *reinterpret_cast<float4*>(R.oz + i) = make_float4(r0.oz, r1.oz, r2.oz, r3.oz);
+            *reinterpret_cast<float4*>(R.dx + i) = make_float4(r0.dx, r1.dx, r2.dx, r3.dx);
+            *reinterpret_cast<float4*>(R.dy + i) = make_float4(r0.dy, r1.dy, r2.dy, r3.dy);
+            *reinterpret_cast<float4*>(R.dz + i) = make_float4(r0.dz, r1.dz, r2.dz, r3.dz);
+            *reinterpret_cast<float4*>(R.ra + i) = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+            if (R.obliq) *reinterpret_cast<float4*>(R.obliq + i) = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+        } else {
+            store_ray(R, i, make_ray(po[3 * nq], po[3 * nq + 1], po[3 * nq + 2], xs, ys, pz));
+        }
+        s += ds; nq += dn;
+        if (nq >= NQ) { nq -= NQ; s += 1; }
     }
 }
 
@@ -139,15 +168,32 @@ k_trace(TripTable trips /* kernarg offset 0 */, const DevSurface* __restrict__ l
         atomicOr(&conv_mask[threadIdx.x], lds_mask[threadIdx.x]);
 }
 
-__global__ void k_propagate(float z, sdirt_rays R, int64_t M)
+// Ray.propagate_to (basics.py:256-264) on SoA rays: reads 24, writes 12 bytes per ray and divides once -- a
+// streaming kernel.  VEC: four rays per thread, every component moved as dwordx4 (M % 4 == 0, aligned arrays).
+template <bool VEC>
+__global__ void __launch_bounds__(kBlock) k_propagate(float z, sdirt_rays R, int64_t M)
 {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        const float dz = R.dz[i];
-        const float t = (z - R.oz[i]) / dz;
-        R.ox[i] = R.ox[i] + R.dx[i] * t;
-        R.oy[i] = R.oy[i] + R.dy[i] * t;
-        R.oz[i] = R.oz[i] + dz * t;
+    if (VEC) {
+        const int64_t MQ = M / 4;
+        for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < MQ; q += (int64_t)gridDim.x * blockDim.x) {
+            const int64_t i = 4 * q;
+            const float4 oz = *reinterpret_cast<const float4*>(R.oz + i), dz = *reinterpret_cast<const float4*>(R.dz + i);
+            const float4 ox = *reinterpret_cast<const float4*>(R.ox + i), dx = *reinterpret_cast<const float4*>(R.dx + i);
+            const float4 oy = *reinterpret_cast<const float4*>(R.oy + i), dy = *reinterpret_cast<const float4*>(R.dy + i);
+            const float t0 = (z - oz.x) / dz.x, t1 = (z - oz.y) / dz.y, t2 = (z - oz.z) / dz.z, t3 = (z - oz.w) / dz.w;
+            *reinterpret_cast<float4*>(R.ox + i) = make_float4(ox.x + dx.x * t0, ox.y + dx.y * t1, ox.z + dx.z * t2, ox.w + dx.w * t3);
+            *reinterpret_cast<float4*>(R.oy + i) = make_float4(oy.x + dy.x * t0, oy.y + dy.y * t1, oy.z + dy.z * t2, oy.w + dy.w * t3);
+            *reinterpret_cast<float4*>(R.oz + i) = make_float4(oz.x + dz.x * t0, oz.y + dz.y * t1, oz.z + dz.z * t2, oz.w + dz.w * t3);
+        }
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M;
+             i += (int64_t)gridDim.x * blockDim.x) {
+            const float dz = R.dz[i];
+            const float t = (z - R.oz[i]) / dz;
+            R.ox[i] = R.ox[i] + R.dx[i] * t;
+            R.oy[i] = R.oy[i] + R.dy[i] * t;
+            R.oz[i] = R.oz[i] + dz * t;
+        }
     }
 }
 
@@ -334,8 +380,13 @@ int sdirt_sample_rays(const float* point_obj, int64_t N, const float* x2, const 
         return fail(SDIRT_ERR_INVALID_ARGUMENT, "bad argument");
     if (int rc = check_rays(rays)) return rc;
     if (N * S == 0) return SDIRT_OK;
-    k_sample_rays<<<grid_for(N * S, kBlock), kBlock, 0, as_stream(stream)>>>(
-        point_obj, N, x2, y2, S, (float)pupil_z, rays);
+    // streaming kernels: ~8 workgroups per CU, the rest by grid stride (each thread keeps 128 bytes of stores in flight)
+    if (N % 4 == 0 && rays_aligned16(rays) && ((uintptr_t)point_obj & 15) == 0)
+        k_sample_rays<true><<<grid_for(N / 4 * S, kBlock, 2048), kBlock, 0, as_stream(stream)>>>(
+            point_obj, N, x2, y2, S, (float)pupil_z, rays);
+    else
+        k_sample_rays<false><<<grid_for(N * S, kBlock), kBlock, 0, as_stream(stream)>>>(
+            point_obj, N, x2, y2, S, (float)pupil_z, rays);
     LAUNCH_CHECK();
     return SDIRT_OK;
 }
@@ -399,7 +450,10 @@ int sdirt_propagate_to(double z, sdirt_rays rays, int64_t M, void* stream)
 {
     if (int rc = check_rays(rays)) return rc;
     if (M <= 0) return M < 0 ? fail(SDIRT_ERR_INVALID_ARGUMENT, "n_rays < 0") : SDIRT_OK;
-    k_propagate<<<grid_for(M, kBlock), kBlock, 0, as_stream(stream)>>>((float)z, rays, M);
+    if (M % 4 == 0 && rays_aligned16(rays))
+        k_propagate<true><<<grid_for(M / 4, kBlock, 2048), kBlock, 0, as_stream(stream)>>>((float)z, rays, M);
+    else
+        k_propagate<false><<<grid_for(M, kBlock), kBlock, 0, as_stream(stream)>>>((float)z, rays, M);
     LAUNCH_CHECK();
     return SDIRT_OK;
 }

@@ -1,0 +1,144 @@
+"""The STAGED ray pipeline (rays in HBM as SoA [spp, N]; deeplens/optics.py:460-494, :638-664,
+deeplens/monte_carlo.py:9-68) through the C ABI: the vectorised sample / propagate kernels against their
+one-ray-per-thread forms bit for bit, forward_integral with the grids in LDS against the CPU oracle's splat
+and against the fused kernel, for every launch shape its planner produces (points per workgroup 1..64,
+ragged point counts, the spp axis cut or not, the HBM fallback above SDIRT_MAX_KS)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_state, make_lens
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+DP = (0.78, 1.44, 0.3, 0.5)
+
+
+@pytest.fixture(scope="module")
+def lens():
+    return make_lens("rf50mm", DEV)
+
+
+def _points(n, seed=3):
+    g = torch.Generator().manual_seed(seed)
+    p = torch.rand(n, 3, generator=g)
+    p[:, :2] = p[:, :2] * 1.8 - 0.9
+    p[:, 2] = -(200.0 + p[:, 2] ** 2 * 19800.0)
+    return p
+
+
+def _pupil(lens, spp, seed):
+    torch.manual_seed(seed)
+    return lens._pupil_samples(spp, lens.entrance_pupil()[1])
+
+
+def _sample(lens, po, x2, y2, n=None):
+    from sdirt_amd import _lib
+    from sdirt_amd.basics import Ray, dptr, stream_ptr
+    n = po.shape[0] if n is None else n
+    ray = Ray.empty((x2.shape[0], n), 0.589, DEV)
+    _lib.check(_lib.lib().sdirt_sample_rays(dptr(po), n, dptr(x2), dptr(y2), x2.shape[0],
+                                            float(lens.entrance_pupil()[0]), ray.c_rays(), stream_ptr(torch.device(DEV))))
+    return ray
+
+
+@pytest.mark.parametrize("n", [256, 52])
+def test_vectorised_sampler_and_propagate_equal_the_scalar_kernels_bit_for_bit(lens, n):
+    """N % 4 == 0 takes the dwordx4 kernels; the same points as a batch of N + 1 (one more point appended)
+    take the one-ray-per-thread kernels: rows [s, :N] must be the same bits."""
+    spp = 192
+    pts = _points(n + 1)
+    po = lens._points_to_object(pts)
+    x2, y2 = _pupil(lens, spp, 5)
+    a = _sample(lens, po[:n].contiguous(), x2, y2)
+    b = _sample(lens, po, x2, y2)
+    va = a.soa.view(8, spp, n)
+    vb = b.soa.view(8, spp, n + 1)[:, :, :n]
+    assert torch.equal(va.view(torch.int32), vb.contiguous().view(torch.int32))
+    assert torch.all(va[6] == 1) and torch.all(va[7] == 1)
+    a.propagate_to(-3.25)
+    b.propagate_to(-3.25)
+    vb = b.soa.view(8, spp, n + 1)[:, :, :n]
+    assert torch.equal(a.soa.view(8, spp, n).view(torch.int32), vb.contiguous().view(torch.int32))
+    # the sampler against its definition (optics.py:486-494): d = normalize(pupil point - o)
+    o = po[:n].double().cpu()
+    tgt = torch.stack([x2.double().cpu()[:, None].expand(spp, n), y2.double().cpu()[:, None].expand(spp, n),
+                       torch.full((spp, n), float(np.float32(lens.entrance_pupil()[0])), dtype=torch.float64)], -1)
+    d = tgt - o[None]
+    d = d / d.norm(dim=-1, keepdim=True)
+    a2 = _sample(lens, po[:n].contiguous(), x2, y2)
+    assert float((a2.d.double().cpu() - d).abs().max()) < 1.5e-7
+
+
+def _oracle_splat(oracle, st, ray, cen, ks, dp, n):
+    """forward_integral of point n's rays by the CPU oracle's splat."""
+    soa = ray.soa.view(8, ray.shape[0], ray.shape[1])[:, :, n].cpu().numpy()
+    o = np.ascontiguousarray(soa[0:3].T[:, None, :])
+    d = np.ascontiguousarray(soa[3:6].T[:, None, :])
+    lg, rg = oracle.forward_integral(o, d, np.ascontiguousarray(soa[6][:, None]), st["pixel_size"], ks,
+                                     cen[n:n + 1].cpu().numpy(), list(dp))
+    return lg[0], rg[0]
+
+
+@pytest.mark.parametrize("n,spp,ks,dp", [
+    (300, 1024, 21, DP),          # several points per workgroup, ragged last group, spp axis cut
+    (1100, 256, 9, DP),           # 64 points per workgroup (tiny grids), N % 64 != 0
+    (520, 512, 65, DP),           # LDS-limited: 4 points per workgroup on 135 KB
+    (3, 4096, 65, DP),            # a handful of points: one per workgroup, many spp slices
+    (37, 700, 33, None),          # param_list=None: L only, R stays zero
+    (130, 512, 21, (0.78, 1.44, 0.3, 0.6)),   # big-radius microlens branch
+    (2, 2048, 150, DP),           # above SDIRT_MAX_KS: grids in HBM
+])
+def test_forward_integral_tiles_match_the_oracle_splat(lens, oracle, n, spp, ks, dp):
+    from sdirt_amd import forward_integral_lr
+    st = load_state("rf50mm")
+    pts = _points(n, seed=n)
+    po = lens._points_to_object(pts)
+    x2, y2 = _pupil(lens, spp, 7)
+    ray = _sample(lens, po, x2, y2)
+    lens.trace2sensor(ray)
+    g = torch.Generator().manual_seed(1)
+    # centres a little off the spot (the window test gets rays on both sides) and a non-0/1 weight on some rays
+    soa = ray.soa.view(8, spp, n)
+    w = soa[6]
+    cen = torch.stack([-(soa[0] * w).sum(0) / (w.sum(0) + 1e-9), -(soa[1] * w).sum(0) / (w.sum(0) + 1e-9)], 1)
+    cen = (cen + (torch.rand(n, 2, generator=g).to(DEV) - 0.5) * 0.1).contiguous()
+    soa[6] *= torch.where(torch.rand(spp, n, generator=g) < 0.2, 0.625, 1.0).to(DEV)
+    lg, rg = forward_integral_lr(ray, lens.pixel_size, ks, cen, None if dp is None else list(dp) + ["l"])
+    assert torch.isfinite(lg).all() and torch.isfinite(rg).all()
+    if dp is None:
+        assert float(rg.abs().max()) == 0.0
+    worst = 0.0
+    for k in sorted(set([0, 1, n // 2, n - 2, n - 1]) & set(range(n))):
+        lo, ro = _oracle_splat(oracle, st, ray, cen, ks, dp if dp is not None else DP, k)
+        scale = max(float(lo.max()), 1e-6)
+        worst = max(worst, float(np.abs(lg[k].cpu().numpy() - lo).max()) / scale)
+        if dp is not None:
+            worst = max(worst, float(np.abs(rg[k].cpu().numpy() - ro).max()) / max(float(ro.max()), 1e-6))
+    print(f"forward_integral n={n} spp={spp} ks={ks}: max |HIP - oracle| / peak = {worst:.2e}")
+    # the segment areas of the default small-radius branch are a polynomial here and acos/sin in the oracle
+    # (3e-7 absolute per weight); sums of up to 4096 fp32 terms in a different order
+    assert worst < 3e-6
+    # energy: what the window keeps of every point is what was splat (bilinear taps sum to the weight)
+    tot = (lg.double().sum((1, 2)) + rg.double().sum((1, 2))).cpu()
+    assert torch.isfinite(tot).all() and float(tot.min()) >= 0
+
+
+def test_staged_chain_equals_fused_kernel_on_a_volume_slab(lens):
+    """The whole staged chain (sample -> chief centre -> trace -> propagate -> forward_integral -> normalise)
+    against the fused kernel on the same pupil samples: 512 points of the config-2 volume, 65x65."""
+    import bench
+    pts = bench.volume_points(1)[::32][:512].contiguous()
+    torch.manual_seed(11)
+    x2, y2, xc, yc = lens._pupil_samples_pair(1024, lens.entrance_pupil()[1], 2048,
+                                              lens.entrance_pupil(shrink_pupil=True)[1], side_stream=False)
+    kw = dict(ks=65, dp=DP, pupil_xy=(x2, y2), center_pupil_xy=(xc, yc))
+    Lf, Rf = lens.psf_lr(pts, **kw)
+    po = lens._points_to_object(pts)
+    Ls, Rs = lens._psf_lr_staged(pts, po, pts.shape[0], 65, 0.589, 1024, True, DP, True, True, False, (x2, y2),
+                                 (xc, yc), None, None, False)
+    d = max(float((Lf - Ls).abs().max()), float((Rf - Rs).abs().max()))
+    print(f"staged vs fused, 512 points x 1024 spp, ks 65 (normalised PSFs): max |diff| = {d:.2e}")
+    assert d < 3e-6
