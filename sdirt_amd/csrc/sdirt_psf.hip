@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <type_traits>
@@ -112,29 +113,41 @@ k_forward_integral_hbm(sdirt_rays R, int64_t S, int64_t N, SplatGeom gm, DevDpPa
 // forward_integral on SoA [S,N] rays with the grids in LDS (monte_carlo.py:9-68 for every ks <= SDIRT_MAX_KS).
 //
 // A workgroup OWNS P consecutive points (a power of two, chosen by the launcher: as many as LDS holds while the
-// grid still covers the chip) and a slice of the spp axis: their L/R tiles live in LDS for the whole kernel
-// (ds_add_f32; no global atomics, no memset, each tile stored once, coalesced) -- or, when the few points of a
-// call are cut along spp (nsplit > 1), added once per workgroup to the zeroed output.  Thread t works on
-// point t % P of row t / P: a wave instruction reads 64 / P rows x (P x 4) contiguous bytes per component.
-// What one workgroup uses of a 128-byte line is P x 4 bytes; the rest belongs to the 32 / P neighbouring
-// workgroups, which the block index -> point-group map below places on the SAME XCD at the same time, so the
-// line comes out of HBM once and the neighbours read it from that XCD's L2 (blocks b, b + 8, b + 16 ... share
-// an XCD).  The rays of the next pass are loaded before the current pass is splatted.
+// grid still covers the chip) and a slice of the spp axis: their L/R tiles live in LDS for the whole kernel (no
+// global atomics, no memset, each tile stored once, coalesced) -- or, when the few points of a call are cut along
+// spp (nsplit > 1), added once per workgroup to the zeroed output.
+//
+// The tiles are DOUBLES whenever two of them fit (ks <= 99): on gfx950 one ds_add_f32 wave instruction occupies the
+// LDS for ~193 cycles whatever its addresses (it is executed lane by lane), ds_add_f64 for 17-30 and ds_add_u64 for
+// 8-20 (tools/lds_atomic_bench.hip, profiles/r04/lds_atomic_bench*.txt) -- with eight adds per ray the fp32 form
+// IS the kernel's time (350 of 350 us on 8.4 M rays).  A double sum rounded once on the way out is also nearer to
+// the reference's sequential fp32 sum's exact value than any fp32 summation order, and takes any weight `ra`.
+//
+// Thread t works on point t % P of row t / P: a wave instruction reads 64 / P rows x (P x 4) contiguous bytes per
+// component.  What one workgroup uses of a 128-byte line is P x 4 bytes; the rest belongs to the 32 / P
+// neighbouring workgroups, which the block index -> point-group map below places on the SAME XCD at the same
+// time, so the line comes out of HBM once and the neighbours read it from that XCD's L2 (blocks b, b + 8, b + 16
+// ... share an XCD).  The rays of the next pass are loaded before the current pass is splatted.
+#ifndef FI_DEPTH
+#define FI_DEPTH 4
+#endif
 constexpr int kFiThreads = 1024;
+constexpr int kFiDepth = FI_DEPTH;      // passes whose rays are in flight
 struct FiLaunch {
     int P, logP;          // points per workgroup
     int ngroups;          // ceil(N / P)
     int nsplit;           // slices of the spp axis
     int64_t chunk;        // rows per slice, a multiple of kFiThreads / P
-    int stride;           // floats per point in LDS: (ntile * ks * ks) | 1, odd -> the same pixel of different
+    int stride;           // accumulators per point in LDS: (ntile * ks * ks) | 1, odd -> the same pixel of different
                           // points never shares a bank
 };
-template <bool HAVE_R, bool BIG>
+template <bool HAVE_R, bool BIG, class ACC>
 __global__ void __launch_bounds__(kFiThreads)
 k_forward_integral_tiles(sdirt_rays R, int64_t S, int64_t N, SplatGeom gm, DevDpParams dp, FiLaunch fl,
                          const float* __restrict__ center, float* __restrict__ lg, float* __restrict__ rg)
 {
-    extern __shared__ __attribute__((aligned(16))) float fi_tiles[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char fi_lds[];
+    ACC* __restrict__ fi_tiles = reinterpret_cast<ACC*>(fi_lds);
     const int tile = gm.ks * gm.ks;
     // XCD-aware block -> work map: XCD x = b % 8 gets the contiguous range of logical ids
     // [x q + min(x, r), ...) (q, r = nblocks / 8, nblocks % 8: bijective for every grid size)
@@ -145,12 +158,12 @@ k_forward_integral_tiles(sdirt_rays R, int64_t S, int64_t N, SplatGeom gm, DevDp
     const int p = threadIdx.x & (fl.P - 1), row = threadIdx.x >> fl.logP, rp = kFiThreads >> fl.logP;
     const int64_t n = (int64_t)g * fl.P + p;
     const bool have_pt = n < N;
-    for (int i = threadIdx.x; i < fl.P * fl.stride; i += kFiThreads) fi_tiles[i] = 0.0f;
+    for (int i = threadIdx.x; i < fl.P * fl.stride; i += kFiThreads) fi_tiles[i] = (ACC)0;
     __syncthreads();
 
     const float cx = have_pt ? center[2 * n] : 0.0f, cy = have_pt ? center[2 * n + 1] : 0.0f;
-    float* __restrict__ tl_ = fi_tiles + p * fl.stride;
-    float* __restrict__ trr = tl_ + tile;
+    ACC* __restrict__ tl_ = fi_tiles + p * fl.stride;
+    ACC* __restrict__ trr = tl_ + tile;
     const auto div_dy = UDiv<Lean>::make(gm.dy_rng), div_dx = UDiv<Lean>::make(gm.dx_rng);
     const auto div_fmh = UDiv<Lean>::make(dp.fmh);
     const int64_t s_begin = (int64_t)j * fl.chunk, s_end = min(S, s_begin + fl.chunk);
@@ -158,51 +171,66 @@ k_forward_integral_tiles(sdirt_rays R, int64_t S, int64_t N, SplatGeom gm, DevDp
     int64_t s = s_begin + row;
     int64_t i = s * N + n;
     const int64_t di = (int64_t)rp * N;
-    float ox = 0.f, oy = 0.f, dx = 0.f, dz = 1.f, ra = 0.f;
-    bool cur = have_pt && s < s_end;
-    if (cur) { ox = R.ox[i]; oy = R.oy[i]; dx = R.dx[i]; dz = R.dz[i]; ra = R.ra[i]; }
-    for (int pass = 0; pass < npass; ++pass) {
+    // The rays of the next kFiDepth passes are in flight while one pass is splatted (a pass of a 1024-thread
+    // workgroup is ~2 k cycles of vector work, an HBM miss under load several times that).  Every thread loads on
+    // every pass -- lanes without a ray read element 0 and ignore it -- so that the number of loads in flight is
+    // the same on every path: the compiler then waits with a counted s_waitcnt vmcnt(5 (kFiDepth - 1)) for exactly
+    // the set it is about to use (a predicated prefetch forces vmcnt(0) right behind its own issue).
+    float vox[kFiDepth], voy[kFiDepth], vdx[kFiDepth], vdz[kFiDepth], vra[kFiDepth];
+    bool vcur[kFiDepth];
+#pragma unroll
+    for (int k = 0; k < kFiDepth; ++k) {
+        vcur[k] = have_pt && s < s_end;
+        const int64_t il = vcur[k] ? i : 0;
+        vox[k] = R.ox[il]; voy[k] = R.oy[il]; vdx[k] = R.dx[il]; vdz[k] = R.dz[il]; vra[k] = R.ra[il];
         s += rp; i += di;
-        const bool nxt = have_pt && s < s_end;
-        float nox = 0.f, noy = 0.f, ndx = 0.f, ndz = 1.f, nra = 0.f;
-        if (nxt) { nox = R.ox[i]; noy = R.oy[i]; ndx = R.dx[i]; ndz = R.dz[i]; nra = R.ra[i]; }
-        SplatTaps tp;
-        if (cur && splat_taps(gm, div_dy, div_dx, ox, oy, cx, cy, ra, tp)) {
-            const float x_tan = (-dx) / dz;              // monte_carlo.py:48
-            float sl, sr;
-            if (BIG) dp_weights_big(dp, x_tan, sl, sr);
-            else dp_weights_small(dp, div_fmh, x_tan, sl, sr);
-            atomicAdd(&tl_[tp.i_tl], tp.w_tl * sl);
-            atomicAdd(&tl_[tp.i_tr], tp.w_tr * sl);
-            atomicAdd(&tl_[tp.i_bl], tp.w_bl * sl);
-            atomicAdd(&tl_[tp.i_br], tp.w_br * sl);
-            if (HAVE_R) {
-                atomicAdd(&trr[tp.i_tl], tp.w_tl * sr);
-                atomicAdd(&trr[tp.i_tr], tp.w_tr * sr);
-                atomicAdd(&trr[tp.i_bl], tp.w_bl * sr);
-                atomicAdd(&trr[tp.i_br], tp.w_br * sr);
+    }
+    for (int pass = 0; pass < npass; pass += kFiDepth) {
+#pragma unroll
+        for (int k = 0; k < kFiDepth; ++k) {
+            const float ox = vox[k], oy = voy[k], dx = vdx[k], dz = vdz[k], ra = vra[k];
+            const bool cur = vcur[k];
+            vcur[k] = have_pt && s < s_end;
+            const int64_t il = vcur[k] ? i : 0;
+            vox[k] = R.ox[il]; voy[k] = R.oy[il]; vdx[k] = R.dx[il]; vdz[k] = R.dz[il]; vra[k] = R.ra[il];
+            s += rp; i += di;
+            SplatTaps tp;
+            if (cur && splat_taps(gm, div_dy, div_dx, ox, oy, cx, cy, ra, tp)) {
+                const float x_tan = (-dx) / dz;              // monte_carlo.py:48
+                float sl, sr;
+                if (BIG) dp_weights_big(dp, x_tan, sl, sr);
+                else dp_weights_small(dp, div_fmh, x_tan, sl, sr);
+                atomicAdd(&tl_[tp.i_tl], (ACC)(tp.w_tl * sl));
+                atomicAdd(&tl_[tp.i_tr], (ACC)(tp.w_tr * sl));
+                atomicAdd(&tl_[tp.i_bl], (ACC)(tp.w_bl * sl));
+                atomicAdd(&tl_[tp.i_br], (ACC)(tp.w_br * sl));
+                if (HAVE_R) {
+                    atomicAdd(&trr[tp.i_tl], (ACC)(tp.w_tl * sr));
+                    atomicAdd(&trr[tp.i_tr], (ACC)(tp.w_tr * sr));
+                    atomicAdd(&trr[tp.i_bl], (ACC)(tp.w_bl * sr));
+                    atomicAdd(&trr[tp.i_br], (ACC)(tp.w_br * sr));
+                }
             }
         }
-        ox = nox; oy = noy; dx = ndx; dz = ndz; ra = nra; cur = nxt;
     }
     __syncthreads();
     // the P tiles of this workgroup are P * ks * ks consecutive floats of the [N, ks, ks] output
     const int np = (int)min((int64_t)fl.P, N - (int64_t)g * fl.P);
     for (int pp = 0; pp < np; ++pp) {
-        const float* __restrict__ src = fi_tiles + pp * fl.stride;
+        const ACC* __restrict__ src = fi_tiles + pp * fl.stride;
         float* __restrict__ Lg = lg + ((int64_t)g * fl.P + pp) * tile;
         float* __restrict__ Rg = HAVE_R ? rg + ((int64_t)g * fl.P + pp) * tile : nullptr;
         if (fl.nsplit == 1) {
             for (int e = threadIdx.x; e < tile; e += kFiThreads) {
-                Lg[e] = src[e];
-                if (HAVE_R) Rg[e] = src[tile + e];
+                Lg[e] = (float)src[e];
+                if (HAVE_R) Rg[e] = (float)src[tile + e];
             }
         } else {
             for (int e = threadIdx.x; e < tile; e += kFiThreads) {
-                const float a = src[e];
+                const float a = (float)src[e];
                 if (a != 0.0f) atomicAdd(&Lg[e], a);
                 if (HAVE_R) {
-                    const float c = src[tile + e];
+                    const float c = (float)src[tile + e];
                     if (c != 0.0f) atomicAdd(&Rg[e], c);
                 }
             }
@@ -627,18 +655,19 @@ k_psf_lr(SplatBlock sb /* kernarg offset 0 */, TripSet trips /* 64 */, TripSet t
 // ---------------------------------------------------------------------------
 extern "C" {
 
-// How k_forward_integral_tiles is launched for N points x S rows on grids of ks x ks (ntile of them per point).
-// false: the grids do not fit LDS (k_forward_integral_hbm).
-static bool plan_forward_integral(int64_t N, int64_t S, int ks, int ntile, int ncu, FiLaunch& fl)
+// How k_forward_integral_tiles is launched for N points x S rows on grids of ks x ks (ntile of them per point,
+// `acc` bytes per accumulator).  false: the grids do not fit LDS.
+static bool plan_forward_integral(int64_t N, int64_t S, int ks, int ntile, size_t acc, int ncu, FiLaunch& fl)
 {
     const size_t lds_max = 160 * 1024 - 1024;
     fl.stride = (ntile * ks * ks) | 1;
-    const size_t per_point = sizeof(float) * (size_t)fl.stride;
+    const size_t per_point = acc * (size_t)fl.stride;
     if (per_point > lds_max) return false;
     int P = 1;
     while (P < 64 && (size_t)(2 * P) * per_point <= lds_max) P *= 2;
     // fewer points per workgroup while the grid would leave CUs without one
     while (P > 1 && (N + P - 1) / P < ncu) P /= 2;
+    if (const char* e = getenv("SDIRT_FI_P")) { const int v = atoi(e); if (v >= 1 && v <= P) P = v; }   // EXPERIMENT
     fl.P = P;
     fl.logP = 0;
     while ((1 << fl.logP) < P) ++fl.logP;
@@ -670,7 +699,10 @@ int sdirt_forward_integral(sdirt_rays rays, int64_t S, int64_t N, double ps, int
     FiLaunch fl;
     int ncu = 0;
     if (int rc = device_cus(&ncu)) return rc;
-    const bool tiles = S > 0 && plan_forward_integral(N, S, ks, both ? 2 : 1, ncu, fl);
+    const int ntile = both ? 2 : 1;
+    // double accumulators when they fit (ks <= 99 for L + R), float ones up to SDIRT_MAX_KS, else the grids stay in HBM
+    const bool wide = S > 0 && plan_forward_integral(N, S, ks, ntile, sizeof(double), ncu, fl);
+    const bool tiles = wide || (S > 0 && plan_forward_integral(N, S, ks, ntile, sizeof(float), ncu, fl));
     // param_list=None leaves the R grid all-zero (monte_carlo.py:230-235); grids that are added to start at zero
     if (!tiles || fl.nsplit > 1) HIP_TRY(hipMemsetAsync(l_grid, 0, bytes, st));
     if (r_grid && (!tiles || fl.nsplit > 1 || !both)) HIP_TRY(hipMemsetAsync(r_grid, 0, bytes, st));
@@ -681,21 +713,26 @@ int sdirt_forward_integral(sdirt_rays rays, int64_t S, int64_t N, double ps, int
         LAUNCH_CHECK();
         return SDIRT_OK;
     }
-    const size_t lds_bytes = sizeof(float) * (size_t)fl.P * fl.stride;
+    const size_t lds_bytes = (wide ? sizeof(double) : sizeof(float)) * (size_t)fl.P * fl.stride;
     const unsigned grid = (unsigned)fl.ngroups * (unsigned)fl.nsplit;
-#define SDIRT_LAUNCH_FI(HR, BG)                                                                   \
+#define SDIRT_LAUNCH_FI_A(HR, BG, AC)                                                             \
     do {                                                                                          \
         if (lds_bytes > 48 * 1024)                                                                \
-            HIP_TRY(hipFuncSetAttribute((const void*)k_forward_integral_tiles<HR, BG>,            \
+            HIP_TRY(hipFuncSetAttribute((const void*)k_forward_integral_tiles<HR, BG, AC>,        \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024)); \
-        k_forward_integral_tiles<HR, BG><<<grid, kFiThreads, lds_bytes, st>>>(                    \
+        k_forward_integral_tiles<HR, BG, AC><<<grid, kFiThreads, lds_bytes, st>>>(                \
             rays, S, N, make_geom(ps, ks), dpp, fl, center, l_grid, both ? r_grid : nullptr);     \
+    } while (0)
+#define SDIRT_LAUNCH_FI(HR, BG)                                                                   \
+    do {                                                                                          \
+        if (wide) SDIRT_LAUNCH_FI_A(HR, BG, double); else SDIRT_LAUNCH_FI_A(HR, BG, float);       \
     } while (0)
     if (both) {
         if (dpp.big) SDIRT_LAUNCH_FI(true, true); else SDIRT_LAUNCH_FI(true, false);
     } else {
         if (dpp.big) SDIRT_LAUNCH_FI(false, true); else SDIRT_LAUNCH_FI(false, false);
     }
+#undef SDIRT_LAUNCH_FI_A
 #undef SDIRT_LAUNCH_FI
     LAUNCH_CHECK();
     return SDIRT_OK;

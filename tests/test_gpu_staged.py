@@ -85,7 +85,8 @@ def _oracle_splat(oracle, st, ray, cen, ks, dp, n):
 @pytest.mark.parametrize("n,spp,ks,dp", [
     (300, 1024, 21, DP),          # several points per workgroup, ragged last group, spp axis cut
     (1100, 256, 9, DP),           # 64 points per workgroup (tiny grids), N % 64 != 0
-    (520, 512, 65, DP),           # LDS-limited: 4 points per workgroup on 135 KB
+    (520, 512, 65, DP),           # LDS-limited: 2 points per workgroup on 135 KB (double accumulators)
+    (5, 1024, 120, DP),           # two double tiles no longer fit: float accumulators
     (3, 4096, 65, DP),            # a handful of points: one per workgroup, many spp slices
     (37, 700, 33, None),          # param_list=None: L only, R stays zero
     (130, 512, 21, (0.78, 1.44, 0.3, 0.6)),   # big-radius microlens branch

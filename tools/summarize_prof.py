@@ -8,7 +8,8 @@ import os
 import sys
 from collections import defaultdict
 
-KEEP = ("k_psf_lr", "k_chief_center", "k_forward_integral", "k_trace", "k_local_psf_render")
+KEEP = ("k_psf_lr", "k_chief_center", "k_forward_integral", "k_trace", "k_local_psf_render", "k_sample_rays",
+        "k_propagate", "k_psf_normalize")
 
 
 def short(name):
