@@ -316,9 +316,11 @@ def bench_f1(args, emit=True):
 # 4096 points x 4096 spp x 32 B = 537 MB of rays: twice the 256 MiB Infinity Cache, so that the streaming kernels
 # of the chain are timed against HBM and not against the cache
 STAGED_N, STAGED_SPP = 4096, 4096
+KERNEL_OF = {"sample_rays": "k_sample_rays", "trace": "k_trace", "propagate_to": "k_propagate",
+             "forward_integral": "k_forward_integral", "psf_normalize": "k_psf_normalize", "chief_center": "k_chief_center"}
 
 
-def bench_staged(args, emit=True, lens=None, ks_list=(65, 21)):
+def bench_staged(args, emit=True, lens=None, ks_list=None):
     """The API-compatible STAGED sequence of the reference (optics.py:460-494 sample_from_points, :889-904 psf_center,
     :638-664 trace2sensor, monte_carlo.py:9-68 forward_integral, optics.py:983-987 normalise) as the library calls a
     caller of those functions makes, rays held in HBM as SoA [spp, N] (8 arrays of 4 bytes per ray):
@@ -335,6 +337,8 @@ def bench_staged(args, emit=True, lens=None, ks_list=(65, 21)):
     dev = torch.device("cuda", torch.cuda.current_device())
     if lens is None:
         lens = build_lens(dev)
+    if ks_list is None:
+        ks_list = tuple(int(v) for v in getattr(args, "staged_ks", "65,21").split(","))
     h, st = _lib.lib(), stream_ptr(dev)
     N, S = STAGED_N, STAGED_SPP
     M = N * S
@@ -412,11 +416,20 @@ def bench_staged(args, emit=True, lens=None, ks_list=(65, 21)):
                "forward_integral": 20 * M + 8 * N + grids,
                "psf_normalize": 2 * grids}
         kern = {}
+        carried = pmc_counters(f"staged_ks{ks}")
         for name, t in ms.items():
             k = {"ms": t}
             if name in alg:
                 gbs = alg[name] / (t * 1e-3) / 1e9
                 k.update({"algorithmic_bytes": alg[name], "achieved_GBps": gbs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS})
+                c = ((carried or {}).get("kernels") or {}).get(KERNEL_OF[name])
+                if c and c.get("hbm_bytes_per_dispatch_mean_last3") and (carried.get("n_points"), carried.get("spp")) == (N, S):
+                    # HBM bytes of this kernel from the committed rocprofv3 --pmc passes of this command
+                    # (2 x FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md), and its rocprofv3 average duration
+                    k.update({"traffic": c["hbm_bytes_per_dispatch_mean_last3"],
+                              "traffic_over_algorithmic": c["hbm_bytes_per_dispatch_mean_last3"] / alg[name],
+                              "rocprof_avg_ms": c["avg_us"] / 1e3, "traffic_stale": bool(carried["stale"]),
+                              "traffic_file": carried["file"]})
             kern[name] = k
         kern["trace"]["bound"] = kern["chief_center"]["bound"] = "valu"
         out[f"ks{ks}"] = {"ms_per_step": wall, "rays_per_s": M / (wall * 1e-3), "psfs_per_s": N / (wall * 1e-3),
@@ -434,13 +447,67 @@ def bench_staged(args, emit=True, lens=None, ks_list=(65, 21)):
                       "ks": list(ks_list), "newton_trip_policy": "reference (tables verified before the timed steps)"},
            "staged": out,
            "roofline": {"bound": "hbm", "achieved": kd["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": kd["frac_of_hbm_peak"], "traffic": None, "kernel": dom,
+                        "frac": kd["frac_of_hbm_peak"], "traffic": kd.get("traffic"), "kernel": dom,
                         "algorithmic_bytes_per_launch": kd["algorithmic_bytes"],
                         "note": "the slowest of the chain's HBM-bound kernels; k_trace and k_chief_center are bound by vector "
                                 "ALU time like the fused kernel (per-kernel figures under `staged`)"}}
     if emit:
         print(json.dumps(res), flush=True)
     return res
+
+
+def quick_volume(workload, steps, device):
+    """K steps of another PSF-volume workload (WORKLOADS) with the stepping of the headline loop -- calls kept in
+    flight, Newton trip check of step i under step i + 1 -- for the `also` block of the default line."""
+    wl = WORKLOADS[workload]
+    lens = build_lens(device, wl["lens"], wl["sensor_z"])
+    gz = 8 if workload.startswith("c3") else wl["grid_z"]
+    pts = volume_points(1, workload).to(device)
+    n, ks, spp = pts.shape[0], wl["ks"], wl["spp"]
+    bufs = [tuple(torch.empty((n, ks, ks), dtype=torch.float32, device=device) for _ in range(2)) for _ in range(3)]
+    lens.psf_lr(pts, ks=ks, spp=spp, dp=DP, out=bufs[0])             # trip-table discovery
+    lens.psf_lr(pts, ks=ks, spp=spp, dp=DP, out=bufs[0])
+    torch.cuda.synchronize(device)
+    lens.kernel_events = {}
+    r0 = lens.trips.relaunches
+    pend = []
+    t0 = time.perf_counter()
+    for i in range(steps):
+        pend.append(lens.psf_lr(pts, ks=ks, spp=spp, dp=DP, out=bufs[i % 3], defer=True))
+        if len(pend) > 2:
+            pend.pop(0).wait()
+    for p_ in pend:
+        p_.wait()
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    ev, lens.kernel_events = lens.kernel_events, None
+    k_ms = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in ev.items()}
+    return {"metric": f"rays/sec {wl['lens']} {ks}x{ks} DP-PSF @{spp}spp", "value": n * spp * steps / dt, "unit": "rays/s",
+            "steps": steps, "ms_per_step": dt / steps * 1e3, "kernels_ms": k_ms,
+            "config": {"workload": wl["desc"].format(gz=gz) + f", {n} points, {spp} spp, {ks}x{ks} L+R", "name": workload,
+                       "relaunches_in_timed_region": lens.trips.relaunches - r0}}
+
+
+def also_block(args, lens, device):
+    """The other driver-timed lines of the default run (3-5 steps each): the staged SoA chain (HBM-bound kernels), the
+    per-pixel PSF convolution f1 (HBM-bound) and config 4 (rf35mm, the second prescription)."""
+    import copy
+    q = copy.copy(args)
+    q.steps, q.warmup, q.sustain_seconds = 5, 2, 0.0
+    out = {}
+    for name, fn in (("staged", lambda: bench_staged(q, emit=False, lens=lens)),
+                     ("f1", lambda: bench_f1(q, emit=False)),
+                     ("c4", lambda: quick_volume("c4", 5, device))):
+        t0 = time.perf_counter()
+        try:
+            r = fn()
+            keep = ("metric", "value", "unit", "steps", "ms_per_step", "config", "roofline", "kernels_ms", "staged")
+            out[name] = {k: r[k] for k in keep if k in r}
+        except Exception as e:       # a broken side line must not cost the headline
+            out[name] = {"error": f"{type(e).__name__}: {e}"}
+        out[name]["wall_s"] = time.perf_counter() - t0
+        torch.cuda.synchronize(device)
+    return out
 
 
 def bench_tcp(args):
@@ -492,6 +559,8 @@ def main():
                          "beside `value` either way)")
     ap.add_argument("--gather", action="store_true", help="(default; kept for older scripts)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true",
+                    help="default c2 run at N = 1: skip the `also` block (staged SoA chain, f1, c4: a few steps each)")
     ap.add_argument("--sustain-seconds", type=float, default=20.0,
                     help="after the K timed steps, keep stepping for this long and report "
                          "ms_per_step_sustained (0 = skip); long enough for a 5-second GPU-activity "
@@ -501,6 +570,7 @@ def main():
                          "convolution of a 512x768 frame (render_psf.py:120-155); tcp: the reference's own "
                          "timing harness PSFNet.time_compare_psf (psfnet.py:570-586); staged: the reference's own "
                          "call sequence sample -> trace -> propagate -> forward_integral on SoA rays in HBM")
+    ap.add_argument("--staged-ks", default="65,21", help="--workload staged: the grid sizes to run the chain for")
     args = ap.parse_args()
     if args.workload in EXTRA_WORKLOADS:
         assert args.gpus == 1, f"--workload {args.workload} is a single-GPU measurement"
@@ -771,8 +841,12 @@ def main():
             res["ms_per_step_sustained"] = dt_sus / k_sus * 1e3
             res["value_sustained"] = n_total * SPP * k_sus / dt_sus
             res["sustained_steps"] = k_sus
+        pupil_last = lens.last_pupil_points
+        if world == 1 and args.workload == "c2" and not args.no_also:
+            del out_bufs[1:]                    # 4.4 GB of PSF buffers the side lines do not need
+            res["also"] = also_block(args, lens, device)
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(lens, points_all, lens.last_pupil_points)
+            res["cpu_baseline"] = cpu_baseline(lens, points_all, pupil_last)
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

@@ -33,14 +33,14 @@
 extern "C" {
 #endif
 
-#define SDIRT_ABI_VERSION 1
+#define SDIRT_ABI_VERSION 2
 #define SDIRT_MAX_SURFACES 64
 #define SDIRT_MAX_AI 8
 #define SDIRT_NEWTON_MAXITER 10 /* deeplens/surfaces.py:26 */
 #define SDIRT_MAX_WAVELENGTHS 3 /* wavelength slots of one fused launch (psf_rgb) */
 #define SDIRT_MAX_KS 141        /* two ks*ks fp32 tiles + 1 KiB of bookkeeping fit in 160 KiB of LDS */
-#define SDIRT_MAX_KS_STAGED 1024 /* sdirt_forward_integral adds into the grids in HBM: no LDS bound (the reference's
-                                   draw_mtf asks for ks 256, optics.py:2056) */
+#define SDIRT_MAX_KS_STAGED 1024 /* sdirt_forward_integral above SDIRT_MAX_KS adds into the grids in HBM: no LDS bound
+                                   (the reference's draw_mtf asks for ks 256, optics.py:2056) */
 
 typedef enum sdirt_status {
     SDIRT_OK = 0,
@@ -75,11 +75,20 @@ typedef struct sdirt_surface_desc {
 /* A lens prescription at ONE wavelength, resident on the device. */
 typedef struct sdirt_lens sdirt_lens;
 
-/* SoA ray bundle: the reference's Ray(o, d, ra, obliq) (deeplens/basics.py:216-245). */
+/* SoA ray bundle: the reference's Ray(o, d, ra, obliq) (deeplens/basics.py:216-245).
+ *
+ * Order in memory.  A bundle of M rays is eight arrays of M floats.  For the [spp, n_points] bundles of the PSF path
+ * (sdirt_sample_rays, sdirt_center_from_rays, sdirt_forward_integral; n_points > 1 in sdirt_rays_from_aos / _to_aos)
+ * the order is POINT-MAJOR: ray (s, n) -- sample s of point n, the reference's tensor element [s, n] -- is element
+ * n * spp + s: the rays of one point are contiguous.  Sampling, tracing and propagation are per-ray and read / write
+ * every array front to back whatever the order; the per-point reductions (centroid, splat) then read each point's
+ * rays as one contiguous run, which the reference's own [spp, n_points] order would scatter at a stride of
+ * n_points floats (measured: 8 to 32 useful bytes per 128-byte line and workgroup, profiles/r04).  The Python
+ * binding presents the reference's [spp, n_points(, 3)] views on top (sdirt_amd/basics.py: Ray). */
 typedef struct sdirt_rays {
-    float* ox; float* oy; float* oz; /* dev, S*N each */
-    float* dx; float* dy; float* dz; /* dev, S*N each, unit length */
-    float* ra;                       /* dev, validity 0/1                      */
+    float* ox; float* oy; float* oz; /* dev, M each */
+    float* dx; float* dy; float* dz; /* dev, M each, unit length */
+    float* ra;                       /* dev, weight (validity 0/1 on traced rays) */
     float* obliq;                    /* dev, product of cos(refraction angles); may be NULL */
 } sdirt_rays;
 
@@ -148,20 +157,22 @@ int sdirt_pupil_samples(const float* u_theta /*dev [S]*/, const float* u_r2 /*de
 
 /* Lensgroup.sample_from_points + Ray.__init__, deeplens/optics.py:479,490-494,
  * deeplens/basics.py:238-245: rays from every point to every pupil sample,
- * normalised; ra = obliq = 1. */
+ * normalised; ra = obliq = 1.  Point-major: ray (s, n) is element n * spp + s. */
 int sdirt_sample_rays(const float* point_obj /*dev [N,3]*/, int64_t n_points,
                       const float* x2 /*dev [S]*/, const float* y2 /*dev [S]*/, int64_t spp,
                       double pupil_z, sdirt_rays rays, void* stream);
 
 /* Ray.__init__, deeplens/basics.py:233-245: build a ray bundle from the
  * reference's AoS tensors o,d [M,3] (d is L2-normalised with eps 1e-12 when
- * normalize != 0); ra (dev [M]) may be NULL (= all ones); obliq is set to 1. */
+ * normalize != 0); ra (dev [M]) may be NULL (= all ones); obliq is set to 1.
+ * n_points <= 1: ray j of the tensors is element j of the bundle.  n_points > 1: the tensors are the reference's
+ * [spp, n_points, 3] (spp = n_rays / n_points; ra [spp, n_points]) and the bundle is point-major. */
 int sdirt_rays_from_aos(const float* o /*dev [M,3]*/, const float* d /*dev [M,3]*/,
-                        const float* ra /*dev [M] or NULL*/, int64_t n_rays, int32_t normalize,
+                        const float* ra /*dev [M] or NULL*/, int64_t n_rays, int64_t n_points, int32_t normalize,
                         sdirt_rays rays, void* stream);
 
-/* Inverse view for callers that read ray.o / ray.d as [..., 3] tensors. */
-int sdirt_rays_to_aos(sdirt_rays rays, int64_t n_rays, float* o /*dev [M,3] or NULL*/,
+/* Inverse view for callers that read ray.o / ray.d as [..., 3] tensors (n_points as above). */
+int sdirt_rays_to_aos(sdirt_rays rays, int64_t n_rays, int64_t n_points, float* o /*dev [M,3] or NULL*/,
                       float* d /*dev [M,3] or NULL*/, void* stream);
 
 /* Lensgroup.trace / _forward_tracing / _backward_tracing,
@@ -191,16 +202,17 @@ int sdirt_trace(const sdirt_lens* lens, int32_t first, int32_t last, int32_t bac
 int sdirt_propagate_to(double z, sdirt_rays rays, int64_t n_rays, void* stream);
 
 /* Centroid part of Lensgroup.psf_center, deeplens/optics.py:902-904:
- * center[n] = -(sum_s o*ra / (sum_s ra + 1e-9)).xy;  any_valid (dev int32,
- * zeroed by caller, may be NULL) is set to 1 if any ray has ra == 1. */
+ * center[n] = -(sum_s o*ra / (sum_s ra + 1e-9)).xy (sums in float64);  any_valid (dev int32,
+ * zeroed by caller, may be NULL) is set to 1 if any ray has ra == 1.  Point-major bundle. */
 int sdirt_center_from_rays(sdirt_rays rays, int64_t spp, int64_t n_points,
                            float* center /*dev [N,2]*/, int32_t* any_valid /*dev*/, void* stream);
 
 /* forward_integral + assign_points_to_pixels_small_r / _big_r,
  * deeplens/monte_carlo.py:9-68, 135-240, 242-372: sensor-plane rays -> RAW left
- * and right grids [N,ks,ks] (fully overwritten).  r_grid may be NULL.
- * ps = pixel size; center = pointc_ref [N,2].  ks up to SDIRT_MAX_KS_STAGED (the fused sdirt_psf_* entries
- * keep a point's grids in LDS and stop at SDIRT_MAX_KS; the staged chain sample -> trace -> chief centre ->
+ * and right grids [N,ks,ks] (fully overwritten).  r_grid may be NULL.  Point-major bundle (ray (s, n) = element
+ * n * spp + s).  ps = pixel size; center = pointc_ref [N,2].  ks up to SDIRT_MAX_KS_STAGED: up to SDIRT_MAX_KS a
+ * point's grids are summed in LDS (in float64 up to ks 99) and written once, above that they are added to in HBM
+ * (the fused sdirt_psf_* entries stop at SDIRT_MAX_KS; the staged chain sample -> trace -> chief centre ->
  * forward_integral -> normalize is the path for larger grids). */
 int sdirt_forward_integral(sdirt_rays rays, int64_t spp, int64_t n_points, double ps, int32_t ks,
                            const float* center /*dev [N,2]*/, const sdirt_dp_params* dp /*host*/,

@@ -11,6 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # SDIRT_AMD_LIB overrides the path (kernel-variant A/B runs in tools/kbench.py only)
 LIB_PATH = os.environ.get("SDIRT_AMD_LIB") or os.path.join(HERE, "libsdirt_dp.so")
 
+ABI_VERSION = 2          # SDIRT_ABI_VERSION of include/sdirt_dp.h this binding was written against
 MAX_SURFACES = 64
 MAX_AI = 8
 NEWTON_MAXITER = 10
@@ -60,8 +61,8 @@ SIGNATURES = {
     "sdirt_points_to_object": (C.c_int, [_P, _I64, _D, _D, _D, _D, _P, _P]),
     "sdirt_pupil_samples": (C.c_int, [_P, _P, _I64, _D, _P, _P, _P]),
     "sdirt_sample_rays": (C.c_int, [_P, _I64, _P, _P, _I64, _D, Rays, _P]),
-    "sdirt_rays_from_aos": (C.c_int, [_P, _P, _P, _I64, _I32, Rays, _P]),
-    "sdirt_rays_to_aos": (C.c_int, [Rays, _I64, _P, _P, _P]),
+    "sdirt_rays_from_aos": (C.c_int, [_P, _P, _P, _I64, _I64, _I32, Rays, _P]),
+    "sdirt_rays_to_aos": (C.c_int, [Rays, _I64, _I64, _P, _P, _P]),
     "sdirt_trace": (C.c_int, [_P, _I32, _I32, _I32, C.POINTER(_I32), _U32, Rays, _I64, _P, _P]),
     "sdirt_propagate_to": (C.c_int, [_D, Rays, _I64, _P]),
     "sdirt_center_from_rays": (C.c_int, [Rays, _I64, _I64, _P, _P, _P]),
@@ -173,7 +174,7 @@ def lib():
         except OSError as e:      # pragma: no cover
             raise SdirtError(f"cannot load {LIB_PATH}: {e}") from e
         wrapped = _Library(h)
-        if wrapped.sdirt_abi_version() != 1:
+        if wrapped.sdirt_abi_version() != ABI_VERSION:
             raise SdirtError("libsdirt_dp.so ABI version mismatch; rebuild")
         _lib = wrapped
     return _lib

@@ -133,7 +133,7 @@ class Ray:
         ra_d = None
         if ra is not None:
             ra_d = ra.to(device=device, dtype=torch.float32).expand(self.shape).contiguous()
-        _lib.check(_lib.lib().sdirt_rays_from_aos(dptr(o), dptr(d), dptr(ra_d), self.numel, 1,
+        _lib.check(_lib.lib().sdirt_rays_from_aos(dptr(o), dptr(d), dptr(ra_d), self.numel, self._n_points(), 1,
                                                   self.c_rays(), stream_ptr(device)))
         if obliq is not None:
             self.obliq = obliq
@@ -151,7 +151,7 @@ class Ray:
         ra_d = None
         if ra is not None:
             ra_d = ra.to(device=device, dtype=torch.float32).expand(self.shape).contiguous()
-        _lib.check(_lib.lib().sdirt_rays_from_aos(dptr(o), dptr(d), dptr(ra_d), self.numel, 0,
+        _lib.check(_lib.lib().sdirt_rays_from_aos(dptr(o), dptr(d), dptr(ra_d), self.numel, self._n_points(), 0,
                                                   self.c_rays(), stream_ptr(device)))
         return self
 
@@ -171,6 +171,23 @@ class Ray:
         self._init_empty(shape, wvln, device if device is not None else default_device())
         return self
 
+    def _n_points(self):
+        """Order of the rays in `soa` (include/sdirt_dp.h, sdirt_rays): a 2-D bundle [spp, N] -- the shape of every
+        bundle on the PSF path -- is stored POINT-MAJOR, ray (s, n) at n * spp + s, so that the per-point
+        reductions (centroid, splat) read each point's rays as one contiguous run; bundles of any other rank are
+        stored in the row-major order of their shape.  -> N for the former, 1 for the latter."""
+        return self.shape[1] if len(self.shape) == 2 else 1
+
+    def _field(self, row):
+        """Row `row` of the SoA buffer as a tensor of the reference's shape (a view: writes go through)."""
+        flat = self.soa[row, :self.numel]
+        if len(self.shape) == 2:
+            return flat.view(self.shape[1], self.shape[0]).t()
+        return flat.view(self.shape)
+
+    def _set_field(self, row, v):
+        self._field(row).copy_(v.to(self.device, torch.float32).expand(self.shape))
+
     def c_rays(self):
         base, stride = self.soa.data_ptr(), self.soa.stride(0) * 4
         return _lib.Rays(*[C.c_void_p(base + i * stride) for i in range(8)])
@@ -179,13 +196,14 @@ class Ray:
     def _aos(self, which):
         out = torch.empty(self.shape + (3,), dtype=torch.float32, device=self.device)
         args = (dptr(out), None) if which == "o" else (None, dptr(out))
-        _lib.check(_lib.lib().sdirt_rays_to_aos(self.c_rays(), self.numel, *args,
+        _lib.check(_lib.lib().sdirt_rays_to_aos(self.c_rays(), self.numel, self._n_points(), *args,
                                                 stream_ptr(self.device)))
         return out
 
     def _set_aos(self, row0, value):
         v = value.to(device=self.device, dtype=torch.float32).expand(self.shape + (3,))
-        self.soa[row0:row0 + 3].copy_(v.reshape(-1, 3).t())
+        for c in range(3):
+            self._field(row0 + c).copy_(v[..., c])
 
     @property
     def o(self):
@@ -205,19 +223,19 @@ class Ray:
 
     @property
     def ra(self):
-        return self.soa[6, :self.numel].view(self.shape)
+        return self._field(6)
 
     @ra.setter
     def ra(self, v):
-        self.soa[6, :self.numel].copy_(v.to(self.device, torch.float32).expand(self.shape).reshape(-1))
+        self._set_field(6, v)
 
     @property
     def obliq(self):
-        return self.soa[7, :self.numel].view(self.shape)
+        return self._field(7)
 
     @obliq.setter
     def obliq(self, v):
-        self.soa[7, :self.numel].copy_(v.to(self.device, torch.float32).expand(self.shape).reshape(-1))
+        self._set_field(7, v)
 
     @property
     def en(self):          # never modified on this path (basics.py:239)

@@ -74,10 +74,9 @@ static SplatBlock make_splat_block(const SplatGeom& g, const DevDpParams& p)
     return b;
 }
 
-// forward_integral on SoA [S,N] rays, grids too large for LDS (ks > SDIRT_MAX_KS; the one caller is a plot that
-// traces three points): one thread per ray, contributions added to the pre-zeroed [N,ks,ks] grids in HBM with
-// global float atomics.  Consecutive lanes are consecutive POINTS, the worst shape for these atomics (64 tiles
-// per wave instruction) -- every grid that fits LDS takes k_forward_integral_tiles below instead.
+// forward_integral on a point-major SoA bundle, grids too large for LDS (ks > SDIRT_MAX_KS; the one caller is a
+// plot that traces three points): one thread per ray, contributions added to the pre-zeroed [N,ks,ks] grids in HBM
+// with global float atomics (the 64 adds of a wave instruction fall into ONE tile).
 __global__ void __launch_bounds__(kBlock)
 k_forward_integral_hbm(sdirt_rays R, int64_t S, int64_t N, SplatGeom gm, DevDpParams dp,
                        const float* __restrict__ center, float* __restrict__ lg,
@@ -87,7 +86,7 @@ k_forward_integral_hbm(sdirt_rays R, int64_t S, int64_t N, SplatGeom gm, DevDpPa
     const int64_t tile = (int64_t)gm.ks * gm.ks;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M;
          i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t n = i % N;
+        const int64_t n = i / S;
         SplatTaps tp;
         if (!splat_taps(gm, R.ox[i], R.oy[i], center[2 * n], center[2 * n + 1], R.ra[i], tp))
             continue;
@@ -110,34 +109,32 @@ k_forward_integral_hbm(sdirt_rays R, int64_t S, int64_t N, SplatGeom gm, DevDpPa
     }
 }
 
-// forward_integral on SoA [S,N] rays with the grids in LDS (monte_carlo.py:9-68 for every ks <= SDIRT_MAX_KS).
+// forward_integral on a point-major SoA bundle with the grids in LDS (monte_carlo.py:9-68 for every ks <=
+// SDIRT_MAX_KS).
 //
-// A workgroup OWNS P consecutive points (a power of two, chosen by the launcher: as many as LDS holds while the
-// grid still covers the chip) and a slice of the spp axis: their L/R tiles live in LDS for the whole kernel (no
-// global atomics, no memset, each tile stored once, coalesced) -- or, when the few points of a call are cut along
-// spp (nsplit > 1), added once per workgroup to the zeroed output.
+// A workgroup OWNS P consecutive points (one, unless a point has fewer samples than the workgroup has threads)
+// and a slice of the spp axis: their L/R tiles live in LDS for the whole kernel (no global atomics, no memset,
+// each tile stored once, coalesced) -- or, when the few points of a call are cut along spp (nsplit > 1), added
+// once per workgroup to the zeroed output.  Thread t works on sample t % rp of point t / rp (rp = 1024 / P): a wave
+// reads 64 consecutive samples of one point, 256 contiguous bytes per component (sample-major bundles, the
+// reference's tensor order, gave a workgroup 8 to 32 useful bytes of every 128-byte line: 44.8 M L2 requests and
+// 352 us for the 16.8 M rays of the staged bench at ks 65, profiles/r04/staged_pmc_sample_major.json).
 //
 // The tiles are DOUBLES whenever two of them fit (ks <= 99): on gfx950 one ds_add_f32 wave instruction occupies the
 // LDS for ~193 cycles whatever its addresses (it is executed lane by lane), ds_add_f64 for 17-30 and ds_add_u64 for
 // 8-20 (tools/lds_atomic_bench.hip, profiles/r04/lds_atomic_bench*.txt) -- with eight adds per ray the fp32 form
 // IS the kernel's time (350 of 350 us on 8.4 M rays).  A double sum rounded once on the way out is also nearer to
 // the reference's sequential fp32 sum's exact value than any fp32 summation order, and takes any weight `ra`.
-//
-// Thread t works on point t % P of row t / P: a wave instruction reads 64 / P rows x (P x 4) contiguous bytes per
-// component.  What one workgroup uses of a 128-byte line is P x 4 bytes; the rest belongs to the 32 / P
-// neighbouring workgroups, which the block index -> point-group map below places on the SAME XCD at the same
-// time, so the line comes out of HBM once and the neighbours read it from that XCD's L2 (blocks b, b + 8, b + 16
-// ... share an XCD).  The rays of the next pass are loaded before the current pass is splatted.
 #ifndef FI_DEPTH
-#define FI_DEPTH 4
+#define FI_DEPTH 2
 #endif
 constexpr int kFiThreads = 1024;
 constexpr int kFiDepth = FI_DEPTH;      // passes whose rays are in flight
 struct FiLaunch {
-    int P, logP;          // points per workgroup
+    int P, logRp;         // points per workgroup; log2(samples per pass and point = kFiThreads / P)
     int ngroups;          // ceil(N / P)
     int nsplit;           // slices of the spp axis
-    int64_t chunk;        // rows per slice, a multiple of kFiThreads / P
+    int64_t chunk;        // samples per slice, a multiple of kFiThreads / P
     int stride;           // accumulators per point in LDS: (ntile * ks * ks) | 1, odd -> the same pixel of different
                           // points never shares a bank
 };
@@ -149,13 +146,9 @@ k_forward_integral_tiles(sdirt_rays R, int64_t S, int64_t N, SplatGeom gm, DevDp
     extern __shared__ __attribute__((aligned(16))) unsigned char fi_lds[];
     ACC* __restrict__ fi_tiles = reinterpret_cast<ACC*>(fi_lds);
     const int tile = gm.ks * gm.ks;
-    // XCD-aware block -> work map: XCD x = b % 8 gets the contiguous range of logical ids
-    // [x q + min(x, r), ...) (q, r = nblocks / 8, nblocks % 8: bijective for every grid size)
-    const uint32_t nb = gridDim.x, b = blockIdx.x;
-    const uint32_t q = nb >> 3, rem = nb & 7u, x = b & 7u;
-    const uint32_t lb = x * q + min(x, rem) + (b >> 3);
-    const int g = (int)(lb / (uint32_t)fl.nsplit), j = (int)(lb - (uint32_t)g * fl.nsplit);
-    const int p = threadIdx.x & (fl.P - 1), row = threadIdx.x >> fl.logP, rp = kFiThreads >> fl.logP;
+    const int g = (int)(blockIdx.x / (uint32_t)fl.nsplit), j = (int)(blockIdx.x - (uint32_t)g * fl.nsplit);
+    const int rp = 1 << fl.logRp;
+    const int p = threadIdx.x >> fl.logRp, row = threadIdx.x & (rp - 1);
     const int64_t n = (int64_t)g * fl.P + p;
     const bool have_pt = n < N;
     for (int i = threadIdx.x; i < fl.P * fl.stride; i += kFiThreads) fi_tiles[i] = (ACC)0;
@@ -167,15 +160,13 @@ k_forward_integral_tiles(sdirt_rays R, int64_t S, int64_t N, SplatGeom gm, DevDp
     const auto div_dy = UDiv<Lean>::make(gm.dy_rng), div_dx = UDiv<Lean>::make(gm.dx_rng);
     const auto div_fmh = UDiv<Lean>::make(dp.fmh);
     const int64_t s_begin = (int64_t)j * fl.chunk, s_end = min(S, s_begin + fl.chunk);
-    const int npass = (int)((s_end - s_begin + rp - 1) / rp);     // the same for every thread: no vote, no barrier
+    const int npass = (int)((s_end - s_begin + rp - 1) >> fl.logRp);     // the same for every thread: no vote, no barrier
     int64_t s = s_begin + row;
-    int64_t i = s * N + n;
-    const int64_t di = (int64_t)rp * N;
-    // The rays of the next kFiDepth passes are in flight while one pass is splatted (a pass of a 1024-thread
-    // workgroup is ~2 k cycles of vector work, an HBM miss under load several times that).  Every thread loads on
-    // every pass -- lanes without a ray read element 0 and ignore it -- so that the number of loads in flight is
-    // the same on every path: the compiler then waits with a counted s_waitcnt vmcnt(5 (kFiDepth - 1)) for exactly
-    // the set it is about to use (a predicated prefetch forces vmcnt(0) right behind its own issue).
+    int64_t i = (have_pt ? n : 0) * S + s;
+    // The rays of the next kFiDepth passes are in flight while one pass is splatted.  Every thread loads on every
+    // pass -- lanes without a ray read element 0 and ignore it -- so that the number of loads in flight is the same on
+    // every path: the compiler then waits with a counted s_waitcnt vmcnt for exactly the set it is about to use (a
+    // predicated prefetch forces vmcnt(0) right behind its own issue).
     float vox[kFiDepth], voy[kFiDepth], vdx[kFiDepth], vdz[kFiDepth], vra[kFiDepth];
     bool vcur[kFiDepth];
 #pragma unroll
@@ -183,7 +174,7 @@ k_forward_integral_tiles(sdirt_rays R, int64_t S, int64_t N, SplatGeom gm, DevDp
         vcur[k] = have_pt && s < s_end;
         const int64_t il = vcur[k] ? i : 0;
         vox[k] = R.ox[il]; voy[k] = R.oy[il]; vdx[k] = R.dx[il]; vdz[k] = R.dz[il]; vra[k] = R.ra[il];
-        s += rp; i += di;
+        s += rp; i += rp;
     }
     for (int pass = 0; pass < npass; pass += kFiDepth) {
 #pragma unroll
@@ -193,7 +184,7 @@ k_forward_integral_tiles(sdirt_rays R, int64_t S, int64_t N, SplatGeom gm, DevDp
             vcur[k] = have_pt && s < s_end;
             const int64_t il = vcur[k] ? i : 0;
             vox[k] = R.ox[il]; voy[k] = R.oy[il]; vdx[k] = R.dx[il]; vdz[k] = R.dz[il]; vra[k] = R.ra[il];
-            s += rp; i += di;
+            s += rp; i += rp;
             SplatTaps tp;
             if (cur && splat_taps(gm, div_dy, div_dx, ox, oy, cx, cy, ra, tp)) {
                 const float x_tan = (-dx) / dz;              // monte_carlo.py:48
@@ -655,7 +646,7 @@ k_psf_lr(SplatBlock sb /* kernarg offset 0 */, TripSet trips /* 64 */, TripSet t
 // ---------------------------------------------------------------------------
 extern "C" {
 
-// How k_forward_integral_tiles is launched for N points x S rows on grids of ks x ks (ntile of them per point,
+// How k_forward_integral_tiles is launched for N points x S samples on grids of ks x ks (ntile of them per point,
 // `acc` bytes per accumulator).  false: the grids do not fit LDS.
 static bool plan_forward_integral(int64_t N, int64_t S, int ks, int ntile, size_t acc, int ncu, FiLaunch& fl)
 {
@@ -663,19 +654,19 @@ static bool plan_forward_integral(int64_t N, int64_t S, int ks, int ntile, size_
     fl.stride = (ntile * ks * ks) | 1;
     const size_t per_point = acc * (size_t)fl.stride;
     if (per_point > lds_max) return false;
+    // one point per workgroup unless a point has fewer samples than the workgroup has threads (whole waves per
+    // point: at most 16 points), and never more than LDS holds
     int P = 1;
-    while (P < 64 && (size_t)(2 * P) * per_point <= lds_max) P *= 2;
-    // fewer points per workgroup while the grid would leave CUs without one
-    while (P > 1 && (N + P - 1) / P < ncu) P /= 2;
-    if (const char* e = getenv("SDIRT_FI_P")) { const int v = atoi(e); if (v >= 1 && v <= P) P = v; }   // EXPERIMENT
+    while (P < 16 && (int64_t)(kFiThreads / (2 * P)) >= S) P *= 2;
+    while (P > 1 && (size_t)P * per_point > lds_max) P /= 2;
     fl.P = P;
-    fl.logP = 0;
-    while ((1 << fl.logP) < P) ++fl.logP;
-    fl.ngroups = (int)((N + P - 1) / P);
     const int rp = kFiThreads / P;
+    fl.logRp = 0;
+    while ((1 << fl.logRp) < rp) ++fl.logRp;
+    fl.ngroups = (int)((N + P - 1) / P);
     // few points: cut the spp axis as well, at least two passes per slice
     int64_t nsplit = 1;
-    if (fl.ngroups < ncu) nsplit = std::min<int64_t>((ncu + fl.ngroups - 1) / fl.ngroups, std::max<int64_t>(1, S / (2 * rp)));
+    if (fl.ngroups < 2 * ncu) nsplit = std::min<int64_t>((2 * ncu + fl.ngroups - 1) / fl.ngroups, std::max<int64_t>(1, S / (2 * rp)));
     int64_t chunk = (S + nsplit - 1) / nsplit;
     chunk = std::max<int64_t>(rp, (chunk + rp - 1) / rp * rp);
     fl.chunk = chunk;

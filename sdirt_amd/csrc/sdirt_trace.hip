@@ -84,31 +84,30 @@ __global__ void k_pupil_samples(const float* __restrict__ ut, const float* __res
     y2[s] = r * (float)__ocml_sin_f64((double)theta);
 }
 
-// sample_from_points (optics.py:486-494) into SoA [S,N] rays: a pure streaming WRITE (32 bytes per ray against
-// 12 / N + 8 / S read), so the kernel is shaped for the store path.  VEC: every thread makes FOUR consecutive
-// points of one pupil sample (N % 4 == 0, arrays 16-byte aligned) and stores each component as one dwordx4 --
-// a wave instruction writes 1 KiB contiguous; the (s, n) pair is divided out once per thread and then stepped.
+// sample_from_points (optics.py:486-494) into a point-major SoA bundle (ray (s, n) = element n S + s): a pure
+// streaming WRITE (32 bytes per ray against 12 / S + 8 / N read), so the kernel is shaped for the store path.
+// VEC: every thread makes FOUR consecutive samples of one point (S % 4 == 0, arrays 16-byte aligned) and stores
+// each component as one dwordx4 -- a wave instruction writes 1 KiB contiguous; the (n, s) pair is divided out
+// once per thread and then stepped.
 template <bool VEC>
 __global__ void __launch_bounds__(kBlock)
 k_sample_rays(const float* __restrict__ po, int64_t N, const float* __restrict__ x2,
               const float* __restrict__ y2, int64_t S, float pz, sdirt_rays R)
 {
     constexpr int W = VEC ? 4 : 1;
-    const int64_t NQ = N / W, MQ = S * NQ;
+    const int64_t SQ = S / W, MQ = N * SQ;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= MQ) return;
-    int64_t s = q / NQ, nq = q - s * NQ;
-    const int64_t ds = stride / NQ, dn = stride - ds * NQ;
+    int64_t n = q / SQ, sq = q - n * SQ;
+    const int64_t dn = stride / SQ, dsq = stride - dn * SQ;
     for (; q < MQ; q += stride) {
-        const float xs = x2[s], ys = y2[s];
-        const int64_t i = s * N + nq * W;
+        const float px = po[3 * n], py = po[3 * n + 1], pzo = po[3 * n + 2];
+        const int64_t i = n * S + sq * W;
         if (VEC) {
-            // four points = 48 contiguous bytes of the [N,3] table
-            const float4* pp = reinterpret_cast<const float4*>(po + 12 * nq);
-            const float4 a = pp[0], b = pp[1], c = pp[2];
-            const Ray r0 = make_ray(a.x, a.y, a.z, xs, ys, pz), r1 = make_ray(a.w, b.x, b.y, xs, ys, pz),
-                      r2 = make_ray(b.z, b.w, c.x, xs, ys, pz), r3 = make_ray(c.y, c.z, c.w, xs, ys, pz);
+            const float4 xs = *reinterpret_cast<const float4*>(x2 + 4 * sq), ys = *reinterpret_cast<const float4*>(y2 + 4 * sq);
+            const Ray r0 = make_ray(px, py, pzo, xs.x, ys.x, pz), r1 = make_ray(px, py, pzo, xs.y, ys.y, pz),
+                      r2 = make_ray(px, py, pzo, xs.z, ys.z, pz), r3 = make_ray(px, py, pzo, xs.w, ys.w, pz);
             *reinterpret_cast<float4*>(R.ox + i) = make_float4(r0.ox, r1.ox, r2.ox, r3.ox);
             *reinterpret_cast<float4*>(R.oy + i) = make_float4(r0.oy, r1.oy, r2.oy, r3.oy);
             *reinterpret_cast<float4*>(R.oz + i) = make_float4(r0.oz, r1.oz, r2.oz, r3.oz);
@@ -118,34 +117,44 @@ k_sample_rays(const float* __restrict__ po, int64_t N, const float* __restrict__
             *reinterpret_cast<float4*>(R.ra + i) = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
             if (R.obliq) *reinterpret_cast<float4*>(R.obliq + i) = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
         } else {
-            store_ray(R, i, make_ray(po[3 * nq], po[3 * nq + 1], po[3 * nq + 2], xs, ys, pz));
+            store_ray(R, i, make_ray(px, py, pzo, x2[sq], y2[sq], pz));
         }
-        s += ds; nq += dn;
-        if (nq >= NQ) { nq -= NQ; s += 1; }
+        n += dn; sq += dsq;
+        if (sq >= SQ) { sq -= SQ; n += 1; }
     }
+}
+
+// Element j of the reference's [S, N(, 3)] tensors <-> element of the bundle: the same index for a flat bundle
+// (N <= 1), n S + s for a point-major one.
+__device__ __forceinline__ int64_t soa_index(int64_t j, int64_t S, int64_t N)
+{
+    if (N <= 1) return j;
+    const int64_t s = j / N, n = j - s * N;
+    return n * S + s;
 }
 
 __global__ void k_rays_from_aos(const float* __restrict__ o, const float* __restrict__ d,
-                                const float* __restrict__ ra, int64_t M, int normalize, sdirt_rays R)
+                                const float* __restrict__ ra, int64_t M, int64_t S, int64_t N, int normalize, sdirt_rays R)
 {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M;
-         i += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < M;
+         j += (int64_t)gridDim.x * blockDim.x) {
         Ray r;
-        r.ox = o[3 * i]; r.oy = o[3 * i + 1]; r.oz = o[3 * i + 2];
-        r.dx = d[3 * i]; r.dy = d[3 * i + 1]; r.dz = d[3 * i + 2];
+        r.ox = o[3 * j]; r.oy = o[3 * j + 1]; r.oz = o[3 * j + 2];
+        r.dx = d[3 * j]; r.dy = d[3 * j + 1]; r.dz = d[3 * j + 2];
         if (normalize) normalize3<Ieee>(r.dx, r.dy, r.dz);
-        r.ra = ra ? ra[i] : 1.0f;
+        r.ra = ra ? ra[j] : 1.0f;
         r.ob = 1.0f;
-        store_ray(R, i, r);
+        store_ray(R, soa_index(j, S, N), r);
     }
 }
 
-__global__ void k_rays_to_aos(sdirt_rays R, int64_t M, float* __restrict__ o, float* __restrict__ d)
+__global__ void k_rays_to_aos(sdirt_rays R, int64_t M, int64_t S, int64_t N, float* __restrict__ o, float* __restrict__ d)
 {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        if (o) { o[3 * i] = R.ox[i]; o[3 * i + 1] = R.oy[i]; o[3 * i + 2] = R.oz[i]; }
-        if (d) { d[3 * i] = R.dx[i]; d[3 * i + 1] = R.dy[i]; d[3 * i + 2] = R.dz[i]; }
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < M;
+         j += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = soa_index(j, S, N);
+        if (o) { o[3 * j] = R.ox[i]; o[3 * j + 1] = R.oy[i]; o[3 * j + 2] = R.oz[i]; }
+        if (d) { d[3 * j] = R.dx[i]; d[3 * j + 1] = R.dy[i]; d[3 * j + 2] = R.dz[i]; }
     }
 }
 
@@ -197,27 +206,43 @@ __global__ void __launch_bounds__(kBlock) k_propagate(float z, sdirt_rays R, int
     }
 }
 
-// Centroid over the spp axis with fp64 accumulation; one thread per point so
-// that consecutive lanes read consecutive addresses of the [S,N] arrays.
-__global__ void k_center_from_rays(sdirt_rays R, int64_t S, int64_t N, float* __restrict__ center,
-                                   int32_t* __restrict__ any_valid)
+// Centroid over the spp axis of a point-major bundle: one workgroup per point reads the point's contiguous run,
+// fp64 partial sums per thread (samples s = t, t + 256, ...) reduced in a fixed tree order (deterministic).
+__global__ void __launch_bounds__(kBlock)
+k_center_from_rays(sdirt_rays R, int64_t S, int64_t N, float* __restrict__ center, int32_t* __restrict__ any_valid)
 {
-    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
+    __shared__ double red[3][kBlock];
+    __shared__ int red_any;
+    const int64_t n = blockIdx.x;
+    if (threadIdx.x == 0) red_any = 0;
+    __syncthreads();
     double sx = 0.0, sy = 0.0, sr = 0.0;
     int any = 0;
-    for (int64_t s = 0; s < S; ++s) {
-        const int64_t i = s * N + n;
+    for (int64_t s = threadIdx.x; s < S; s += kBlock) {
+        const int64_t i = n * S + s;
         const float ra = R.ra[i];
         sx += (double)(R.ox[i] * ra);
         sy += (double)(R.oy[i] * ra);
         sr += (double)ra;
         any |= (ra == 1.0f);
     }
-    const float den = (float)sr + (float)1e-9;
-    center[2 * n] = -((float)sx / den);
-    center[2 * n + 1] = -((float)sy / den);
-    if (any_valid && any) atomicOr(any_valid, 1);
+    red[0][threadIdx.x] = sx; red[1][threadIdx.x] = sy; red[2][threadIdx.x] = sr;
+    if (any) red_any = 1;
+    __syncthreads();
+    for (int off = kBlock / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + off];
+            red[1][threadIdx.x] += red[1][threadIdx.x + off];
+            red[2][threadIdx.x] += red[2][threadIdx.x + off];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float den = (float)red[2][0] + (float)1e-9;
+        center[2 * n] = -((float)red[0][0] / den);
+        center[2 * n + 1] = -((float)red[1][0] / den);
+        if (any_valid && red_any) atomicOr(any_valid, 1);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -381,8 +406,8 @@ int sdirt_sample_rays(const float* point_obj, int64_t N, const float* x2, const 
     if (int rc = check_rays(rays)) return rc;
     if (N * S == 0) return SDIRT_OK;
     // streaming kernels: ~8 workgroups per CU, the rest by grid stride (each thread keeps 128 bytes of stores in flight)
-    if (N % 4 == 0 && rays_aligned16(rays) && ((uintptr_t)point_obj & 15) == 0)
-        k_sample_rays<true><<<grid_for(N / 4 * S, kBlock, 2048), kBlock, 0, as_stream(stream)>>>(
+    if (S % 4 == 0 && rays_aligned16(rays) && (((uintptr_t)x2 | (uintptr_t)y2) & 15) == 0)
+        k_sample_rays<true><<<grid_for(S / 4 * N, kBlock, 2048), kBlock, 0, as_stream(stream)>>>(
             point_obj, N, x2, y2, S, (float)pupil_z, rays);
     else
         k_sample_rays<false><<<grid_for(N * S, kBlock), kBlock, 0, as_stream(stream)>>>(
@@ -391,24 +416,24 @@ int sdirt_sample_rays(const float* point_obj, int64_t N, const float* x2, const 
     return SDIRT_OK;
 }
 
-int sdirt_rays_from_aos(const float* o, const float* d, const float* ra, int64_t M, int32_t normalize,
+int sdirt_rays_from_aos(const float* o, const float* d, const float* ra, int64_t M, int64_t N, int32_t normalize,
                         sdirt_rays rays, void* stream)
 {
-    if (!o || !d || M < 0) return fail(SDIRT_ERR_INVALID_ARGUMENT, "bad argument");
+    if (!o || !d || M < 0 || (N > 1 && M % N != 0)) return fail(SDIRT_ERR_INVALID_ARGUMENT, "bad argument");
     if (int rc = check_rays(rays)) return rc;
     if (M == 0) return SDIRT_OK;
-    k_rays_from_aos<<<grid_for(M, kBlock), kBlock, 0, as_stream(stream)>>>(o, d, ra, M, normalize,
+    k_rays_from_aos<<<grid_for(M, kBlock), kBlock, 0, as_stream(stream)>>>(o, d, ra, M, N > 1 ? M / N : M, N, normalize,
                                                                            rays);
     LAUNCH_CHECK();
     return SDIRT_OK;
 }
 
-int sdirt_rays_to_aos(sdirt_rays rays, int64_t M, float* o, float* d, void* stream)
+int sdirt_rays_to_aos(sdirt_rays rays, int64_t M, int64_t N, float* o, float* d, void* stream)
 {
-    if (M < 0) return fail(SDIRT_ERR_INVALID_ARGUMENT, "n_rays < 0");
+    if (M < 0 || (N > 1 && M % N != 0)) return fail(SDIRT_ERR_INVALID_ARGUMENT, "bad argument");
     if (int rc = check_rays(rays)) return rc;
     if (M == 0 || (!o && !d)) return SDIRT_OK;
-    k_rays_to_aos<<<grid_for(M, kBlock), kBlock, 0, as_stream(stream)>>>(rays, M, o, d);
+    k_rays_to_aos<<<grid_for(M, kBlock), kBlock, 0, as_stream(stream)>>>(rays, M, N > 1 ? M / N : M, N, o, d);
     LAUNCH_CHECK();
     return SDIRT_OK;
 }
@@ -464,8 +489,8 @@ int sdirt_center_from_rays(sdirt_rays rays, int64_t S, int64_t N, float* center,
     if (int rc = check_rays(rays)) return rc;
     if (!center || S < 0 || N < 0) return fail(SDIRT_ERR_INVALID_ARGUMENT, "bad argument");
     if (N == 0) return SDIRT_OK;
-    k_center_from_rays<<<grid_for(N, 64, 1 << 30), 64, 0, as_stream(stream)>>>(rays, S, N, center,
-                                                                               any_valid);
+    if (N > (1ll << 30)) return fail(SDIRT_ERR_INVALID_ARGUMENT, "n_points too large");
+    k_center_from_rays<<<(unsigned)N, kBlock, 0, as_stream(stream)>>>(rays, S, N, center, any_valid);
     LAUNCH_CHECK();
     return SDIRT_OK;
 }

@@ -1,8 +1,8 @@
-"""The STAGED ray pipeline (rays in HBM as SoA [spp, N]; deeplens/optics.py:460-494, :638-664,
+"""The STAGED ray pipeline (rays in HBM as a point-major SoA bundle; deeplens/optics.py:460-494, :638-664,
 deeplens/monte_carlo.py:9-68) through the C ABI: the vectorised sample / propagate kernels against their
 one-ray-per-thread forms bit for bit, forward_integral with the grids in LDS against the CPU oracle's splat
-and against the fused kernel, for every launch shape its planner produces (points per workgroup 1..64,
-ragged point counts, the spp axis cut or not, the HBM fallback above SDIRT_MAX_KS)."""
+and against the fused kernel, for every launch shape its planner produces (points per workgroup 1..16,
+ragged point and sample counts, the spp axis cut or not, float tiles and the HBM fallback above SDIRT_MAX_KS)."""
 import ctypes as C
 
 import numpy as np
@@ -44,37 +44,40 @@ def _sample(lens, po, x2, y2, n=None):
     return ray
 
 
-@pytest.mark.parametrize("n", [256, 52])
+@pytest.mark.parametrize("n", [256, 51])
 def test_vectorised_sampler_and_propagate_equal_the_scalar_kernels_bit_for_bit(lens, n):
-    """N % 4 == 0 takes the dwordx4 kernels; the same points as a batch of N + 1 (one more point appended)
-    take the one-ray-per-thread kernels: rows [s, :N] must be the same bits."""
+    """spp % 4 == 0 takes the dwordx4 kernels (four consecutive samples of a point per thread); the same points
+    with the first spp - 1 samples take the one-ray-per-thread kernels: samples [:spp - 1] must be the same bits."""
     spp = 192
-    pts = _points(n + 1)
+    pts = _points(n)
     po = lens._points_to_object(pts)
     x2, y2 = _pupil(lens, spp, 5)
-    a = _sample(lens, po[:n].contiguous(), x2, y2)
-    b = _sample(lens, po, x2, y2)
-    va = a.soa.view(8, spp, n)
-    vb = b.soa.view(8, spp, n + 1)[:, :, :n]
-    assert torch.equal(va.view(torch.int32), vb.contiguous().view(torch.int32))
-    assert torch.all(va[6] == 1) and torch.all(va[7] == 1)
+    a = _sample(lens, po, x2, y2)
+    b = _sample(lens, po, x2[:spp - 1], y2[:spp - 1])
+    assert a.shape == (spp, n) and b.shape == (spp - 1, n)
+    # point-major storage: ray (s, n) is element n * spp + s of every component array
+    assert torch.equal(a.soa[0, :a.numel].view(n, spp).t(), a.o[..., 0])
+
+    def bits(r, k):
+        return torch.stack([r._field(c)[:k] for c in range(8)]).contiguous().view(torch.int32)
+    assert torch.equal(bits(a, spp - 1), bits(b, spp - 1))
+    assert torch.all(a.ra == 1) and torch.all(a.obliq == 1)
     a.propagate_to(-3.25)
     b.propagate_to(-3.25)
-    vb = b.soa.view(8, spp, n + 1)[:, :, :n]
-    assert torch.equal(a.soa.view(8, spp, n).view(torch.int32), vb.contiguous().view(torch.int32))
+    assert torch.equal(bits(a, spp - 1), bits(b, spp - 1))
     # the sampler against its definition (optics.py:486-494): d = normalize(pupil point - o)
-    o = po[:n].double().cpu()
+    o = po.double().cpu()
     tgt = torch.stack([x2.double().cpu()[:, None].expand(spp, n), y2.double().cpu()[:, None].expand(spp, n),
                        torch.full((spp, n), float(np.float32(lens.entrance_pupil()[0])), dtype=torch.float64)], -1)
     d = tgt - o[None]
     d = d / d.norm(dim=-1, keepdim=True)
-    a2 = _sample(lens, po[:n].contiguous(), x2, y2)
+    a2 = _sample(lens, po, x2, y2)
     assert float((a2.d.double().cpu() - d).abs().max()) < 1.5e-7
 
 
 def _oracle_splat(oracle, st, ray, cen, ks, dp, n):
     """forward_integral of point n's rays by the CPU oracle's splat."""
-    soa = ray.soa.view(8, ray.shape[0], ray.shape[1])[:, :, n].cpu().numpy()
+    soa = np.stack([ray._field(c)[:, n].cpu().numpy() for c in range(7)])
     o = np.ascontiguousarray(soa[0:3].T[:, None, :])
     d = np.ascontiguousarray(soa[3:6].T[:, None, :])
     lg, rg = oracle.forward_integral(o, d, np.ascontiguousarray(soa[6][:, None]), st["pixel_size"], ks,
@@ -83,11 +86,12 @@ def _oracle_splat(oracle, st, ray, cen, ks, dp, n):
 
 
 @pytest.mark.parametrize("n,spp,ks,dp", [
-    (300, 1024, 21, DP),          # several points per workgroup, ragged last group, spp axis cut
-    (1100, 256, 9, DP),           # 64 points per workgroup (tiny grids), N % 64 != 0
-    (520, 512, 65, DP),           # LDS-limited: 2 points per workgroup on 135 KB (double accumulators)
+    (300, 1024, 21, DP),          # one point per workgroup, one pass
+    (1100, 200, 9, DP),           # four points per workgroup (fewer samples than threads), N % 4 != 0, ragged rows
+    (520, 512, 65, DP),           # two points per workgroup on 135 KB of double accumulators
+    (130, 50, 65, DP),            # sixteen points would not fit: LDS caps the points per workgroup
     (5, 1024, 120, DP),           # two double tiles no longer fit: float accumulators
-    (3, 4096, 65, DP),            # a handful of points: one per workgroup, many spp slices
+    (3, 4096, 65, DP),            # a handful of points: the spp axis cut into slices, tiles added to the output
     (37, 700, 33, None),          # param_list=None: L only, R stays zero
     (130, 512, 21, (0.78, 1.44, 0.3, 0.6)),   # big-radius microlens branch
     (2, 2048, 150, DP),           # above SDIRT_MAX_KS: grids in HBM
@@ -102,11 +106,10 @@ def test_forward_integral_tiles_match_the_oracle_splat(lens, oracle, n, spp, ks,
     lens.trace2sensor(ray)
     g = torch.Generator().manual_seed(1)
     # centres a little off the spot (the window test gets rays on both sides) and a non-0/1 weight on some rays
-    soa = ray.soa.view(8, spp, n)
-    w = soa[6]
-    cen = torch.stack([-(soa[0] * w).sum(0) / (w.sum(0) + 1e-9), -(soa[1] * w).sum(0) / (w.sum(0) + 1e-9)], 1)
+    w, ox, oy = ray.ra, ray._field(0), ray._field(1)
+    cen = torch.stack([-(ox * w).sum(0) / (w.sum(0) + 1e-9), -(oy * w).sum(0) / (w.sum(0) + 1e-9)], 1)
     cen = (cen + (torch.rand(n, 2, generator=g).to(DEV) - 0.5) * 0.1).contiguous()
-    soa[6] *= torch.where(torch.rand(spp, n, generator=g) < 0.2, 0.625, 1.0).to(DEV)
+    ray.ra = w * torch.where(torch.rand(spp, n, generator=g) < 0.2, 0.625, 1.0).to(DEV)
     lg, rg = forward_integral_lr(ray, lens.pixel_size, ks, cen, None if dp is None else list(dp) + ["l"])
     assert torch.isfinite(lg).all() and torch.isfinite(rg).all()
     if dp is None:
