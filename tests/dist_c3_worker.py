@@ -1,0 +1,54 @@
+"""One rank of tests/test_gpu_dist.py::test_config3_whole_grid_sharded_over_eight_ranks: BASELINE config 3 AS
+STATED -- the 65536-point dense PSFNet grid rendered as ONE batch by 8 ranks (8192 spp, 21x21) -- with the real
+kernels.  The ranks share cuda:0 (the boxes of the pool have one GPU) and talk over gloo; on an 8-GPU node the
+same calls run over RCCL.  Each rank renders its contiguous shard with the pupil points the test wrote to
+`<dir>/pupil.npy`; the per-surface convergence masks are OR-reduced over the ranks before the Newton trip tables
+are verified (sdirt_amd/dist.py), so the tables every rank lands on are those of the whole 65536-point batch
+(deeplens/surfaces.py:547).  The shards are all-gathered; rank 0 writes the volume, the centres and the tables
+to `<dir>/result.npz`.  Exit code 0 = done."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    out_dir = os.environ["SDIRT_C3_DIR"]
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    from conftest import make_lens
+    from sdirt_amd import dist as sd
+
+    ks, dp = 21, (0.78, 1.44, 0.3, 0.5)
+    points = bench.volume_points(world, "c3")            # 32 x 32 x (8 * world) depth planes, z-major
+    n_total = points.shape[0]
+    a, b = sd.shard_bounds(n_total, world)[rank]
+    pupil = [torch.from_numpy(v).to("cuda:0") for v in np.load(os.path.join(out_dir, "pupil.npy"), allow_pickle=True)]
+    lens = make_lens("rf50mm", "cuda:0")
+    sd.ShardedPSF.from_lens(lens, ks, dp=dp)             # installs the mask reduction over the ranks
+    cen = torch.empty((b - a, 2), dtype=torch.float32, device="cuda:0")
+    L, R = lens.psf_lr(points[a:b], ks=ks, dp=dp, pupil_xy=(pupil[0], pupil[1]),
+                       center_pupil_xy=(pupil[2], pupil[3]), center_out=cen)
+    full = sd.all_gather_shards(torch.stack((L, R), dim=1), n_total, world)
+    cen_all = sd.all_gather_shards(cen, n_total, world)
+    tables = {"psf": lens.trips.cache[("psf", 0.589, "lean")].tolist(), "center": lens.trips.cache[("center", "lean")].tolist()}
+    gathered = [None] * world
+    dist.all_gather_object(gathered, tables)
+    assert all(t == gathered[0] for t in gathered), f"ranks verified different trip tables: {gathered}"
+    if rank == 0:
+        np.savez(os.path.join(out_dir, "result.npz"), L=full[:, 0].cpu().numpy(), R=full[:, 1].cpu().numpy(),
+                 center=cen_all.cpu().numpy(), trips_psf=np.asarray(tables["psf"]), trips_center=np.asarray(tables["center"]),
+                 launches=lens.trips.launches, relaunches=lens.trips.relaunches)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
