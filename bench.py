@@ -11,10 +11,12 @@ verification of the batch-global Newton trip counts (of step i while step i+1 ru
 the ranks share the pupil sample set (48 KB broadcast) and the trip check (mask all-reduce), and
 the PSF shards are all-gathered to every rank over RCCL (north_star's reassembly step; on a side
 stream under the next step's kernels) -- `value` includes it, `value_no_gather` is the rate of the
-same loop without it.  Weak scaling: every rank renders its own 16384-point slab of a
-32x32x(16*N) volume.
+same loop without it; `gather` carries the bytes a rank receives per step, the all-gather's own time on its stream
+and `gather_bound` (does it take longer than the kernel it hides under?).  Weak scaling (default): every rank
+renders its own 16384-point slab of a 32x32x(16*N) volume; `--scaling strong`: the ONE 16384-point volume (c3:
+65536 points) cut into N contiguous shards.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1: starts its own N ranks)
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--scaling weak|strong]   (N > 1: starts its own N ranks)
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
 Rank 0 prints ONE JSON line (see the driver contract); `roofline` describes the
@@ -558,6 +560,10 @@ def main():
                          "ends each step with the whole PSF volume; `value_no_gather` is reported "
                          "beside `value` either way)")
     ap.add_argument("--gather", action="store_true", help="(default; kept for older scripts)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="N > 1: weak (default) = every rank renders its own 16384-point slab of a volume N times as "
+                         "deep; strong = the ONE volume of the workload (c2 / c4: 16384 points, c3: 65536) cut into N "
+                         "contiguous shards")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true",
                     help="default c2 run at N = 1: skip the `also` block (staged SoA chain, f1, c4: a few steps each)")
@@ -606,7 +612,10 @@ def main():
 
     from sdirt_amd import dist as sd
     lens = build_lens(device, wl["lens"], wl["sensor_z"])
-    points_all = volume_points(world, args.workload)
+    strong = args.scaling == "strong"
+    # weak: the volume grows with the ranks (16 -- c3: 8 -- depth planes per GPU); strong: the workload's own volume
+    # (c3 is stated for a node of 8: 64 planes) whatever the number of ranks
+    points_all = volume_points((8 if args.workload.startswith("c3") else 1) if strong else world, args.workload)
     n_total = points_all.shape[0]
     a, b = sd.shard_bounds(n_total, world)[rank]
     points_local = points_all[a:b].to(device)
@@ -633,6 +642,7 @@ def main():
 
     gather_done = [None] * (DEPTH + 1)   # per output buffer set: event of the last gather reading it
     gathers = [0]
+    gather_events = []                   # (start, end) on the comm stream, one pair per step's all-gather
     in_flight = []                       # (PendingPSF, out, slot, ready event | None)
 
     def settle(keep=0):
@@ -654,10 +664,13 @@ def main():
             gathers[0] += 1
             with torch.cuda.stream(comm_stream):
                 comm_stream.wait_event(ready)
+                g0 = torch.cuda.Event(enable_timing=True)
+                g0.record(comm_stream)
                 sd.all_gather_shards(out[0], n_total, world, group=gather_group, out=buf[0])
                 sd.all_gather_shards(out[1], n_total, world, group=gather_group, out=buf[1])
-                done = torch.cuda.Event()
+                done = torch.cuda.Event(enable_timing=True)
                 done.record(comm_stream)
+                gather_events.append((g0, done))
             gather_done[slot] = done
 
     def step(gather):
@@ -721,8 +734,16 @@ def main():
         step(gather_default)
     lens.kernel_events = {}
     relaunch0 = lens.trips.relaunches
+    del gather_events[:]
     dt = timed(args.steps, gather_default)
     relaunches = lens.trips.relaunches - relaunch0
+    # the all-gathers of the timed steps as the comm stream saw them (start = the shards are final and the previous
+    # gather has left the stream, end = every rank's shards have arrived here); MAX over ranks like the wall time
+    gather_ms = None
+    if gather_default and gather_events:
+        gm = torch.tensor([float(np.mean([a_.elapsed_time(b_) for a_, b_ in gather_events]))], dtype=torch.float64, device=device)
+        dist.all_reduce(gm, op=dist.ReduceOp.MAX)
+        gather_ms = float(gm.item())
 
     ev = lens.kernel_events
     lens.kernel_events = None
@@ -788,11 +809,13 @@ def main():
         res = {
             "metric": f"rays/sec {wl['lens']} {KS}x{KS} DP-PSF @{SPP}spp", "value": rays / dt,
             "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak",
+            "world_size": dist.get_world_size() if world > 1 else 1,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "psfs_per_sec": n_total * args.steps / dt,
             "backend": backend,
-            "config": {"workload": wl["desc"].format(gz=GRID_Z * world)
+            "config": {"workload": wl["desc"].format(gz=(64 if args.workload.startswith("c3") else GRID_Z) if strong else GRID_Z * world)
+                                   + (f" cut into {world} shards" if strong and world > 1 else "")
                                    + f", {n_local} points/GPU, {SPP} spp (+2048 chief-ray "
                                    f"rays/point), {KS}x{KS} L+R PSFs, lambda 0.589um, focus 1 m F/4",
                        "name": args.workload,
@@ -834,9 +857,18 @@ def main():
         if dt_ng is not None:
             res["value_no_gather"] = rays / dt_ng
             res["ms_per_step_no_gather"] = dt_ng / args.steps * 1e3
-            gb = 2 * (world - 1) * n_local * KS * KS * 4 / 1e9      # received per rank and step
+            gb = 2 * (n_total - n_local) * KS * KS * 4 / 1e9      # received per rank and step
+            compute_ms = k_ms[dom]
             res["gather"] = {"algo": os.environ.get("SDIRT_GATHER_ALGO", "allgather"),
-                             "gb_received_per_rank_per_step": gb}
+                             "backend": dist.get_backend(gather_group), "world_size": dist.get_world_size(gather_group),
+                             "gb_received_per_rank_per_step": gb,
+                             "ms": gather_ms, "GBps_received_per_rank": gb / (gather_ms * 1e-3) if gather_ms else None,
+                             "compute_ms": compute_ms,
+                             # the gather runs on its own stream under the next step's kernel: it costs the step
+                             # time only when it takes longer than the kernel it hides under
+                             "gather_bound": bool(gather_ms is not None and gather_ms > compute_ms),
+                             "what": "ms = mean HIP-event time of one step's two all-gathers (L, R) on the comm stream in the "
+                                     "timed region, MAX over ranks; compute_ms = this rank's kernel time per step"}
         if dt_sus is not None:
             res["ms_per_step_sustained"] = dt_sus / k_sus * 1e3
             res["value_sustained"] = n_total * SPP * k_sus / dt_sus

@@ -158,6 +158,38 @@ def test_bench_config3_with_eight_ranks_on_one_gpu():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("algo", ["allgather", "direct"])
+def test_bench_strong_scaling_config2_with_eight_ranks_on_one_gpu(algo):
+    """`bench.py --gpus 8 --scaling strong`: config 2's ONE 16384-point volume cut into 8 shards of 2048 points, the
+    554 MB volume all-gathered to every rank (485 MB received per rank and step), with both gather algorithms --
+    on the one GPU of this pool (gloo dry run: the control path is the node's, the numbers mean nothing).  The JSON
+    line carries what makes a real 8-GPU run interpretable: scaling, world size, gather bytes / ms / gather_bound."""
+    env = _env(SDIRT_BENCH_BACKEND="gloo", SDIRT_GATHER_ALGO=algo)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
+                        "--scaling", "strong", "--sustain-seconds", "0"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout + p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 8 and res["world_size"] == 8 and res["scaling"] == "strong"
+    assert res["config"]["points_per_gpu"] == 2048 and res["config"]["name"] == "c2" and res["config"]["gather"] is True
+    assert res["value"] > 0 and res["value_no_gather"] > 0
+    # rays of ONE 16384-point volume per step, whatever the number of ranks
+    assert abs(res["value"] * res["ms_per_step"] * 1e-3 - 16384 * 4096) < 1
+    g = res["gather"]
+    assert g["algo"] == algo and g["world_size"] == 8 and g["backend"] == "gloo"
+    assert abs(g["gb_received_per_rank_per_step"] - 2 * 7 * 2048 * 65 * 65 * 4 / 1e9) < 1e-9
+    assert g["ms"] > 0 and g["compute_ms"] > 0 and isinstance(g["gather_bound"], bool)
+    log = os.environ.get("SDIRT_TEST_LOG_DIR")
+    if log:
+        with open(os.path.join(log, f"bench_gpus8_dryrun_c2_strong_{algo}.log"), "w") as f:
+            f.write(lines[0] + "\n")
+
+
+@pytest.mark.gpu
 def test_rccl_backend_accepts_the_collectives_of_the_multi_gpu_path():
     """tests/rccl_single_rank_worker.py: backend "nccl" (= RCCL) with one rank on the one GPU."""
     env = _env(MASTER_PORT=str(_free_port()))
