@@ -141,19 +141,24 @@ class TripPlanner:
         done = list(done or [])
         tables = [self.initial(k, curved) for k in keys] if not done else done[0][0]
         rounds = max_rounds if max_rounds is not None else 3 * K + 3
+        identity = tuple(order) == tuple(range(K))
+        curved_sig = tuple(bool(c) for c in curved)
         for i in range(rounds):
             masks = done[i][1] if i < len(done) else launch(tables)
             self.launches += 1
             # a caller rendering the same kind of batch over and over reports the same masks for the
-            # same tables: what verify() accepted once it accepts again
-            sig = tuple((tuple(int(x) for x in t), tuple(int(x) for x in m)) for t, m in zip(tables, masks))
-            if sig in self._accepted and tuple(order) == tuple(range(K)):
-                for k, t in zip(keys, tables):
-                    self.learn(k, t)
-                return tables
+            # same tables: what verify() accepted once it accepts again (for the same surface kinds: the
+            # planner outlives edits of the prescription it serves)
+            sig = None
+            if identity:
+                sig = (curved_sig, tuple((tuple(int(x) for x in t), tuple(int(x) for x in m)) for t, m in zip(tables, masks)))
+                if sig in self._accepted:
+                    for k, t in zip(keys, tables):
+                        self.learn(k, t)
+                    return tables
             results = [verify(t, m, order, curved, aggressive=i > 0) for t, m in zip(tables, masks)]
             if all(ok for ok, _ in results):
-                if tuple(order) == tuple(range(K)) and len(self._accepted) < 4096:
+                if sig is not None and len(self._accepted) < 4096:
                     self._accepted.add(sig)
                 for k, t in zip(keys, tables):
                     self.learn(k, t)

@@ -290,8 +290,11 @@ class Lensgroup:
         if dl is None:
             with torch.cuda.device(self.device):
                 dl = _DevLens(self.surfaces, key)
-            self._dev[key] = dl
+            # the handle is only cached -- and handed out -- once the library has passed its self-test on this
+            # prescription: a failed test raises on THIS and on every later call (the failure is remembered per
+            # device and prescription, _selftest_failed), never just on the first
             self._prefetch_selftest(dl.handle)
+            self._dev[key] = dl
         return dl.handle
 
     def _prefetch_selftest(self, handle):
@@ -302,8 +305,11 @@ class Lensgroup:
         math policies; the two must agree bit for bit.  A compiler that moved an instruction into
         the in-flight window would make the prefetching loop trace with stale constants or trip
         counts; then every call on this lens raises instead of returning wrong PSFs.  Draws no random numbers."""
-        if Lensgroup._selftest_done.get((self.device.index, len(self.surfaces))) == self._table_digest():
+        digest = self._table_digest()
+        if Lensgroup._selftest_done.get((self.device.index, len(self.surfaces))) == digest:
             return
+        if (self.device.index, digest) in Lensgroup._selftest_failed:
+            raise _lib.SdirtError(Lensgroup._selftest_failed[(self.device.index, digest)])
         K = len(self.surfaces)
         front, back = self.surfaces[0], self.surfaces[-1]
         n = 16
@@ -323,13 +329,15 @@ class Lensgroup:
                     _lib.check(_lib.lib().sdirt_trace(handle, 0, K, 0 if forward else 1, trips, flags | extra,
                                                       ray.c_rays(), ray.numel, None, stream_ptr(self.device)))
                 if not torch.equal(a.soa.view(torch.int32), b.soa.view(torch.int32)):
-                    raise _lib.SdirtError(
-                        "libsdirt_dp.so self-test failed: the trace loop with prefetched surface constants "
-                        "disagrees with the load-and-wait form (miscompiled surf_issue/surf_wait window?); "
-                        "rebuild with `make -C sdirt_amd/csrc` and check tools/check_prefetch_hazard.py")
-        Lensgroup._selftest_done[(self.device.index, K)] = self._table_digest()
+                    msg = ("libsdirt_dp.so self-test failed: the trace loop with prefetched surface constants "
+                           "disagrees with the load-and-wait form (miscompiled surf_issue/surf_wait window?); "
+                           "rebuild with `make -C sdirt_amd/csrc` and check tools/check_prefetch_hazard.py")
+                    Lensgroup._selftest_failed[(self.device.index, digest)] = msg
+                    raise _lib.SdirtError(msg)
+        Lensgroup._selftest_done[(self.device.index, K)] = digest
 
     _selftest_done = {}
+    _selftest_failed = {}          # (device index, prescription digest) -> message: sticky
 
     def _table_digest(self):
         return hash(tuple((s.kind, float(s.r), float(s.d), float(s.c), float(s.k),
@@ -1153,7 +1161,19 @@ class Lensgroup:
                 raise ValueError("center=False runs no chief-ray pass")
             return self._psf_rgb_uncentred(points, ks, spp, param_list, pupil_xy)
         if pupil_xy is not None or center_pupil_xy is not None:
-            raise ValueError("explicit pupil points need the fused path (center=True)")
+            # not one launch (grids above SDIRT_MAX_KS, or a rank of a sharded run): wavelength by wavelength through
+            # psf_lr, which takes the explicit points of that wavelength on every path
+            if center_pupil_xy is not None and not center:
+                raise ValueError("center=False runs no chief-ray pass")
+            dp, direct = (None, "l") if param_list is None else (tuple(param_list[:4]), param_list[4])
+            psfs = []
+            for i, w in enumerate(WAVE_RGB):
+                lr = self.psf_lr(points, ks=ks, wvln=w, spp=spp, center=center, dp=dp,
+                                 want_r=(param_list is not None and direct != "l"), _default_r_zero=(param_list is None),
+                                 pupil_xy=None if pupil_xy is None else (pupil_xy[0][i], pupil_xy[1][i]),
+                                 center_pupil_xy=None if center_pupil_xy is None else (center_pupil_xy[0][i], center_pupil_xy[1][i]))
+                psfs.append(lr[0] if direct == "l" else lr[1])
+            return torch.stack(psfs, dim=-3)
         psfs = [self.psf_diff(points=points, wvln=w, ks=ks, spp=spp, center=center,
                               param_list=param_list) for w in WAVE_RGB]
         return torch.stack(psfs, dim=-3)

@@ -124,7 +124,7 @@ class PSFNet(Lensgroup):
             self.psfnet.invalidate_packed()
 
     def train_psfnet(self, iters=10000, bs=128, lr=1e-4, spp=2048, evaluate_every=1000,
-                     result_dir="./results/temp", pipelined=None):
+                     result_dir="./results/temp", pipelined=None, figures=True):
         """psfnet.py:101-168: fit the network to PSFs ray-traced on the fly.  AdamW, cosine
         schedule over iters//3, MSE on max-normalised kernels, fp16 autocast + loss scaling on
         the GPU.  Every `evaluate_every` steps: checkpoint + L1/L2 of sum-normalised kernels
@@ -138,8 +138,14 @@ class PSFNet(Lensgroup):
         without reading the inf-check back, and batch i+1 is ray-traced on a second stream
         while step i runs.  Same draws from the RNGs in the same order (prefetching stops at an
         evaluation step, whose test-set draws come first, and resumes after it), same arithmetic
-        per step; `pipelined=False` is the plain loop."""
+        per step; `pipelined=False` is the plain loop.  figures=False: no matplotlib, no iterN.png (the
+        checkpoints and the logged test errors stay); with figures on, matplotlib is imported before the first step,
+        so a missing one fails at the start and not after evaluate_every steps."""
         psfnet = self.psfnet
+        plt = None
+        if figures:
+            from .plots import _pyplot
+            plt = _pyplot()
         psfnet.train()
         on_gpu = torch.device(self.device).type == "cuda"
         pipelined = on_gpu if pipelined is None else (pipelined and on_gpu)
@@ -153,16 +159,15 @@ class PSFNet(Lensgroup):
             with torch.no_grad(), amp():
                 psfnet.eval()
                 # psfnet.py:131-146: five (target, prediction) pairs of the current batch
-                from .plots import _pyplot
-                plt = _pyplot()
-                shown = psfnet(batch_inp[:5]).float().cpu()
-                fig, axs = plt.subplots(5, 2)
-                for j in range(min(5, shown.shape[0])):
-                    axs[j, 0].imshow(batch_psf[j].float().cpu().numpy())
-                    axs[j, 1].imshow(shown[j].numpy())
-                fig.suptitle(f"GT/Pred PSFs at iter {i + 1}")
-                fig.savefig(os.path.join(result_dir, f"iter{i + 1}.png"), dpi=300)
-                plt.close(fig)
+                if plt is not None:
+                    shown = psfnet(batch_inp[:5]).float().cpu()
+                    fig, axs = plt.subplots(5, 2)
+                    for j in range(min(5, shown.shape[0])):
+                        axs[j, 0].imshow(batch_psf[j].float().cpu().numpy())
+                        axs[j, 1].imshow(shown[j].numpy())
+                    fig.suptitle(f"GT/Pred PSFs at iter {i + 1}")
+                    fig.savefig(os.path.join(result_dir, f"iter{i + 1}.png"), dpi=300)
+                    plt.close(fig)
                 torch.save(psfnet.state_dict(),
                            os.path.join(result_dir, f"iter{i + 1}_PSFNet_{self.model_name}.pkl"))
                 inp, psf = self.get_test_data()

@@ -767,3 +767,30 @@ def test_ownership_and_mutation_follow_the_reference(lens):
     assert lens.trace2sensor(ray2) is ray2
     assert float(ray2.ra.sum()) > 0
     assert torch.allclose(ray2.o[..., 2][ray2.ra > 0], torch.tensor(float(lens.d_sensor), device=DEV))
+
+
+def test_a_failed_library_selftest_is_remembered(monkeypatch):
+    """Lensgroup.dev_lens traces a probe bundle with and without the hand-scheduled prefetch when a prescription is
+    first uploaded and refuses the library if the two differ.  The refusal must hold for EVERY later call on that
+    prescription (a caller's retry, a try/except around get_training_data), not only for the first: the handle of a
+    failed test is never cached and the verdict is kept per device and prescription."""
+    from sdirt_amd import _lib, optics
+    lens = make_lens("rf50mm", DEV)
+    monkeypatch.setattr(optics.Lensgroup, "_selftest_done", {})
+    monkeypatch.setattr(optics.Lensgroup, "_selftest_failed", {})
+    healthy = optics.Ray.clone
+
+    def corrupted(self, device=None):
+        c = healthy(self, device)
+        c.soa[0, 0] += 1.0                      # what a prefetch that traced with stale constants would look like
+        return c
+    monkeypatch.setattr(optics.Ray, "clone", corrupted)
+    with pytest.raises(_lib.SdirtError, match="self-test failed"):
+        lens.dev_lens(0.55)
+    assert 0.55 not in lens._dev
+    monkeypatch.setattr(optics.Ray, "clone", healthy)
+    with pytest.raises(_lib.SdirtError, match="self-test failed"):       # the second call raises as well
+        lens.dev_lens(0.55)
+    with pytest.raises(_lib.SdirtError, match="self-test failed"):
+        lens.psf(torch.tensor([0.0, 0.0, -1500.0]), ks=17, spp=256, wvln=0.55)
+    assert 0.55 not in lens._dev
