@@ -381,7 +381,7 @@ def bench_staged(args, emit=True, lens=None, ks_list=None):
             ("trace", lambda: h.sdirt_trace(handle, 0, K, 0, trips_t, flags, ray.c_rays(), M, dptr(mask_t), st)),
             ("propagate_to", lambda: h.sdirt_propagate_to(float(lens.d_sensor), ray.c_rays(), M, st)),
             ("forward_integral", lambda: h.sdirt_forward_integral(ray.c_rays(), S, N, float(lens.pixel_size), ks, dptr(cen),
-                                                                  C.byref(dp), dptr(L), dptr(R), st)),
+                                                                  C.byref(dp), flags, dptr(L), dptr(R), st)),
             ("psf_normalize", lambda: (h.sdirt_psf_normalize(dptr(L), N, ks, st) or h.sdirt_psf_normalize(dptr(R), N, ks, st))),
         ]
 

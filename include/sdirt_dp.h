@@ -216,6 +216,7 @@ int sdirt_center_from_rays(sdirt_rays rays, int64_t spp, int64_t n_points,
  * forward_integral -> normalize is the path for larger grids). */
 int sdirt_forward_integral(sdirt_rays rays, int64_t spp, int64_t n_points, double ps, int32_t ks,
                            const float* center /*dev [N,2]*/, const sdirt_dp_params* dp /*host*/,
+                           uint32_t flags /*SDIRT_PSF_STRICT_IEEE or 0*/,
                            float* l_grid /*dev [N,ks,ks]*/, float* r_grid /*dev or NULL*/,
                            void* stream);
 

@@ -706,8 +706,12 @@ __device__ __forceinline__ float over_r(const DevDpParams& p, float x)
     return p.r_pow2 ? x * p.inv_r : x / p.r;
 }
 
-// monte_carlo.py:169-206 (r <= 0.5); div_fmh(a) = a / fmh
-template <class Div>
+// monte_carlo.py:169-206 (r <= 0.5); div_fmh(a) = a / fmh.
+// M = Lean: the six segment areas through seg_acos (one fused polynomial each).  M = Ieee (SDIRT_PSF_STRICT_IEEE):
+// the reference's LITERAL sequence -- torch.clamp, arccos, u - 1/2 sin(2u) -- with ocml's acos / sin, as
+// dp_weights_big has it: the on-GPU yardstick of the polynomial (tests/test_gpu_parity.py::
+// test_lean_and_literal_subpixel_weights_on_random_geometries).
+template <class M, class Div>
 __device__ __forceinline__ void dp_weights_small(const DevDpParams& p, const Div& div_fmh, float x_tan,
                                                  float& sl, float& sr)
 {
@@ -716,11 +720,30 @@ __device__ __forceinline__ void dp_weights_small(const DevDpParams& p, const Div
     float xr = p.w - div_fmh((fx - p.w) * p.h);
     float xm = div_fmh((-fx) * p.h);
     float xl = (-p.w) - div_fmh((fx + p.w) * p.h);
+    const float hx = p.h * x_tan;
+    if (!M::kFused) {
+        xr = clampf(xr, -r, r); xm = clampf(xm, -r, r); xl = clampf(xl, -r, r);
+        float ur = __ocml_acos_f32(over_r(p, xr)), um = __ocml_acos_f32(over_r(p, xm)), ul = __ocml_acos_f32(over_r(p, xl));
+        float sm = seg(um);
+        const float sr_ml = rr * (sm - seg(ur));
+        const float sl_ml = rr * (seg(ul) - sm);
+        xr = p.w - hx; xm = 0.0f - hx; xl = (-p.w) - hx;
+        xr = clampf(xr, -0.5f, 0.5f); xm = clampf(xm, -0.5f, 0.5f); xl = clampf(xl, -0.5f, 0.5f);
+        const float xri = clampf(xr, -r, r), xmi = clampf(xm, -r, r), xli = clampf(xl, -r, r);
+        ur = __ocml_acos_f32(over_r(p, xri)); um = __ocml_acos_f32(over_r(p, xmi)); ul = __ocml_acos_f32(over_r(p, xli));
+        sm = seg(um);
+        const float sr_in = rr * (sm - seg(ur));
+        const float sl_in = rr * (seg(ul) - sm);
+        const float sr_mg = (xr - xm) * 1.0f - sr_in;
+        const float sl_mg = (xm - xl) * 1.0f - sl_in;
+        sr = sr_ml + sr_mg;
+        sl = sl_ml + sl_mg;
+        return;
+    }
     xr = clamp_finite(xr, -r, r); xm = clamp_finite(xm, -r, r); xl = clamp_finite(xl, -r, r);
     float sm = seg_acos(over_r(p, xm));
     const float sr_ml = rr * (sm - seg_acos(over_r(p, xr)));
     const float sl_ml = rr * (seg_acos(over_r(p, xl)) - sm);
-    const float hx = p.h * x_tan;
     xr = p.w - hx; xm = 0.0f - hx; xl = (-p.w) - hx;
     xr = clamp_finite(xr, -0.5f, 0.5f); xm = clamp_finite(xm, -0.5f, 0.5f); xl = clamp_finite(xl, -0.5f, 0.5f);
     const float xri = clamp_finite(xr, -r, r), xmi = clamp_finite(xm, -r, r), xli = clamp_finite(xl, -r, r);
@@ -735,7 +758,7 @@ __device__ __forceinline__ void dp_weights_small(const DevDpParams& p, const Div
 
 __device__ __forceinline__ void dp_weights_small(const DevDpParams& p, float x_tan, float& sl, float& sr)
 {
-    dp_weights_small(p, UDiv<Ieee>::make(p.fmh), x_tan, sl, sr);
+    dp_weights_small<Lean>(p, UDiv<Ieee>::make(p.fmh), x_tan, sl, sr);
 }
 
 // monte_carlo.py:274-338 (r > 0.5)

@@ -138,7 +138,7 @@ struct FiLaunch {
     int stride;           // accumulators per point in LDS: (ntile * ks * ks) | 1, odd -> the same pixel of different
                           // points never shares a bank
 };
-template <bool HAVE_R, bool BIG, class ACC>
+template <bool HAVE_R, bool BIG, class ACC, class M>
 __global__ void __launch_bounds__(kFiThreads)
 k_forward_integral_tiles(sdirt_rays R, int64_t S, int64_t N, SplatGeom gm, DevDpParams dp, FiLaunch fl,
                          const float* __restrict__ center, float* __restrict__ lg, float* __restrict__ rg)
@@ -157,8 +157,8 @@ k_forward_integral_tiles(sdirt_rays R, int64_t S, int64_t N, SplatGeom gm, DevDp
     const float cx = have_pt ? center[2 * n] : 0.0f, cy = have_pt ? center[2 * n + 1] : 0.0f;
     ACC* __restrict__ tl_ = fi_tiles + p * fl.stride;
     ACC* __restrict__ trr = tl_ + tile;
-    const auto div_dy = UDiv<Lean>::make(gm.dy_rng), div_dx = UDiv<Lean>::make(gm.dx_rng);
-    const auto div_fmh = UDiv<Lean>::make(dp.fmh);
+    const auto div_dy = UDiv<M>::make(gm.dy_rng), div_dx = UDiv<M>::make(gm.dx_rng);
+    const auto div_fmh = UDiv<M>::make(dp.fmh);
     const int64_t s_begin = (int64_t)j * fl.chunk, s_end = min(S, s_begin + fl.chunk);
     const int npass = (int)((s_end - s_begin + rp - 1) >> fl.logRp);     // the same for every thread: no vote, no barrier
     int64_t s = s_begin + row;
@@ -190,7 +190,7 @@ k_forward_integral_tiles(sdirt_rays R, int64_t S, int64_t N, SplatGeom gm, DevDp
                 const float x_tan = (-dx) / dz;              // monte_carlo.py:48
                 float sl, sr;
                 if (BIG) dp_weights_big(dp, x_tan, sl, sr);
-                else dp_weights_small(dp, div_fmh, x_tan, sl, sr);
+                else dp_weights_small<M>(dp, div_fmh, x_tan, sl, sr);
                 atomicAdd(&tl_[tp.i_tl], (ACC)(tp.w_tl * sl));
                 atomicAdd(&tl_[tp.i_tr], (ACC)(tp.w_tr * sl));
                 atomicAdd(&tl_[tp.i_bl], (ACC)(tp.w_bl * sl));
@@ -584,7 +584,7 @@ k_psf_lr(SplatBlock sb /* kernarg offset 0 */, TripSet trips /* 64 */, TripSet t
         const float x_tan = HotMath::div(-dx, dz);
         float sl, sr;
         if (BIG) dp_weights_big(dp, x_tan, sl, sr);      // separate instantiation: the rarely
-        else dp_weights_small(dp, UDiv<HotMath>::make(dp.fmh), x_tan, sl, sr);   // used r > 0.5 branch costs registers
+        else dp_weights_small<HotMath>(dp, UDiv<HotMath>::make(dp.fmh), x_tan, sl, sr);   // used r > 0.5 branch costs registers
         atomicAdd(&tl_[tp.i_tl], tp.w_tl * sl);
         atomicAdd(&tl_[tp.i_tr], tp.w_tr * sl);
         atomicAdd(&tl_[tp.i_bl], tp.w_bl * sl);
@@ -675,7 +675,7 @@ static bool plan_forward_integral(int64_t N, int64_t S, int ks, int ntile, size_
 }
 
 int sdirt_forward_integral(sdirt_rays rays, int64_t S, int64_t N, double ps, int32_t ks,
-                           const float* center, const sdirt_dp_params* dp, float* l_grid,
+                           const float* center, const sdirt_dp_params* dp, uint32_t flags, float* l_grid,
                            float* r_grid, void* stream)
 {
     if (int rc = check_rays(rays)) return rc;
@@ -687,6 +687,7 @@ int sdirt_forward_integral(sdirt_rays rays, int64_t S, int64_t N, double ps, int
     const size_t bytes = sizeof(float) * (size_t)N * ks * ks;
     const DevDpParams dpp = make_dp(dp);
     const bool both = r_grid != nullptr && dpp.have_r;
+    const bool strict = (flags & SDIRT_PSF_STRICT_IEEE) != 0;
     FiLaunch fl;
     int ncu = 0;
     if (int rc = device_cus(&ncu)) return rc;
@@ -706,13 +707,17 @@ int sdirt_forward_integral(sdirt_rays rays, int64_t S, int64_t N, double ps, int
     }
     const size_t lds_bytes = (wide ? sizeof(double) : sizeof(float)) * (size_t)fl.P * fl.stride;
     const unsigned grid = (unsigned)fl.ngroups * (unsigned)fl.nsplit;
-#define SDIRT_LAUNCH_FI_A(HR, BG, AC)                                                             \
+#define SDIRT_LAUNCH_FI_M(HR, BG, AC, MM)                                                         \
     do {                                                                                          \
         if (lds_bytes > 48 * 1024)                                                                \
-            HIP_TRY(hipFuncSetAttribute((const void*)k_forward_integral_tiles<HR, BG, AC>,        \
+            HIP_TRY(hipFuncSetAttribute((const void*)k_forward_integral_tiles<HR, BG, AC, MM>,    \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024)); \
-        k_forward_integral_tiles<HR, BG, AC><<<grid, kFiThreads, lds_bytes, st>>>(                \
+        k_forward_integral_tiles<HR, BG, AC, MM><<<grid, kFiThreads, lds_bytes, st>>>(            \
             rays, S, N, make_geom(ps, ks), dpp, fl, center, l_grid, both ? r_grid : nullptr);     \
+    } while (0)
+#define SDIRT_LAUNCH_FI_A(HR, BG, AC)                                                             \
+    do {                                                                                          \
+        if (strict) SDIRT_LAUNCH_FI_M(HR, BG, AC, Ieee); else SDIRT_LAUNCH_FI_M(HR, BG, AC, Lean); \
     } while (0)
 #define SDIRT_LAUNCH_FI(HR, BG)                                                                   \
     do {                                                                                          \
@@ -724,6 +729,7 @@ int sdirt_forward_integral(sdirt_rays rays, int64_t S, int64_t N, double ps, int
         if (dpp.big) SDIRT_LAUNCH_FI(false, true); else SDIRT_LAUNCH_FI(false, false);
     }
 #undef SDIRT_LAUNCH_FI_A
+#undef SDIRT_LAUNCH_FI_M
 #undef SDIRT_LAUNCH_FI
     LAUNCH_CHECK();
     return SDIRT_OK;

@@ -20,9 +20,17 @@ def _dp(param_list):
     return _lib.DpParams(float(h), float(f), float(w), float(r)), direct
 
 
-def forward_integral_lr(ray, ps, ks, pointc_ref=None, param_list=None):
+def _flags(precision):
+    if precision not in ("lean", "ieee"):
+        raise ValueError("precision must be 'lean' or 'ieee'")
+    return _lib.PSF_STRICT_IEEE if precision == "ieee" else 0
+
+
+def forward_integral_lr(ray, ps, ks, pointc_ref=None, param_list=None, precision="lean"):
     """RAW (l_grid, r_grid), each [N, ks, ks]; r_grid is all-zero when
-    param_list is None exactly as in monte_carlo.py:230-235."""
+    param_list is None exactly as in monte_carlo.py:230-235.  precision='ieee': the reference's literal
+    sequence for the sub-pixel areas (arccos, sin) and the compiler's full-range divisions instead of the
+    fused segment-area polynomial (SDIRT_PSF_STRICT_IEEE)."""
     if len(ray.shape) != 2:
         raise ValueError("ray must have shape [spp, N]")
     S, N = ray.shape
@@ -39,19 +47,19 @@ def forward_integral_lr(ray, ps, ks, pointc_ref=None, param_list=None):
     rg = torch.empty_like(lg)
     _lib.check(_lib.lib().sdirt_forward_integral(
         ray.c_rays(), S, N, float(ps), int(ks), dptr(center),
-        C.byref(dp) if dp is not None else None, dptr(lg), dptr(rg), stream_ptr(dev)))
+        C.byref(dp) if dp is not None else None, _flags(precision), dptr(lg), dptr(rg), stream_ptr(dev)))
     return lg, rg
 
 
-def forward_integral(ray, ps, ks, pointc_ref=None, interpolate=False, param_list=None):
+def forward_integral(ray, ps, ks, pointc_ref=None, interpolate=False, param_list=None, precision="lean"):
     """monte_carlo.py:9-68 -> [N, ks, ks]: the left grid, or the right one when
     param_list[4] != 'l' (the reference returns `psf_l` of a swapped pair, :64,237-240)."""
-    lg, rg = forward_integral_lr(ray, ps, ks, pointc_ref, param_list)
+    lg, rg = forward_integral_lr(ray, ps, ks, pointc_ref, param_list, precision)
     _, direct = _dp(param_list)
     return lg if direct == "l" else rg
 
 
-def _assign(points, ks, x_range, ra, x_tan, param_list, big):
+def _assign(points, ks, x_range, ra, x_tan, param_list, big, precision="lean"):
     if param_list is None:
         r = 0.5
     else:
@@ -77,7 +85,7 @@ def _assign(points, ks, x_range, ra, x_tan, param_list, big):
     center = torch.zeros((1, 2), dtype=torch.float32, device=dev)
     if big and param_list is None:
         param_list = [0.78, 1.44, 0.3, 0.5, "l"]
-    lg, rg = forward_integral_lr(ray, ps, ks, center, param_list)
+    lg, rg = forward_integral_lr(ray, ps, ks, center, param_list, precision)
     lg, rg = lg[0], rg[0]
     direct = "l" if param_list is None else param_list[4]
     return (lg, rg) if direct == "l" else (rg, lg)
@@ -85,10 +93,10 @@ def _assign(points, ks, x_range, ra, x_tan, param_list, big):
 
 def assign_points_to_pixels_small_r(points, ks, x_range, y_range, ra, interpolate=True,
                                     coherent=False, phase=None, d=None, obliq=None, wvln=0.589,
-                                    x_tan=None, param_list=None):
+                                    x_tan=None, param_list=None, precision="lean"):
     """monte_carlo.py:135-240 for one point source: points [spp,2] inside the
     PSF window, ra [spp], x_tan [spp] -> (l_grid, r_grid) [ks,ks]."""
-    return _assign(points, ks, x_range, ra, x_tan, param_list, big=False)
+    return _assign(points, ks, x_range, ra, x_tan, param_list, big=False, precision=precision)
 
 
 def assign_points_to_pixels_big_r(points, ks, x_range, y_range, ra, interpolate=True,

@@ -1047,7 +1047,8 @@ class Lensgroup:
         h, st = _lib.lib(), stream_ptr(self.device)
         with self._timed("forward_integral"):
             _lib.check(h.sdirt_forward_integral(ray.c_rays(), spp, N, float(self.pixel_size), int(ks), dptr(cen),
-                                                C.byref(dpp) if dpp is not None else None, dptr(L), dptr(R), st))
+                                                C.byref(dpp) if dpp is not None else None, self._math_flags(),
+                                                dptr(L), dptr(R), st))
         if normalize:
             for g in (L, R):
                 if g is not None:

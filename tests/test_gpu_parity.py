@@ -375,6 +375,35 @@ def test_splat_on_random_dual_pixel_geometries():
         assert np.abs(r.cpu().numpy() - g[f"r{i}"]).max() <= 2e-6 * scale, (i, dp)
 
 
+def test_lean_and_literal_subpixel_weights_on_random_geometries():
+    """The small-radius sub-pixel areas (monte_carlo.py:169-206) two ways on the GPU, on F13's random (h, f, w, r)
+    sets: precision='lean' = six fused segment-area polynomials per ray (seg_acos), precision='ieee' = the
+    reference's literal clamp / arccos / u - sin(2u)/2 sequence on ocml's acos and sin.  Both against the reference's
+    grids, and against each other: the polynomial's own error (<= 3.1e-7 absolute per area) is what separates them."""
+    from sdirt_amd import assign_points_to_pixels_small_r
+    g = load_golden("f13_splat_fuzz")
+    ks, ps = int(g["ks"]), float(g["ps"])
+    xr = [(-ks / 2 + 0.5) * ps, (ks / 2 - 0.5) * ps]
+    seen = 0
+    for i, dp in enumerate(g["params"]):
+        if dp[3] > 0.5:
+            continue
+        seen += 1
+        out = {}
+        for precision in ("lean", "ieee"):
+            l, r = assign_points_to_pixels_small_r(points=t(g[f"points{i}"]), ks=ks, x_range=xr, y_range=xr, ra=t(g[f"ra{i}"]),
+                                                   x_tan=t(g[f"x_tan{i}"]), param_list=list(dp) + ["l"], precision=precision)
+            out[precision] = (l.cpu().numpy(), r.cpu().numpy())
+        scale = max(g[f"l{i}"].max(), g[f"r{i}"].max())
+        d_ref = {p_: max(np.abs(v[0] - g[f"l{i}"]).max(), np.abs(v[1] - g[f"r{i}"]).max()) / scale for p_, v in out.items()}
+        d_ab = max(np.abs(out["lean"][0] - out["ieee"][0]).max(), np.abs(out["lean"][1] - out["ieee"][1]).max()) / scale
+        print(f"F13 set {i} (h, f, w, r) = {tuple(round(float(v), 4) for v in dp)}: |lean - reference| {d_ref['lean']:.2e}, "
+              f"|literal - reference| {d_ref['ieee']:.2e}, |lean - literal| {d_ab:.2e} of the peak")
+        assert d_ref["lean"] <= 2e-6 and d_ref["ieee"] <= 2e-6, (i, d_ref)
+        assert d_ab <= 1.5e-6, (i, d_ab)
+    assert seen >= 3
+
+
 def _norm(psf):
     return psf / (psf.amax(dim=(1, 2), keepdim=True) + 1e-6)          # optics.py:983-987
 

@@ -33,7 +33,7 @@ for ks in KS:
     L = torch.empty((N, ks, ks), device=dev)
     R = torch.empty_like(L)
     fn = lambda: _lib.check(h.sdirt_forward_integral(ray.c_rays(), S, N, float(lens.pixel_size), ks, dptr(cen),
-                                                     C.byref(dp), dptr(L), dptr(R), st))
+                                                     C.byref(dp), 0, dptr(L), dptr(R), st))
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
