@@ -99,7 +99,8 @@ def test_own_geometric_optics_against_reference_state(name):
     closed-form line intersections) vs the values the reference computed
     (tests/golden/lens_state_*.json).  The reference's pupil is itself only
     reproducible to ~1.3e-5 relative (fp32 lstsq), its refocus depends on the
-    2048 random rays drawn."""
+    2048 random rays drawn -- from the same seed (torch.manual_seed(0), the CPU generator's stream reproduced draw
+    for draw) the sensor lands on the reference's position exactly."""
     from sdirt_amd.psfnet import PSFNet
     st = load_state(name)
     torch.manual_seed(0)
@@ -122,14 +123,22 @@ def test_own_geometric_optics_against_reference_state(name):
     lens.pupil_method = "reference"
     lens._pupil_cache.clear()
     lens.refocus(-1000 + lens.d_sensor)                       # 1_fit_psfnet.py:23-25
-    assert abs(lens.d_sensor - st["d_sensor"]) < 0.05
-    assert abs(lens.hfov / st["hfov"] - 1) < 2e-3
-    assert abs(lens.foclen / st["foclen"] - 1) < 2e-3
-    assert abs(lens.fnum / st["fnum"] - 1) < 2e-3
+    m = dict(d_sensor=abs(lens.d_sensor - st["d_sensor"]), hfov=abs(lens.hfov / st["hfov"] - 1),
+             foclen=abs(lens.foclen / st["foclen"] - 1), fnum=abs(lens.fnum / st["fnum"] - 1))
+    print(name, "after refocus (seed 0): d_sensor", lens.d_sensor, "ref", st["d_sensor"], "MEASURED", m)
+    # measured (MI355X box, EPYC host): 0.0 mm -- the reference's 62.25132751464844 / 81.8495864868164 to the last
+    # fp32 digit -- and 0 / 0 / 8e-8 relative
+    assert m["d_sensor"] < 1e-5
+    assert m["hfov"] < 1e-5
+    assert m["foclen"] < 1e-5
+    assert m["fnum"] < 1e-5
     # with the sensor pinned to the reference's value hfov agrees tightly (same 100 rays)
     lens.d_sensor = st["d_sensor"]
     lens.post_computation()
-    assert abs(lens.hfov / st["hfov"] - 1) < 2e-5
+    m2 = dict(hfov=abs(lens.hfov / st["hfov"] - 1), foclen=abs(lens.foclen / st["foclen"] - 1),
+              fnum=abs(lens.fnum / st["fnum"] - 1))
+    print(name, "sensor pinned: MEASURED", m2)
+    assert m2["hfov"] < 1e-5 and m2["foclen"] < 1e-5 and m2["fnum"] < 1e-5
 
 
 def test_psfnet_data_generators():

@@ -239,7 +239,8 @@ def test_rgb(oracle):
     torch.manual_seed(3)
     psf = lens.psf_rgb(torch.tensor(g["points"]), ks=17, spp=64)
     assert psf.shape == g["psf"].shape
-    assert np.abs(psf.cpu().numpy() - g["psf"]).max() <= 5e-4      # 64 spp, own disc mapping
+    print("test_rgb MEASURED |psf - reference| max", np.abs(psf.cpu().numpy() - g["psf"]).max())
+    assert np.abs(psf.cpu().numpy() - g["psf"]).max() <= 1.2e-4    # measured 3.7e-5: 64 spp, own disc mapping
     # the three wavelengths are ONE launch: its result equals three psf_diff calls on the same draws
     torch.manual_seed(3)
     three = torch.stack([lens.psf_diff(torch.tensor(g["points"]), wvln=w, ks=17, spp=64)
@@ -371,8 +372,9 @@ def test_splat_on_random_dual_pixel_geometries():
         l, r = fn(points=t(g[f"points{i}"]), ks=ks, x_range=xr, y_range=xr, ra=t(g[f"ra{i}"]),
                   x_tan=t(g[f"x_tan{i}"]), param_list=list(dp) + ["l"])
         scale = max(g[f"l{i}"].max(), g[f"r{i}"].max())
-        assert np.abs(l.cpu().numpy() - g[f"l{i}"]).max() <= 2e-6 * scale, (i, dp)
-        assert np.abs(r.cpu().numpy() - g[f"r{i}"]).max() <= 2e-6 * scale, (i, dp)
+        dl_, dr_ = np.abs(l.cpu().numpy() - g[f"l{i}"]).max() / scale, np.abs(r.cpu().numpy() - g[f"r{i}"]).max() / scale
+        print(f"F13 set {i} r={float(dp[3]):.3f}: MEASURED |HIP - reference| / peak L {dl_:.2e} R {dr_:.2e}")
+        assert dl_ <= 2e-6 and dr_ <= 2e-6, (i, dp)
 
 
 def test_lean_and_literal_subpixel_weights_on_random_geometries():
@@ -399,8 +401,8 @@ def test_lean_and_literal_subpixel_weights_on_random_geometries():
         d_ab = max(np.abs(out["lean"][0] - out["ieee"][0]).max(), np.abs(out["lean"][1] - out["ieee"][1]).max()) / scale
         print(f"F13 set {i} (h, f, w, r) = {tuple(round(float(v), 4) for v in dp)}: |lean - reference| {d_ref['lean']:.2e}, "
               f"|literal - reference| {d_ref['ieee']:.2e}, |lean - literal| {d_ab:.2e} of the peak")
-        assert d_ref["lean"] <= 2e-6 and d_ref["ieee"] <= 2e-6, (i, d_ref)
-        assert d_ab <= 1.5e-6, (i, d_ab)
+        assert d_ref["lean"] <= 6e-7 and d_ref["ieee"] <= 6e-7, (i, d_ref)      # measured <= 1.8e-7
+        assert d_ab <= 4e-7, (i, d_ab)                                          # measured <= 1.2e-7
     assert seen >= 3
 
 
@@ -500,10 +502,11 @@ def test_psf_without_chief_ray_centre():
     Rref = g["grid_r"] / (g["grid_r"].max(axis=(1, 2), keepdims=True) + 1e-6)
     dl, dr = np.abs(L.cpu().numpy() - g["psf"]).max(), np.abs(R.cpu().numpy() - Rref).max()
     print("center=False hand-off: L", dl, "R", dr)
-    assert dl <= 1e-4 and dr <= 1e-4
+    assert dl <= 4e-5 and dr <= 9e-5                                  # measured 1.3e-5 / 2.9e-5
     torch.manual_seed(16)
     L2 = lens.psf_diff(pts, ks=33, spp=1024, center=False, param_list=DP + ["l"])
-    assert np.abs(L2.cpu().numpy() - g["psf"]).max() <= 5e-4
+    print("center=False same seed MEASURED", np.abs(L2.cpu().numpy() - g["psf"]).max())
+    assert np.abs(L2.cpu().numpy() - g["psf"]).max() <= 4e-5          # measured 1.3e-5
     # only the two primary vectors were drawn: the generator is where the reference leaves it
     torch.manual_seed(16)
     torch.rand(1024); torch.rand(1024)
@@ -536,11 +539,12 @@ def test_psf_rgb_without_chief_ray_centre_is_one_launch():
     psf_r = lens.psf_rgb(pts, ks=ks, center=False, param_list=DP + ["r"], pupil_xy=hand)
     dr = np.abs(psf_r.cpu().numpy() - g["psf_r"]).max()
     print("psf_rgb(center=False) hand-off: L", d, "R", dr)
-    assert psf.shape == (3, 3, ks, ks) and d <= 1e-4 and dr <= 1e-4
+    assert psf.shape == (3, 3, ks, ks) and d <= 6e-5 and dr <= 5e-5   # measured 1.9e-5 / 1.6e-5
     torch.manual_seed(int(g["seed"]))
     same_seed = lens.psf_rgb(pts, ks=ks, spp=spp, center=False, param_list=DP + ["l"])
     tail = torch.rand(3)
-    assert np.abs(same_seed.cpu().numpy() - g["psf"]).max() <= 5e-4
+    print("psf_rgb(center=False) same seed MEASURED", np.abs(same_seed.cpu().numpy() - g["psf"]).max())
+    assert np.abs(same_seed.cpu().numpy() - g["psf"]).max() <= 6e-5   # measured 1.9e-5
     torch.manual_seed(int(g["seed"]))
     three = torch.stack([lens.psf_diff(pts, wvln=float(w), ks=ks, spp=spp, center=False, param_list=DP + ["l"])
                          for w in g["wvlns"]], dim=-3)
