@@ -56,6 +56,47 @@ class Aspheric:
         s.n2 = float(self.mat2.ior(wvln))
         return s
 
+    def ray_reaction(self, ray):
+        """surfaces.py:391-520: intersect `ray` with THIS surface and refract it, in place (the ray is also returned,
+        as in the reference): Newton intersection with the batch-wide trip count of the reference's loop
+        (surfaces.py:547, speculated and verified like Lensgroup.trace does it), position / weight update of the rays
+        that hit inside the aperture, refraction unless the surface is a plane between equal media.  The direction
+        of travel is the reference's test, sum(d_z * ra) > 0 (surfaces.py:399-405: n1/n2 forward, n2/n1 backward).
+        One launch of sdirt_trace on a one-surface table at the ray's wavelength (cached on the surface)."""
+        import ctypes as C
+
+        import torch
+
+        from .basics import dptr, stream_ptr
+        from .newton import TripPlanner
+        from .optics import _DevLens
+        dev = ray.device
+        key = (float(ray.wvln), dev.index)
+        tables = self.__dict__.setdefault("_dev_tables", {})
+        state = (self.kind, self.r, float(self.d), float(self.c), float(self.k), None if self.ai is None else tuple(self.ai.tolist()),
+                 self.mat1.name, self.mat2.name)
+        if tables.get(key, (None, None))[1] != state:       # first use, or the record was edited since
+            with torch.cuda.device(dev):
+                tables[key] = (_DevLens([self], float(ray.wvln)), state)
+            self.__dict__["_planner"] = TripPlanner()
+        handle = tables[key][0].handle
+        planner = self.__dict__.setdefault("_planner", TripPlanner())
+        forward = bool(float((ray._field(5) * ray.ra).sum()) > 0)
+        curved = [self.kind != _lib.KIND_PLANE]
+        mask = torch.zeros(_lib.MAX_SURFACES, dtype=torch.int32, device=dev)
+        saved, calls = ray.soa.clone(), [0]                 # the trace is in place: keep the input for a re-launch
+
+        def launch(trips):
+            if calls[0]:
+                ray.soa.copy_(saved)
+            calls[0] += 1
+            mask.zero_()
+            _lib.check(_lib.lib().sdirt_trace(handle, 0, 1, 0 if forward else 1, (C.c_int32 * 1)(int(trips[0])), 0,
+                                              ray.c_rays(), ray.numel, dptr(mask), stream_ptr(dev)))
+            return mask[:1].cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+        planner.run(("ray_reaction", forward), curved, [0], launch)
+        return ray
+
     def surface(self, x, y):
         """surfaces.py:766-771 with :787-808, on the host in fp32 numpy: the sag z(x, y) of the surface about its
         vertex, evaluated at the apex where (x, y) lies outside the conic's domain (_valid_loose, :735-743).  For
