@@ -20,7 +20,7 @@ rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_IN
     --output-format csv -d "$OUT/pmc_a" -- $CMD > "$OUT/pmc_a.log" 2>&1
 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INSTS_LDS_ATOMIC GRBM_GUI_ACTIVE \
     --output-format csv -d "$OUT/pmc_b" -- $CMD > "$OUT/pmc_b.log" 2>&1
-python3 tools/summarize_prof.py "$OUT" > "$OUT/summary.json"
+python3 tools/summarize_prof.py "$OUT" --biggest-grid > "$OUT/summary.json"
 python3 - "$OUT" "$COMMIT" "$KS" <<'PY'
 import json, sys, time
 sys.path.insert(0, ".")

@@ -19,13 +19,23 @@ def short(name):
     return None
 
 
-def main(d):
+def main(d, biggest_grid_only=False):
+    """biggest_grid_only: per kernel keep only the dispatches of its LARGEST grid (the workload's own launches, not the
+    16-ray probes of lens set-up that go through the same kernels)."""
     out = {"kernel_trace": {}, "pmc": {}}
     for f in glob.glob(os.path.join(d, "trace", "**", "*_kernel_trace.csv"), recursive=True):
         durs = defaultdict(list)
         meta = {}
-        for r in csv.DictReader(open(f)):
+        rows = list(csv.DictReader(open(f)))
+        big = defaultdict(int)
+        for r in rows:
             k = short(r["Kernel_Name"])
+            if k:
+                big[k] = max(big[k], int(r["Grid_Size_X"]))
+        for r in rows:
+            k = short(r["Kernel_Name"])
+            if k and biggest_grid_only and int(r["Grid_Size_X"]) != big[k]:
+                continue
             if k:
                 durs[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
                 meta[k] = {x: r[x] for x in ("LDS_Block_Size", "Scratch_Size", "VGPR_Count",
@@ -37,8 +47,16 @@ def main(d):
                                       "per_dispatch_us": [round(x, 1) for x in v], **meta[k]}
     for f in glob.glob(os.path.join(d, "pmc_*", "**", "*_counter_collection.csv"), recursive=True):
         acc = defaultdict(lambda: defaultdict(list))
-        for r in csv.DictReader(open(f)):
+        rows = list(csv.DictReader(open(f)))
+        big = defaultdict(int)
+        for r in rows:
             k = short(r["Kernel_Name"])
+            if k:
+                big[k] = max(big[k], int(r["Grid_Size"]))
+        for r in rows:
+            k = short(r["Kernel_Name"])
+            if k and biggest_grid_only and int(r["Grid_Size"]) != big[k]:
+                continue
             if k:
                 acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k, cs in acc.items():
@@ -50,4 +68,4 @@ def main(d):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    main(sys.argv[1], biggest_grid_only="--biggest-grid" in sys.argv[2:])
