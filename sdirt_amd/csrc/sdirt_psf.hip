@@ -229,16 +229,24 @@ k_forward_integral_tiles(sdirt_rays R, int64_t S, int64_t N, SplatGeom gm, DevDp
     }
 }
 
-// optics.py:983-987: one workgroup per point.
+// optics.py:983-987: one workgroup per point.  LDS_TILE: the tile is read from HBM once, into LDS (grids up to
+// ks 110: 48 KB), its maximum taken there and the quotients written back -- one read and one write per pixel; larger grids
+// are read twice (the second pass mostly out of L2).
+template <bool LDS_TILE>
 __global__ void __launch_bounds__(kBlock) k_psf_normalize(float* __restrict__ psf, int tile)
 {
+    extern __shared__ __attribute__((aligned(16))) float nz_tile[];
     __shared__ float red[kBlock / 64];
     float* g = psf + (int64_t)blockIdx.x * tile;
     float mx = -INFINITY;
-    for (int i = threadIdx.x; i < tile; i += blockDim.x) mx = fmaxf(mx, g[i]);
+    for (int i = threadIdx.x; i < tile; i += blockDim.x) {
+        const float v = g[i];
+        if (LDS_TILE) nz_tile[i] = v;
+        mx = fmaxf(mx, v);
+    }
     mx = block_max(mx, red);
     const float den = mx + 1e-6f;
-    for (int i = threadIdx.x; i < tile; i += blockDim.x) g[i] = g[i] / den;
+    for (int i = threadIdx.x; i < tile; i += blockDim.x) g[i] = (LDS_TILE ? nz_tile[i] : g[i]) / den;
 }
 
 // ---------------------------------------------------------------------------
@@ -641,6 +649,15 @@ k_psf_lr(SplatBlock sb /* kernarg offset 0 */, TripSet trips /* 64 */, TripSet t
         atomicOr(&conv_mask[threadIdx.x], lds_mask[threadIdx.x]);
 }
 
+static void launch_normalize(float* psf, int64_t N, int tile, hipStream_t st)
+{
+    const size_t lds = sizeof(float) * (size_t)tile;
+    if (lds <= 48 * 1024 - 64)            // ks <= 110: inside the default dynamic-LDS allowance, two to ten workgroups per CU
+        k_psf_normalize<true><<<(unsigned)N, kBlock, lds, st>>>(psf, tile);
+    else
+        k_psf_normalize<false><<<(unsigned)N, kBlock, 0, st>>>(psf, tile);
+}
+
 // ---------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------
@@ -740,7 +757,7 @@ int sdirt_psf_normalize(float* psf, int64_t N, int32_t ks, void* stream)
     if (!psf || N < 0) return fail(SDIRT_ERR_INVALID_ARGUMENT, "bad argument");
     if (ks < 1) return fail(SDIRT_ERR_INVALID_ARGUMENT, "ks < 1");
     if (N == 0) return SDIRT_OK;
-    k_psf_normalize<<<(int)N, kBlock, 0, as_stream(stream)>>>(psf, ks * ks);
+    launch_normalize(psf, N, ks * ks, as_stream(stream));
     LAUNCH_CHECK();
     return SDIRT_OK;
 }
@@ -955,8 +972,8 @@ static int launch_psf(const sdirt_lens* const* lens, int W, const float* point_o
     // param_list=None leaves the R grid all-zero (monte_carlo.py:230-235)
     if (!both && have_r) HIP_TRY(hipMemsetAsync(r_psf, 0, sizeof(float) * (size_t)N * W * tile, st));
     if (!vr && nsplit > 1 && (flags & SDIRT_PSF_NORMALIZE)) {
-        k_psf_normalize<<<(int)N, kBlock, 0, st>>>(l_psf, tile);
-        if (have_r && dpp.have_r) k_psf_normalize<<<(int)N, kBlock, 0, st>>>(r_psf, tile);
+        launch_normalize(l_psf, N, tile, st);
+        if (have_r && dpp.have_r) launch_normalize(r_psf, N, tile, st);
         LAUNCH_CHECK();
     }
     return SDIRT_OK;
