@@ -220,6 +220,14 @@ int sdirt_forward_integral(sdirt_rays rays, int64_t spp, int64_t n_points, doubl
                            float* l_grid /*dev [N,ks,ks]*/, float* r_grid /*dev or NULL*/,
                            void* stream);
 
+/* How sdirt_forward_integral launches on a device of n_cus compute units (host arithmetic only, for callers that size
+ * scratch or want to know the path taken, and for the CPU tests): plan[0] = bytes per accumulator -- 8: float64 tiles in
+ * LDS, 4: float tiles in LDS, 0: grids added to in HBM --, plan[1] = points per workgroup, plan[2] = workgroups along the
+ * points, plan[3] = slices of the spp axis (> 1: partial tiles are added to the zeroed output), plan[4] = samples per
+ * slice, plan[5] = LDS bytes per workgroup.  both != 0: L and R grids. */
+int sdirt_forward_integral_plan(int64_t n_points, int64_t spp, int32_t ks, int32_t both, int32_t n_cus,
+                                int64_t* plan /*host [6]*/);
+
 /* deeplens/optics.py:983-987: psf / (max + 1e-6), per point, in place. */
 int sdirt_psf_normalize(float* psf /*dev [N,ks,ks]*/, int64_t n_points, int32_t ks, void* stream);
 

@@ -68,6 +68,7 @@ SIGNATURES = {
     "sdirt_center_from_rays": (C.c_int, [Rays, _I64, _I64, _P, _P, _P]),
     "sdirt_forward_integral": (C.c_int, [Rays, _I64, _I64, _D, _I32, _P, C.POINTER(DpParams), _U32,
                                          _P, _P, _P]),
+    "sdirt_forward_integral_plan": (C.c_int, [_I64, _I64, _I32, _I32, _I32, C.POINTER(_I64)]),
     "sdirt_psf_normalize": (C.c_int, [_P, _I64, _I32, _P]),
     "sdirt_chief_center": (C.c_int, [_P, _P, _I64, _P, _P, _I64, _D, _D, C.POINTER(_I32), _U32,
                                      _P, _P, _P, _P]),

@@ -691,6 +691,22 @@ static bool plan_forward_integral(int64_t N, int64_t S, int ks, int ntile, size_
     return true;
 }
 
+int sdirt_forward_integral_plan(int64_t N, int64_t S, int32_t ks, int32_t both, int32_t n_cus, int64_t* plan)
+{
+    if (!plan || N < 1 || S < 1 || n_cus < 1) return fail(SDIRT_ERR_INVALID_ARGUMENT, "bad argument");
+    if (int rc = check_ks(ks, SDIRT_MAX_KS_STAGED)) return rc;
+    FiLaunch fl;
+    const int ntile = both ? 2 : 1;
+    const bool wide = plan_forward_integral(N, S, ks, ntile, sizeof(double), n_cus, fl);
+    const bool tiles = wide || plan_forward_integral(N, S, ks, ntile, sizeof(float), n_cus, fl);
+    plan[0] = tiles ? (wide ? 8 : 4) : 0;
+    for (int i = 1; i < 6; ++i) plan[i] = 0;
+    if (!tiles) return SDIRT_OK;
+    plan[1] = fl.P; plan[2] = fl.ngroups; plan[3] = fl.nsplit; plan[4] = fl.chunk;
+    plan[5] = (int64_t)plan[0] * fl.P * fl.stride;
+    return SDIRT_OK;
+}
+
 int sdirt_forward_integral(sdirt_rays rays, int64_t S, int64_t N, double ps, int32_t ks,
                            const float* center, const sdirt_dp_params* dp, uint32_t flags, float* l_grid,
                            float* r_grid, void* stream)

@@ -486,3 +486,37 @@ def test_host_sag_for_drawing():
     assert abs(float(a.surface(np.float32(3.0), np.float32(0.0))) - want) < 1e-6
     flat = Aspheric(5.0, 1.0, c=0.0)
     assert np.all(flat.surface_with_offset(r, r) == 1.0)
+
+
+def test_forward_integral_launch_plan_for_every_grid_and_batch_shape():
+    """sdirt_forward_integral_plan (pure host arithmetic, no GPU): whatever (points, spp, ks, L / L+R, CU count), the
+    launch keeps a workgroup's tiles inside the 160 KiB of LDS, covers every point and every sample exactly once, prefers
+    float64 accumulators while two tiles fit, falls back to float tiles and then to the HBM path, and cuts the spp axis
+    only when the points alone leave CUs idle."""
+    import ctypes as C
+    import itertools
+    from sdirt_amd import _lib
+    h = _lib.lib()
+    plan = (C.c_int64 * 6)()
+    seen = set()
+    for n, s, ks, both, cus in itertools.product([1, 2, 3, 64, 300, 2048, 16384, 65537], [1, 50, 64, 200, 1024, 4096, 20000],
+                                                 [2, 9, 21, 65, 99, 100, 120, 141, 142, 256, 1024], [0, 1], [32, 256]):
+        assert h.sdirt_forward_integral_plan(n, s, ks, both, cus, plan) == 0
+        acc, P, groups, nsplit, chunk, lds = list(plan)
+        tile = (2 if both else 1) * ks * ks
+        seen.add(acc)
+        if acc == 0:
+            assert (tile | 1) * 4 > 160 * 1024 - 1024              # not even one float tile set fits
+            continue
+        assert acc == 8 or (tile | 1) * 8 > 160 * 1024 - 1024      # float tiles only when double ones do not fit
+        assert lds == acc * P * (tile | 1) <= 160 * 1024 - 1024
+        assert P in (1, 2, 4, 8, 16) and groups == -(-n // P)
+        rp = 1024 // P
+        assert chunk % rp == 0 and chunk >= rp
+        assert nsplit == -(-s // chunk) and nsplit * chunk >= s > (nsplit - 1) * chunk
+        if P > 1:
+            assert rp >= s                                          # several points per workgroup only for short rows
+        if nsplit > 1:
+            assert groups < 2 * cus
+    assert seen == {0, 4, 8}
+    assert h.sdirt_forward_integral_plan(0, 10, 21, 1, 256, plan) != 0 and b"bad argument" in h.sdirt_last_error()
