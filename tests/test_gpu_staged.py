@@ -124,7 +124,7 @@ def test_forward_integral_tiles_match_the_oracle_splat(lens, oracle, n, spp, ks,
     print(f"forward_integral n={n} spp={spp} ks={ks}: max |HIP - oracle| / peak = {worst:.2e}")
     # the segment areas of the default small-radius branch are a polynomial here and acos/sin in the oracle
     # (3e-7 absolute per weight); sums of up to 4096 fp32 terms in a different order
-    assert worst < 3e-6
+    assert worst < 2.4e-6                       # measured 2.0e-7 ... 7.6e-7
     # energy: what the window keeps of every point is what was splat (bilinear taps sum to the weight)
     tot = (lg.double().sum((1, 2)) + rg.double().sum((1, 2))).cpu()
     assert torch.isfinite(tot).all() and float(tot.min()) >= 0
@@ -145,4 +145,4 @@ def test_staged_chain_equals_fused_kernel_on_a_volume_slab(lens):
                                  (xc, yc), None, None, False)
     d = max(float((Lf - Ls).abs().max()), float((Rf - Rs).abs().max()))
     print(f"staged vs fused, 512 points x 1024 spp, ks 65 (normalised PSFs): max |diff| = {d:.2e}")
-    assert d < 3e-6
+    assert d < 2e-6                             # measured 6.6e-7 ... 9.5e-7 (fp32 LDS-atomic order of the fused kernel)
