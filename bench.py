@@ -492,18 +492,22 @@ def quick_volume(workload, steps, device):
 
 def also_block(args, lens, device):
     """The other driver-timed lines of the default run (3-5 steps each): the staged SoA chain (HBM-bound kernels), the
-    per-pixel PSF convolution f1 (HBM-bound) and config 4 (rf35mm, the second prescription)."""
+    per-pixel PSF convolution f1 (HBM-bound), config 4 (rf35mm, the second prescription), one GPU's share of config 3
+    (8192 points x 8192 spp, 21 x 21) and the reference's own timing harness (tcp)."""
     import copy
     q = copy.copy(args)
     q.steps, q.warmup, q.sustain_seconds = 5, 2, 0.0
     out = {}
     for name, fn in (("staged", lambda: bench_staged(q, emit=False, lens=lens)),
                      ("f1", lambda: bench_f1(q, emit=False)),
-                     ("c4", lambda: quick_volume("c4", 5, device))):
+                     ("c4", lambda: quick_volume("c4", 5, device)),
+                     ("c3", lambda: quick_volume("c3", 5, device)),
+                     ("tcp", lambda: bench_tcp(q, emit=False))):
         t0 = time.perf_counter()
         try:
             r = fn()
-            keep = ("metric", "value", "unit", "steps", "ms_per_step", "config", "roofline", "kernels_ms", "staged")
+            keep = ("metric", "value", "unit", "steps", "ms_per_step", "config", "roofline", "kernels_ms", "staged",
+                    "value_pcie_inclusive", "reference_harness")
             out[name] = {k: r[k] for k in keep if k in r}
         except Exception as e:       # a broken side line must not cost the headline
             out[name] = {"error": f"{type(e).__name__}: {e}"}
@@ -512,7 +516,7 @@ def also_block(args, lens, device):
     return out
 
 
-def bench_tcp(args):
+def bench_tcp(args, emit=True):
     """The one workload the reference itself times: PSFNet.time_compare_psf (psfnet.py:570-586) -- 24576
     random points, 4096 spp, ks 21, the PSFs copied to the host inside the timed span.  `value` is the
     device-resident rate (inputs and outputs in HBM, as every other line of this file);
@@ -547,7 +551,9 @@ def bench_tcp(args):
                                   "21x21 L PSFs (param_list=None), lambda 0.589um, focus 1 m", "name": "tcp",
                       "points_per_gpu": n, "spp": spp, "ks": ks},
            "kernels_ms": {"psf_lr synchronous call (events)": kern}}
-    print(json.dumps(res), flush=True)
+    if emit:
+        print(json.dumps(res), flush=True)
+    return res
 
 
 def main():
