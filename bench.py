@@ -425,12 +425,15 @@ def bench_staged(args, emit=True, lens=None, ks_list=None):
                 gbs = alg[name] / (t * 1e-3) / 1e9
                 k.update({"algorithmic_bytes": alg[name], "achieved_GBps": gbs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS})
                 c = ((carried or {}).get("kernels") or {}).get(KERNEL_OF[name])
+                nl = 2 if name == "psf_normalize" else 1          # L and R are normalised by one launch each
+                if nl > 1:
+                    k["launches"] = nl
                 if c and c.get("hbm_bytes_per_dispatch_mean_last3") and (carried.get("n_points"), carried.get("spp")) == (N, S):
                     # HBM bytes of this kernel from the committed rocprofv3 --pmc passes of this command
                     # (2 x FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md), and its rocprofv3 average duration
-                    k.update({"traffic": c["hbm_bytes_per_dispatch_mean_last3"],
-                              "traffic_over_algorithmic": c["hbm_bytes_per_dispatch_mean_last3"] / alg[name],
-                              "rocprof_avg_ms": c["avg_us"] / 1e3, "traffic_stale": bool(carried["stale"]),
+                    k.update({"traffic": nl * c["hbm_bytes_per_dispatch_mean_last3"],
+                              "traffic_over_algorithmic": nl * c["hbm_bytes_per_dispatch_mean_last3"] / alg[name],
+                              "rocprof_avg_ms": nl * c["avg_us"] / 1e3, "traffic_stale": bool(carried["stale"]),
                               "traffic_file": carried["file"]})
             kern[name] = k
         kern["trace"]["bound"] = kern["chief_center"]["bound"] = "valu"
