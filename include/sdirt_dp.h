@@ -198,6 +198,14 @@ int sdirt_trace(const sdirt_lens* lens, int32_t first, int32_t last, int32_t bac
                 uint32_t flags /*SDIRT_PSF_STRICT_IEEE | SDIRT_TRACE_NO_PREFETCH or 0*/, sdirt_rays rays, int64_t n_rays, uint32_t* conv_mask /*dev [K] or NULL*/,
                 void* stream);
 
+/* The same trace OUT OF PLACE: reads `rays`, writes `out` (another bundle of n_rays rays; `out` == `rays` is
+ * sdirt_trace).  The reference's trace mutates its Ray; a caller that may have to run a batch again with a corrected
+ * trip table keeps its input this way without copying it first (Lensgroup.trace: the copy was 64 bytes of traffic per
+ * ray on top of the trace's own 64). */
+int sdirt_trace_to(const sdirt_lens* lens, int32_t first, int32_t last, int32_t backward,
+                   const int32_t* trips /*host [K]*/, uint32_t flags, sdirt_rays rays, sdirt_rays out,
+                   int64_t n_rays, uint32_t* conv_mask /*dev [K] or NULL*/, void* stream);
+
 /* Ray.propagate_to, deeplens/basics.py:256-264. */
 int sdirt_propagate_to(double z, sdirt_rays rays, int64_t n_rays, void* stream);
 

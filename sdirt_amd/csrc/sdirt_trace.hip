@@ -158,10 +158,12 @@ __global__ void k_rays_to_aos(sdirt_rays R, int64_t M, int64_t S, int64_t N, flo
     }
 }
 
+// R: the bundle read, W: the bundle written (the same arrays for an in-place trace: every ray is read before it is
+// written, by the thread that writes it).
 template <bool FWD, class MP, bool PREFETCH>
 __global__ void __launch_bounds__(kBlock)
 k_trace(TripTable trips /* kernarg offset 0 */, const DevSurface* __restrict__ lens, int K, int first,
-        int last, sdirt_rays R, int64_t M, uint32_t* __restrict__ conv_mask)
+        int last, sdirt_rays R, sdirt_rays W, int64_t M, uint32_t* __restrict__ conv_mask)
 {
     __shared__ uint32_t lds_mask[SDIRT_MAX_SURFACES];
     if (threadIdx.x < SDIRT_MAX_SURFACES) lds_mask[threadIdx.x] = 0;
@@ -170,7 +172,7 @@ k_trace(TripTable trips /* kernarg offset 0 */, const DevSurface* __restrict__ l
          i += (int64_t)gridDim.x * blockDim.x) {
         Ray r = load_ray(R, i);
         trace_ray<FWD, MP, PREFETCH>(lens, first, last, kernarg_at(0), r, conv_mask ? lds_mask : nullptr);
-        store_ray(R, i, r);
+        store_ray(W, i, r);
     }
     __syncthreads();
     if (conv_mask && (int)threadIdx.x < K && lds_mask[threadIdx.x])
@@ -442,20 +444,42 @@ int sdirt_trace(const sdirt_lens* lens, int32_t first, int32_t last, int32_t bac
                 const int32_t* trips, uint32_t flags, sdirt_rays rays, int64_t M,
                 uint32_t* conv_mask, void* stream)
 {
+    return sdirt_trace_to(lens, first, last, backward, trips, flags, rays, rays, M, conv_mask, stream);
+}
+
+int sdirt_trace_to(const sdirt_lens* lens, int32_t first, int32_t last, int32_t backward,
+                   const int32_t* trips, uint32_t flags, sdirt_rays rays, sdirt_rays out, int64_t M,
+                   uint32_t* conv_mask, void* stream)
+{
     if (!lens) return fail(SDIRT_ERR_INVALID_ARGUMENT, "null lens");
     if (first < 0 || last > lens->n_surfaces || first > last)
         return fail(SDIRT_ERR_INVALID_ARGUMENT, "surface range [%d,%d) outside [0,%d]", first, last,
                     lens->n_surfaces);
     if (int rc = check_rays(rays)) return rc;
+    if (int rc = check_rays(out)) return rc;
+    if ((rays.obliq == nullptr) != (out.obliq == nullptr))
+        return fail(SDIRT_ERR_INVALID_ARGUMENT, "obliq must be present in both bundles or in neither");
     TripTable tt;
     if (int rc = make_trips(lens, trips, tt)) return rc;
-    if (M <= 0 || first == last) return M < 0 ? fail(SDIRT_ERR_INVALID_ARGUMENT, "n_rays < 0") : SDIRT_OK;
+    if (M < 0) return fail(SDIRT_ERR_INVALID_ARGUMENT, "n_rays < 0");
+    if (M == 0) return SDIRT_OK;
+    if (first == last) {                       // nothing to trace: the output bundle is the input bundle
+        if (out.ox != rays.ox) {
+            hipStream_t st = as_stream(stream);
+            const float* src[8] = {rays.ox, rays.oy, rays.oz, rays.dx, rays.dy, rays.dz, rays.ra, rays.obliq};
+            float* dst[8] = {out.ox, out.oy, out.oz, out.dx, out.dy, out.dz, out.ra, out.obliq};
+            for (int c = 0; c < 8; ++c)
+                if (src[c] && dst[c] != src[c])
+                    HIP_TRY(hipMemcpyAsync(dst[c], src[c], sizeof(float) * (size_t)M, hipMemcpyDeviceToDevice, st));
+        }
+        return SDIRT_OK;
+    }
     const int grid = grid_for(M, kBlock);
     const bool lean = (flags & SDIRT_PSF_STRICT_IEEE) == 0;
     const bool prefetch = (flags & SDIRT_TRACE_NO_PREFETCH) == 0;
 #define SDIRT_LAUNCH_TRACE_P(FW, MM, PF)                                                        \
     k_trace<FW, MM, PF><<<grid, kBlock, 0, as_stream(stream)>>>(tt, lens->dev, lens->n_surfaces, \
-                                                                first, last, rays, M, conv_mask)
+                                                                first, last, rays, out, M, conv_mask)
 #define SDIRT_LAUNCH_TRACE(FW, MM)                                                              \
     do {                                                                                        \
         if (prefetch) SDIRT_LAUNCH_TRACE_P(FW, MM, true); else SDIRT_LAUNCH_TRACE_P(FW, MM, false); \

@@ -531,17 +531,19 @@ class Lensgroup:
                                               mask_ptr, stream_ptr(self.device)))
 
         if self.trip_policy == "reference":
-            # the trace is in place: keep the input to be able to re-launch
-            saved = ray.soa.clone()
-            calls = [0]
+            # a wrong bet on the trip table means tracing the batch again from its input: the trace goes OUT OF PLACE
+            # into a second bundle (sdirt_trace_to) which then becomes the ray's storage -- the reference's trace
+            # rebinds ray.o / ray.d / ray.ra to new tensors in the same way (surfaces.py:425, 676-677); copying the
+            # bundle first to trace in place cost as much memory traffic as the trace itself
+            dst = Ray.empty(ray.shape, ray.wvln, self.device)
 
-            def enqueue_fresh(trips, mask_ptr):
-                if calls[0]:
-                    ray.soa.copy_(saved)
-                calls[0] += 1
-                enqueue(trips, mask_ptr)
+            def enqueue_to(trips, mask_ptr):
+                _lib.check(_lib.lib().sdirt_trace_to(handle, first, last, 0 if forward else 1, trips,
+                                                     self._math_flags(), ray.c_rays(), dst.c_rays(), ray.numel,
+                                                     mask_ptr, stream_ptr(self.device)))
             key = ("trace", round(float(ray.wvln), 6), first, last, forward, self.precision)
-            self._run_with_trips(key, order, enqueue_fresh)
+            self._run_with_trips(key, order, enqueue_to)
+            ray.soa = dst.soa
         else:
             self._run_with_trips(None, order, enqueue)
         valid = ray.ra == 1

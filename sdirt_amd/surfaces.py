@@ -57,17 +57,17 @@ class Aspheric:
         return s
 
     def ray_reaction(self, ray):
-        """surfaces.py:391-520: intersect `ray` with THIS surface and refract it, in place (the ray is also returned,
-        as in the reference): Newton intersection with the batch-wide trip count of the reference's loop
+        """surfaces.py:391-520: intersect `ray` with THIS surface and refract it; the ray object is updated and also
+        returned, as in the reference.  Newton intersection with the batch-wide trip count of the reference's loop
         (surfaces.py:547, speculated and verified like Lensgroup.trace does it), position / weight update of the rays
         that hit inside the aperture, refraction unless the surface is a plane between equal media.  The direction
         of travel is the reference's test, sum(d_z * ra) > 0 (surfaces.py:399-405: n1/n2 forward, n2/n1 backward).
-        One launch of sdirt_trace on a one-surface table at the ray's wavelength (cached on the surface)."""
+        One launch of sdirt_trace_to on a one-surface table at the ray's wavelength (cached on the surface)."""
         import ctypes as C
 
         import torch
 
-        from .basics import dptr, stream_ptr
+        from .basics import Ray, dptr, stream_ptr
         from .newton import TripPlanner
         from .optics import _DevLens
         dev = ray.device
@@ -84,17 +84,15 @@ class Aspheric:
         forward = bool(float((ray._field(5) * ray.ra).sum()) > 0)
         curved = [self.kind != _lib.KIND_PLANE]
         mask = torch.zeros(_lib.MAX_SURFACES, dtype=torch.int32, device=dev)
-        saved, calls = ray.soa.clone(), [0]                 # the trace is in place: keep the input for a re-launch
+        dst = Ray.empty(ray.shape, ray.wvln, dev)           # out of place: a re-launch with a corrected count re-reads `ray`
 
         def launch(trips):
-            if calls[0]:
-                ray.soa.copy_(saved)
-            calls[0] += 1
             mask.zero_()
-            _lib.check(_lib.lib().sdirt_trace(handle, 0, 1, 0 if forward else 1, (C.c_int32 * 1)(int(trips[0])), 0,
-                                              ray.c_rays(), ray.numel, dptr(mask), stream_ptr(dev)))
+            _lib.check(_lib.lib().sdirt_trace_to(handle, 0, 1, 0 if forward else 1, (C.c_int32 * 1)(int(trips[0])), 0,
+                                                 ray.c_rays(), dst.c_rays(), ray.numel, dptr(mask), stream_ptr(dev)))
             return mask[:1].cpu().numpy().astype(np.int64) & 0xFFFFFFFF
         planner.run(("ray_reaction", forward), curved, [0], launch)
+        ray.soa = dst.soa                                   # the reference rebinds ray.o / ray.d / ray.ra as well (:425, :676)
         return ray
 
     def surface(self, x, y):
