@@ -146,3 +146,42 @@ def test_staged_chain_equals_fused_kernel_on_a_volume_slab(lens):
     d = max(float((Lf - Ls).abs().max()), float((Rf - Rs).abs().max()))
     print(f"staged vs fused, 512 points x 1024 spp, ks 65 (normalised PSFs): max |diff| = {d:.2e}")
     assert d < 2e-6                             # measured 6.6e-7 ... 9.5e-7 (fp32 LDS-atomic order of the fused kernel)
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("SDIRT_FUZZ_SEEDS", 6))))
+def test_forward_integral_random_batch_shapes_against_the_oracle(oracle, seed):
+    """Fuzz of the launch planner's whole range: random point counts (1 ... 700), samples per point (1 ... 3000), grid
+    sizes (2 ... 150: double tiles, float tiles, the HBM path), L only / L + R, both microlens branches, both math
+    policies; synthetic sensor-plane rays with dead, out-of-window and fractional-weight entries.  Every L and R grid
+    of the HIP splat against the CPU oracle's on the same rays."""
+    from sdirt_amd import forward_integral_lr
+    from sdirt_amd.basics import Ray
+    rng = np.random.default_rng(4000 + seed)
+    N = int(rng.choice([1, 2, 3, 5, 17, 64, 130, 257, 700]))
+    S = int(rng.choice([1, 3, 50, 63, 64, 65, 200, 1023, 1024, 1025, 3000]))
+    if N * S > 400000:
+        S = max(1, 400000 // N)
+    ks = int(rng.choice([2, 5, 9, 21, 33, 65, 99, 100, 141, 150]))
+    ps = 0.046875
+    big = bool(rng.integers(0, 2))
+    h = float(rng.uniform(0.4, 1.1)); f = h + float(rng.uniform(0.3, 1.2))
+    dp = None if rng.random() < 0.2 else [h, f, float(rng.uniform(0.1, 0.45)),
+                                            float(rng.uniform(0.51, 0.9) if big else rng.uniform(0.15, 0.5))]
+    precision = "ieee" if rng.random() < 0.3 else "lean"
+    half = ks / 2 * ps
+    o = np.zeros((S, N, 3), np.float32)
+    o[..., :2] = rng.uniform(-1.15 * half, 1.15 * half, (S, N, 2))          # some rays outside the window
+    d = np.zeros((S, N, 3), np.float32)
+    d[..., 0] = rng.normal(0, 0.15, (S, N)); d[..., 1] = rng.normal(0, 0.15, (S, N)); d[..., 2] = 1.0
+    d = (d / np.linalg.norm(d, axis=-1, keepdims=True)).astype(np.float32)
+    ra = rng.choice(np.array([0.0, 1.0, 1.0, 1.0, 0.625], np.float32), (S, N))
+    cen = rng.uniform(-0.2 * half, 0.2 * half, (N, 2)).astype(np.float32)
+    ray = Ray.from_normalized(torch.from_numpy(o), torch.from_numpy(d), ra=torch.from_numpy(ra), device=DEV)
+    lg, rg = forward_integral_lr(ray, ps, ks, torch.from_numpy(cen), None if dp is None else dp + ["l"], precision=precision)
+    lo, ro = oracle.forward_integral(o, d, ra, ps, ks, cen, dp)
+    scale = max(float(lo.max()), float(ro.max()) if dp is not None else 0.0, 1e-6)
+    dl = float(np.abs(lg.cpu().numpy() - lo).max()) / scale
+    dr = float(np.abs(rg.cpu().numpy() - ro).max()) / scale if dp is not None else float(rg.abs().max())
+    print(f"seed {seed}: N={N} S={S} ks={ks} dp={None if dp is None else [round(v, 3) for v in dp]} {precision}: "
+          f"|L - oracle| {dl:.2e} |R - oracle| {dr:.2e} of the peak")
+    assert dl <= 2e-6 and dr <= 2e-6
