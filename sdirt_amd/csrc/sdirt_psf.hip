@@ -8,7 +8,6 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
-#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <type_traits>
@@ -125,11 +124,8 @@ k_forward_integral_hbm(sdirt_rays R, int64_t S, int64_t N, SplatGeom gm, DevDpPa
 // 8-20 (tools/lds_atomic_bench.hip, profiles/r04/lds_atomic_bench*.txt) -- with eight adds per ray the fp32 form
 // IS the kernel's time (350 of 350 us on 8.4 M rays).  A double sum rounded once on the way out is also nearer to
 // the reference's sequential fp32 sum's exact value than any fp32 summation order, and takes any weight `ra`.
-#ifndef FI_DEPTH
-#define FI_DEPTH 2
-#endif
 constexpr int kFiThreads = 1024;
-constexpr int kFiDepth = FI_DEPTH;      // passes whose rays are in flight
+constexpr int kFiDepth = 2;             // passes whose rays are in flight (2, 4, 8 time within 7 %: profiles/r04)
 struct FiLaunch {
     int P, logRp;         // points per workgroup; log2(samples per pass and point = kFiThreads / P)
     int ngroups;          // ceil(N / P)
