@@ -206,6 +206,14 @@ int sdirt_trace_to(const sdirt_lens* lens, int32_t first, int32_t last, int32_t 
                    const int32_t* trips /*host [K]*/, uint32_t flags, sdirt_rays rays, sdirt_rays out,
                    int64_t n_rays, uint32_t* conv_mask /*dev [K] or NULL*/, void* stream);
 
+/* Lensgroup.trace2sensor, deeplens/optics.py:638-664: the forward trace through ALL surfaces and the propagation to the
+ * sensor plane z = d_sensor in one pass over the bundle (reads `rays`, writes `out`; the same bundle for in place).
+ * Equal, bit for bit, to sdirt_trace_to(0, K, forward) followed by sdirt_propagate_to(d_sensor) under the default math
+ * policy (the propagation's one division is the policy's: correctly rounded either way). */
+int sdirt_trace2sensor(const sdirt_lens* lens, const int32_t* trips /*host [K]*/, uint32_t flags /*SDIRT_PSF_STRICT_IEEE or 0*/,
+                       double d_sensor, sdirt_rays rays, sdirt_rays out, int64_t n_rays,
+                       uint32_t* conv_mask /*dev [K] or NULL*/, void* stream);
+
 /* Ray.propagate_to, deeplens/basics.py:256-264. */
 int sdirt_propagate_to(double z, sdirt_rays rays, int64_t n_rays, void* stream);
 
@@ -221,10 +229,12 @@ int sdirt_center_from_rays(sdirt_rays rays, int64_t spp, int64_t n_points,
  * n * spp + s).  ps = pixel size; center = pointc_ref [N,2].  ks up to SDIRT_MAX_KS_STAGED: up to SDIRT_MAX_KS a
  * point's grids are summed in LDS (in float64 up to ks 99) and written once, above that they are added to in HBM
  * (the fused sdirt_psf_* entries stop at SDIRT_MAX_KS; the staged chain sample -> trace -> chief centre ->
- * forward_integral -> normalize is the path for larger grids). */
+ * forward_integral -> normalize is the path for larger grids).  SDIRT_PSF_NORMALIZE: the grids leave max-normalised
+ * (deeplens/optics.py:983-987, what sdirt_psf_normalize does) -- straight from the tiles in LDS when a workgroup holds a
+ * point's whole sum: the 2 x 4 bytes per pixel of the separate pass are never read back. */
 int sdirt_forward_integral(sdirt_rays rays, int64_t spp, int64_t n_points, double ps, int32_t ks,
                            const float* center /*dev [N,2]*/, const sdirt_dp_params* dp /*host*/,
-                           uint32_t flags /*SDIRT_PSF_STRICT_IEEE or 0*/,
+                           uint32_t flags /*SDIRT_PSF_STRICT_IEEE | SDIRT_PSF_NORMALIZE or 0*/,
                            float* l_grid /*dev [N,ks,ks]*/, float* r_grid /*dev or NULL*/,
                            void* stream);
 

@@ -65,6 +65,7 @@ SIGNATURES = {
     "sdirt_rays_to_aos": (C.c_int, [Rays, _I64, _I64, _P, _P, _P]),
     "sdirt_trace": (C.c_int, [_P, _I32, _I32, _I32, C.POINTER(_I32), _U32, Rays, _I64, _P, _P]),
     "sdirt_trace_to": (C.c_int, [_P, _I32, _I32, _I32, C.POINTER(_I32), _U32, Rays, Rays, _I64, _P, _P]),
+    "sdirt_trace2sensor": (C.c_int, [_P, C.POINTER(_I32), _U32, _D, Rays, Rays, _I64, _P, _P]),
     "sdirt_propagate_to": (C.c_int, [_D, Rays, _I64, _P]),
     "sdirt_center_from_rays": (C.c_int, [Rays, _I64, _I64, _P, _P, _P]),
     "sdirt_forward_integral": (C.c_int, [Rays, _I64, _I64, _D, _I32, _P, C.POINTER(DpParams), _U32,

@@ -137,9 +137,10 @@ struct FiLaunch {
 template <bool HAVE_R, bool BIG, class ACC, class M>
 __global__ void __launch_bounds__(kFiThreads)
 k_forward_integral_tiles(sdirt_rays R, int64_t S, int64_t N, SplatGeom gm, DevDpParams dp, FiLaunch fl,
-                         const float* __restrict__ center, float* __restrict__ lg, float* __restrict__ rg)
+                         const float* __restrict__ center, float* __restrict__ lg, float* __restrict__ rg, int normalize)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char fi_lds[];
+    __shared__ float fi_red[kFiThreads / 64];
     ACC* __restrict__ fi_tiles = reinterpret_cast<ACC*>(fi_lds);
     const int tile = gm.ks * gm.ks;
     const int g = (int)(blockIdx.x / (uint32_t)fl.nsplit), j = (int)(blockIdx.x - (uint32_t)g * fl.nsplit);
@@ -207,7 +208,21 @@ k_forward_integral_tiles(sdirt_rays R, int64_t S, int64_t N, SplatGeom gm, DevDp
         const ACC* __restrict__ src = fi_tiles + pp * fl.stride;
         float* __restrict__ Lg = lg + ((int64_t)g * fl.P + pp) * tile;
         float* __restrict__ Rg = HAVE_R ? rg + ((int64_t)g * fl.P + pp) * tile : nullptr;
-        if (fl.nsplit == 1) {
+        if (fl.nsplit == 1 && normalize) {
+            // optics.py:983-987 on the way out (SDIRT_PSF_NORMALIZE): psf / (max + 1e-6) of the float grids, the same
+            // values and the same division k_psf_normalize would read back and perform
+            float ml = -INFINITY, mr = -INFINITY;
+            for (int e = threadIdx.x; e < tile; e += kFiThreads) {
+                ml = fmaxf(ml, (float)src[e]);
+                if (HAVE_R) mr = fmaxf(mr, (float)src[tile + e]);
+            }
+            const float dl = block_max(ml, fi_red) + 1e-6f;
+            const float dr = HAVE_R ? block_max(mr, fi_red) + 1e-6f : 1.0f;
+            for (int e = threadIdx.x; e < tile; e += kFiThreads) {
+                Lg[e] = (float)src[e] / dl;
+                if (HAVE_R) Rg[e] = (float)src[tile + e] / dr;
+            }
+        } else if (fl.nsplit == 1) {
             for (int e = threadIdx.x; e < tile; e += kFiThreads) {
                 Lg[e] = (float)src[e];
                 if (HAVE_R) Rg[e] = (float)src[tile + e];
@@ -728,9 +743,14 @@ int sdirt_forward_integral(sdirt_rays rays, int64_t S, int64_t N, double ps, int
     if (!tiles || fl.nsplit > 1) HIP_TRY(hipMemsetAsync(l_grid, 0, bytes, st));
     if (r_grid && (!tiles || fl.nsplit > 1 || !both)) HIP_TRY(hipMemsetAsync(r_grid, 0, bytes, st));
     if (S == 0) return SDIRT_OK;
+    const bool normalize = (flags & SDIRT_PSF_NORMALIZE) != 0;
     if (!tiles) {
         k_forward_integral_hbm<<<grid_for(S * N, kBlock), kBlock, 0, st>>>(
             rays, S, N, make_geom(ps, ks), dpp, center, l_grid, r_grid);
+        if (normalize) {
+            launch_normalize(l_grid, N, ks * ks, st);
+            if (both) launch_normalize(r_grid, N, ks * ks, st);
+        }
         LAUNCH_CHECK();
         return SDIRT_OK;
     }
@@ -742,7 +762,8 @@ int sdirt_forward_integral(sdirt_rays rays, int64_t S, int64_t N, double ps, int
             HIP_TRY(hipFuncSetAttribute((const void*)k_forward_integral_tiles<HR, BG, AC, MM>,    \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024)); \
         k_forward_integral_tiles<HR, BG, AC, MM><<<grid, kFiThreads, lds_bytes, st>>>(            \
-            rays, S, N, make_geom(ps, ks), dpp, fl, center, l_grid, both ? r_grid : nullptr);     \
+            rays, S, N, make_geom(ps, ks), dpp, fl, center, l_grid, both ? r_grid : nullptr,      \
+            (flags & SDIRT_PSF_NORMALIZE) ? 1 : 0);                                               \
     } while (0)
 #define SDIRT_LAUNCH_FI_A(HR, BG, AC)                                                             \
     do {                                                                                          \
@@ -760,6 +781,10 @@ int sdirt_forward_integral(sdirt_rays rays, int64_t S, int64_t N, double ps, int
 #undef SDIRT_LAUNCH_FI_A
 #undef SDIRT_LAUNCH_FI_M
 #undef SDIRT_LAUNCH_FI
+    if (normalize && fl.nsplit > 1) {          // the partial tiles have only just been added up in HBM
+        launch_normalize(l_grid, N, ks * ks, st);
+        if (both) launch_normalize(r_grid, N, ks * ks, st);
+    }
     LAUNCH_CHECK();
     return SDIRT_OK;
 }

@@ -160,10 +160,12 @@ __global__ void k_rays_to_aos(sdirt_rays R, int64_t M, int64_t S, int64_t N, flo
 
 // R: the bundle read, W: the bundle written (the same arrays for an in-place trace: every ray is read before it is
 // written, by the thread that writes it).
-template <bool FWD, class MP, bool PREFETCH>
+// TO_SENSOR: trace2sensor (optics.py:638-664) -- the traced ray is carried on to the plane z = z_sensor
+// (Ray.propagate_to) before it is stored: one pass over the bundle instead of two.
+template <bool FWD, class MP, bool PREFETCH, bool TO_SENSOR = false>
 __global__ void __launch_bounds__(kBlock)
 k_trace(TripTable trips /* kernarg offset 0 */, const DevSurface* __restrict__ lens, int K, int first,
-        int last, sdirt_rays R, sdirt_rays W, int64_t M, uint32_t* __restrict__ conv_mask)
+        int last, sdirt_rays R, sdirt_rays W, int64_t M, uint32_t* __restrict__ conv_mask, float z_sensor)
 {
     __shared__ uint32_t lds_mask[SDIRT_MAX_SURFACES];
     if (threadIdx.x < SDIRT_MAX_SURFACES) lds_mask[threadIdx.x] = 0;
@@ -172,6 +174,7 @@ k_trace(TripTable trips /* kernarg offset 0 */, const DevSurface* __restrict__ l
          i += (int64_t)gridDim.x * blockDim.x) {
         Ray r = load_ray(R, i);
         trace_ray<FWD, MP, PREFETCH>(lens, first, last, kernarg_at(0), r, conv_mask ? lds_mask : nullptr);
+        if (TO_SENSOR) propagate_to<MP>(r, z_sensor);
         store_ray(W, i, r);
     }
     __syncthreads();
@@ -447,9 +450,9 @@ int sdirt_trace(const sdirt_lens* lens, int32_t first, int32_t last, int32_t bac
     return sdirt_trace_to(lens, first, last, backward, trips, flags, rays, rays, M, conv_mask, stream);
 }
 
-int sdirt_trace_to(const sdirt_lens* lens, int32_t first, int32_t last, int32_t backward,
-                   const int32_t* trips, uint32_t flags, sdirt_rays rays, sdirt_rays out, int64_t M,
-                   uint32_t* conv_mask, void* stream)
+static int launch_trace(const sdirt_lens* lens, int32_t first, int32_t last, int32_t backward,
+                        const int32_t* trips, uint32_t flags, sdirt_rays rays, sdirt_rays out, int64_t M,
+                        uint32_t* conv_mask, void* stream, bool to_sensor, double z_sensor)
 {
     if (!lens) return fail(SDIRT_ERR_INVALID_ARGUMENT, "null lens");
     if (first < 0 || last > lens->n_surfaces || first > last)
@@ -472,19 +475,23 @@ int sdirt_trace_to(const sdirt_lens* lens, int32_t first, int32_t last, int32_t 
                 if (src[c] && dst[c] != src[c])
                     HIP_TRY(hipMemcpyAsync(dst[c], src[c], sizeof(float) * (size_t)M, hipMemcpyDeviceToDevice, st));
         }
-        return SDIRT_OK;
+        return to_sensor ? sdirt_propagate_to(z_sensor, out, M, stream) : SDIRT_OK;
     }
     const int grid = grid_for(M, kBlock);
     const bool lean = (flags & SDIRT_PSF_STRICT_IEEE) == 0;
     const bool prefetch = (flags & SDIRT_TRACE_NO_PREFETCH) == 0;
-#define SDIRT_LAUNCH_TRACE_P(FW, MM, PF)                                                        \
-    k_trace<FW, MM, PF><<<grid, kBlock, 0, as_stream(stream)>>>(tt, lens->dev, lens->n_surfaces, \
-                                                                first, last, rays, out, M, conv_mask)
+    const float zs = (float)z_sensor;
+#define SDIRT_LAUNCH_TRACE_P(FW, MM, PF, TS)                                                        \
+    k_trace<FW, MM, PF, TS><<<grid, kBlock, 0, as_stream(stream)>>>(tt, lens->dev, lens->n_surfaces, \
+                                                                    first, last, rays, out, M, conv_mask, zs)
 #define SDIRT_LAUNCH_TRACE(FW, MM)                                                              \
     do {                                                                                        \
-        if (prefetch) SDIRT_LAUNCH_TRACE_P(FW, MM, true); else SDIRT_LAUNCH_TRACE_P(FW, MM, false); \
+        if (prefetch) SDIRT_LAUNCH_TRACE_P(FW, MM, true, false); else SDIRT_LAUNCH_TRACE_P(FW, MM, false, false); \
     } while (0)
-    if (backward) {
+    if (to_sensor) {                           // forward, prefetching loop only (the self-test form has no use for it)
+        if (backward || !prefetch) return fail(SDIRT_ERR_UNSUPPORTED, "trace2sensor traces forward with the prefetching loop");
+        if (lean) SDIRT_LAUNCH_TRACE_P(true, Lean, true, true); else SDIRT_LAUNCH_TRACE_P(true, Ieee, true, true);
+    } else if (backward) {
         if (lean) SDIRT_LAUNCH_TRACE(false, Lean); else SDIRT_LAUNCH_TRACE(false, Ieee);
     } else {
         if (lean) SDIRT_LAUNCH_TRACE(true, Lean); else SDIRT_LAUNCH_TRACE(true, Ieee);
@@ -493,6 +500,20 @@ int sdirt_trace_to(const sdirt_lens* lens, int32_t first, int32_t last, int32_t 
 #undef SDIRT_LAUNCH_TRACE
     LAUNCH_CHECK();
     return SDIRT_OK;
+}
+
+int sdirt_trace_to(const sdirt_lens* lens, int32_t first, int32_t last, int32_t backward,
+                   const int32_t* trips, uint32_t flags, sdirt_rays rays, sdirt_rays out, int64_t M,
+                   uint32_t* conv_mask, void* stream)
+{
+    return launch_trace(lens, first, last, backward, trips, flags, rays, out, M, conv_mask, stream, false, 0.0);
+}
+
+int sdirt_trace2sensor(const sdirt_lens* lens, const int32_t* trips, uint32_t flags, double d_sensor, sdirt_rays rays,
+                       sdirt_rays out, int64_t M, uint32_t* conv_mask, void* stream)
+{
+    if (!lens) return fail(SDIRT_ERR_INVALID_ARGUMENT, "null lens");
+    return launch_trace(lens, 0, lens->n_surfaces, 0, trips, flags, rays, out, M, conv_mask, stream, true, d_sensor);
 }
 
 int sdirt_propagate_to(double z, sdirt_rays rays, int64_t M, void* stream)

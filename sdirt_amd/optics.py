@@ -507,9 +507,11 @@ class Lensgroup:
         return xy[:spp], xy[spp:a], xy[a:b], xy[b:]
 
     # ----------------------------------------------------------------- tracing
-    def trace(self, ray, lens_range=None, record=False, forward=None):
+    def trace(self, ray, lens_range=None, record=False, forward=None, _to_sensor=None):
         """optics.py:601-627: in place; returns (ray, valid, oss).  Direction is
-        taken from the first ray's d_z like the reference unless `forward` is given."""
+        taken from the first ray's d_z like the reference unless `forward` is given.
+        _to_sensor = z: trace2sensor's form -- forward through all surfaces and on to the plane z in the same pass
+        (sdirt_trace2sensor)."""
         self._require_gpu()
         K = len(self.surfaces)
         if record:
@@ -538,6 +540,11 @@ class Lensgroup:
             dst = Ray.empty(ray.shape, ray.wvln, self.device)
 
             def enqueue_to(trips, mask_ptr):
+                if _to_sensor is not None:
+                    _lib.check(_lib.lib().sdirt_trace2sensor(handle, trips, self._math_flags(), float(_to_sensor),
+                                                             ray.c_rays(), dst.c_rays(), ray.numel, mask_ptr,
+                                                             stream_ptr(self.device)))
+                    return
                 _lib.check(_lib.lib().sdirt_trace_to(handle, first, last, 0 if forward else 1, trips,
                                                      self._math_flags(), ray.c_rays(), dst.c_rays(), ray.numel,
                                                      mask_ptr, stream_ptr(self.device)))
@@ -546,6 +553,8 @@ class Lensgroup:
             ray.soa = dst.soa
         else:
             self._run_with_trips(None, order, enqueue)
+            if _to_sensor is not None:
+                ray.propagate_to(_to_sensor)
         valid = ray.ra == 1
         return ray, valid, None
 
@@ -572,6 +581,9 @@ class Lensgroup:
         """optics.py:638-664.  record=True: (p, oss) -- the sensor-plane positions [M,3] and the
         recorded paths, each live ray's sensor point appended (twice, as the reference's two loops do)."""
         if not record:
+            if bool(ray.soa[5, 0].item() > 0):                   # forward (optics.py:618): one pass, sdirt_trace2sensor
+                ray, _, _ = self.trace(ray, forward=True, _to_sensor=self.d_sensor)
+                return ray
             ray, _, _ = self.trace(ray)
             return ray.propagate_to(self.d_sensor)
         ray, _, oss = self.trace(ray, record=True)
@@ -1041,20 +1053,17 @@ class Lensgroup:
             cen[:, 0] = pts[:, 0] * (self.sensor_size[1] / 2)               # optics.py:973-975
             cen[:, 1] = pts[:, 1] * (self.sensor_size[0] / 2)
         self.last_pupil_points = (x2, y2, xc, yc)
-        self.trace(ray, forward=True)
-        ray.propagate_to(self.d_sensor)
+        self.trace(ray, forward=True, _to_sensor=self.d_sensor)        # trace2sensor, one pass
         need_r = want_r and not default_r_zero
         L, R = self._psf_buffers(out, N, ks, need_r)
         dpp = None if (dp is None or default_r_zero) else _lib.DpParams(*[float(v) for v in dp])
         h, st = _lib.lib(), stream_ptr(self.device)
         with self._timed("forward_integral"):
+            # normalised on the way out of the tiles (optics.py:983-987): no second pass over the grids
             _lib.check(h.sdirt_forward_integral(ray.c_rays(), spp, N, float(self.pixel_size), int(ks), dptr(cen),
-                                                C.byref(dpp) if dpp is not None else None, self._math_flags(),
+                                                C.byref(dpp) if dpp is not None else None,
+                                                self._math_flags() | (_lib.PSF_NORMALIZE if normalize else 0),
                                                 dptr(L), dptr(R), st))
-        if normalize:
-            for g in (L, R):
-                if g is not None:
-                    _lib.check(h.sdirt_psf_normalize(dptr(g), N, int(ks), st))
         if R is None and want_r:
             R = torch.zeros_like(L)
         if single_point:

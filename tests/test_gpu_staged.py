@@ -185,3 +185,48 @@ def test_forward_integral_random_batch_shapes_against_the_oracle(oracle, seed):
     print(f"seed {seed}: N={N} S={S} ks={ks} dp={None if dp is None else [round(v, 3) for v in dp]} {precision}: "
           f"|L - oracle| {dl:.2e} |R - oracle| {dr:.2e} of the peak")
     assert dl <= 2e-6 and dr <= 2e-6
+
+
+@pytest.mark.parametrize("precision", ["lean", "ieee"])
+def test_fused_calls_equal_the_two_step_forms_bit_for_bit(lens, precision):
+    """sdirt_trace2sensor = sdirt_trace_to + sdirt_propagate_to, and sdirt_forward_integral(SDIRT_PSF_NORMALIZE) =
+    sdirt_forward_integral + sdirt_psf_normalize, to the last bit: the fused forms only skip a pass over memory."""
+    from sdirt_amd import _lib
+    from sdirt_amd.basics import Ray, dptr, stream_ptr
+    h, st = _lib.lib(), stream_ptr(torch.device(DEV))
+    lens.precision = precision
+    try:
+        pts = _points(96, seed=9)
+        po = lens._points_to_object(pts)
+        x2, y2 = _pupil(lens, 1500, 13)
+        a = _sample(lens, po, x2, y2)
+        b = a.clone()
+        lens.trace2sensor(a)                                   # one pass
+        lens.trace(b, forward=True)
+        b.propagate_to(lens.d_sensor)                          # two passes
+        assert torch.equal(a.soa.view(torch.int32), b.soa.view(torch.int32))
+        flags = lens._math_flags()
+        dp = _lib.DpParams(*DP)
+        for n, ks in ((96, 33), (3, 21)):                      # a workgroup per point / few points: the spp axis is cut
+            cen = torch.zeros((n, 2), device=DEV)
+            _lib.check(h.sdirt_center_from_rays(a.c_rays(), 1500, 96, dptr(torch.zeros((96, 2), device=DEV)), None, st))
+            sub = Ray.empty((1500, n), 0.589, DEV)
+            sub.soa.copy_(a.soa.view(8, 96, 1500)[:, :n].reshape(8, -1))
+            _lib.check(h.sdirt_center_from_rays(sub.c_rays(), 1500, n, dptr(cen), None, st))
+            L1, R1 = torch.empty((n, ks, ks), device=DEV), torch.empty((n, ks, ks), device=DEV)
+            L2, R2 = torch.empty_like(L1), torch.empty_like(R1)
+            _lib.check(h.sdirt_forward_integral(sub.c_rays(), 1500, n, float(lens.pixel_size), ks, dptr(cen), C.byref(dp),
+                                                flags | _lib.PSF_NORMALIZE, dptr(L1), dptr(R1), st))
+            plan = (C.c_int64 * 6)()
+            assert h.sdirt_forward_integral_plan(n, 1500, ks, 1, 256, plan) == 0
+            _lib.check(h.sdirt_forward_integral(sub.c_rays(), 1500, n, float(lens.pixel_size), ks, dptr(cen), C.byref(dp),
+                                                flags, dptr(L2), dptr(R2), st))
+            _lib.check(h.sdirt_psf_normalize(dptr(L2), n, ks, st))
+            _lib.check(h.sdirt_psf_normalize(dptr(R2), n, ks, st))
+            if plan[3] == 1:
+                assert torch.equal(L1, L2) and torch.equal(R1, R2)
+            else:                                              # partial tiles meet in HBM in arrival order
+                assert float((L1 - L2).abs().max()) <= 3e-7 and float((R1 - R2).abs().max()) <= 3e-7
+            assert float(L1.amax()) > 0.999 and float(R1.amax()) > 0.999
+    finally:
+        lens.precision = "lean"
