@@ -385,8 +385,19 @@ def bench_staged(args, emit=True, lens=None, ks_list=None):
             ("psf_normalize", lambda: (h.sdirt_psf_normalize(dptr(L), N, ks, st) or h.sdirt_psf_normalize(dptr(R), N, ks, st))),
         ]
 
-        def chain(ev=None):
-            for name, fn in calls:
+        # the same work with the two fused entries: trace2sensor in one pass, grids normalised out of the LDS tiles
+        ray2 = Ray.empty((S, N), 0.589, dev)
+        calls_fused = [
+            calls[0], calls[1],
+            ("trace2sensor", lambda: h.sdirt_trace2sensor(handle, trips_t, flags, float(lens.d_sensor), ray.c_rays(), ray2.c_rays(),
+                                                          M, dptr(mask_t), st)),
+            ("forward_integral_normalized", lambda: h.sdirt_forward_integral(ray2.c_rays(), S, N, float(lens.pixel_size), ks,
+                                                                             dptr(cen), C.byref(dp), flags | _lib.PSF_NORMALIZE,
+                                                                             dptr(L), dptr(R), st)),
+        ]
+
+        def chain(ev=None, which=None):
+            for name, fn in (which or calls):
                 if ev is not None:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record(stream)
@@ -411,6 +422,18 @@ def bench_staged(args, emit=True, lens=None, ks_list=None):
         torch.cuda.synchronize(dev)
         wall = (time.perf_counter() - t0) / steps * 1e3
         ms = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in ev.items()}
+        L_two_step = L.clone()
+        chain(which=calls_fused)
+        torch.cuda.synchronize(dev)
+        # (one ulp at most: the float64 sums of a tile meet in arrival order before they are rounded to fp32)
+        assert float((L - L_two_step).abs().max()) <= 1.2e-7, "fused calls: PSFs differ from the call-by-call chain"
+        ev2 = {}
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            chain(ev2, calls_fused)
+        torch.cuda.synchronize(dev)
+        wall2 = (time.perf_counter() - t0) / steps * 1e3
+        ms2 = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in ev2.items()}
         grids = 2 * N * ks * ks * 4
         alg = {"sample_rays": 28 * M + 12 * N + 8 * S,
                "trace": 56 * M,
@@ -440,7 +463,10 @@ def bench_staged(args, emit=True, lens=None, ks_list=None):
             kern[name] = k
         kern["trace"]["bound"] = kern["chief_center"]["bound"] = "valu"
         out[f"ks{ks}"] = {"ms_per_step": wall, "rays_per_s": M / (wall * 1e-3), "psfs_per_s": N / (wall * 1e-3),
-                          "kernels": kern, "sum_of_kernels_ms": float(sum(ms.values()))}
+                          "kernels": kern, "sum_of_kernels_ms": float(sum(ms.values())),
+                          # sample -> chief centre -> sdirt_trace2sensor -> sdirt_forward_integral(SDIRT_PSF_NORMALIZE):
+                          # the same PSFs (checked above) with two passes over memory less
+                          "fused_calls": {"ms_per_step": wall2, "rays_per_s": M / (wall2 * 1e-3), "kernels_ms": ms2}}
     first = out[f"ks{ks_list[0]}"]
     dom = max(("sample_rays", "propagate_to", "forward_integral"), key=lambda k: first["kernels"][k]["ms"])
     kd = first["kernels"][dom]
