@@ -422,18 +422,23 @@ def bench_staged(args, emit=True, lens=None, ks_list=None):
         torch.cuda.synchronize(dev)
         wall = (time.perf_counter() - t0) / steps * 1e3
         ms = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in ev.items()}
-        L_two_step = L.clone()
-        chain(which=calls_fused)
-        torch.cuda.synchronize(dev)
-        # (one ulp at most: the float64 sums of a tile meet in arrival order before they are rounded to fp32)
-        assert float((L - L_two_step).abs().max()) <= 1.2e-7, "fused calls: PSFs differ from the call-by-call chain"
-        ev2 = {}
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            chain(ev2, calls_fused)
-        torch.cuda.synchronize(dev)
-        wall2 = (time.perf_counter() - t0) / steps * 1e3
-        ms2 = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in ev2.items()}
+        fused = None
+        if getattr(args, "staged_chain", "both") == "both":
+            L_two_step = L.clone()
+            chain(which=calls_fused)
+            torch.cuda.synchronize(dev)
+            # (one ulp at most: the float64 sums of a tile meet in arrival order before they are rounded to fp32)
+            assert float((L - L_two_step).abs().max()) <= 1.2e-7, "fused calls: PSFs differ from the call-by-call chain"
+            ev2 = {}
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                chain(ev2, calls_fused)
+            torch.cuda.synchronize(dev)
+            wall2 = (time.perf_counter() - t0) / steps * 1e3
+            ms2 = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in ev2.items()}
+            # sample -> chief centre -> sdirt_trace2sensor -> sdirt_forward_integral(SDIRT_PSF_NORMALIZE): the same PSFs
+            # (checked above) with two passes over memory less
+            fused = {"ms_per_step": wall2, "rays_per_s": M / (wall2 * 1e-3), "kernels_ms": ms2}
         grids = 2 * N * ks * ks * 4
         alg = {"sample_rays": 28 * M + 12 * N + 8 * S,
                "trace": 56 * M,
@@ -463,10 +468,7 @@ def bench_staged(args, emit=True, lens=None, ks_list=None):
             kern[name] = k
         kern["trace"]["bound"] = kern["chief_center"]["bound"] = "valu"
         out[f"ks{ks}"] = {"ms_per_step": wall, "rays_per_s": M / (wall * 1e-3), "psfs_per_s": N / (wall * 1e-3),
-                          "kernels": kern, "sum_of_kernels_ms": float(sum(ms.values())),
-                          # sample -> chief centre -> sdirt_trace2sensor -> sdirt_forward_integral(SDIRT_PSF_NORMALIZE):
-                          # the same PSFs (checked above) with two passes over memory less
-                          "fused_calls": {"ms_per_step": wall2, "rays_per_s": M / (wall2 * 1e-3), "kernels_ms": ms2}}
+                          "kernels": kern, "sum_of_kernels_ms": float(sum(ms.values())), "fused_calls": fused}
     first = out[f"ks{ks_list[0]}"]
     dom = max(("sample_rays", "propagate_to", "forward_integral"), key=lambda k: first["kernels"][k]["ms"])
     kd = first["kernels"][dom]
@@ -614,6 +616,9 @@ def main():
                          "timing harness PSFNet.time_compare_psf (psfnet.py:570-586); staged: the reference's own "
                          "call sequence sample -> trace -> propagate -> forward_integral on SoA rays in HBM")
     ap.add_argument("--staged-ks", default="65,21", help="--workload staged: the grid sizes to run the chain for")
+    ap.add_argument("--staged-chain", choices=("both", "calls"), default="both",
+                    help="--workload staged: `calls` times the call-by-call chain only (the profiling recipe: one kernel "
+                         "per name), `both` also the chain through sdirt_trace2sensor / SDIRT_PSF_NORMALIZE")
     args = ap.parse_args()
     if args.workload in EXTRA_WORKLOADS:
         assert args.gpus == 1, f"--workload {args.workload} is a single-GPU measurement"

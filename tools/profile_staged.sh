@@ -10,9 +10,9 @@ COMMIT=${1:-unknown}; RND=${2:-r04}; KS=${3:-65}
 OUT=gpurun_out/prof_${RND}_staged_ks${KS}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-CMD="python3 bench.py --workload staged --staged-ks $KS --steps 10 --warmup 2"
+CMD="python3 bench.py --workload staged --staged-ks $KS --staged-chain calls --steps 10 --warmup 2"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $CMD > "$OUT/trace.log" 2>&1
-CMD="python3 bench.py --workload staged --staged-ks $KS --steps 3 --warmup 2"
+CMD="python3 bench.py --workload staged --staged-ks $KS --staged-chain calls --steps 3 --warmup 2"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- $CMD > "$OUT/pmc_fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- $CMD > "$OUT/pmc_write.log" 2>&1
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --output-format csv -d "$OUT/pmc_tcc" -- $CMD > "$OUT/pmc_tcc.log" 2>&1
