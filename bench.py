@@ -425,7 +425,8 @@ def bench_staged(args, emit=True, lens=None, ks_list=None):
         fused = None
         if getattr(args, "staged_chain", "both") == "both":
             L_two_step = L.clone()
-            chain(which=calls_fused)
+            for _ in range(max(args.warmup, 2) + 1):         # first touch of the second bundle, first launches of two kernels
+                chain(which=calls_fused)
             torch.cuda.synchronize(dev)
             # (one ulp at most: the float64 sums of a tile meet in arrival order before they are rounded to fp32)
             assert float((L - L_two_step).abs().max()) <= 1.2e-7, "fused calls: PSFs differ from the call-by-call chain"
