@@ -325,11 +325,13 @@ KERNEL_OF = {"sample_rays": "k_sample_rays", "trace": "k_trace", "propagate_to":
 def bench_staged(args, emit=True, lens=None, ks_list=None):
     """The API-compatible STAGED sequence of the reference (optics.py:460-494 sample_from_points, :889-904 psf_center,
     :638-664 trace2sensor, monte_carlo.py:9-68 forward_integral, optics.py:983-987 normalise) as the library calls a
-    caller of those functions makes, rays held in HBM as SoA [spp, N] (8 arrays of 4 bytes per ray):
+    caller of those functions makes, rays held in HBM as a point-major SoA bundle (8 arrays of 4 bytes per ray):
         sdirt_sample_rays -> sdirt_chief_center -> sdirt_trace -> sdirt_propagate_to -> sdirt_forward_integral ->
         sdirt_psf_normalize (L, R)
     on 4096 points of the config-2 volume (every 4th: all 16 depth planes) x 4096 spp, for 65x65 and 21x21 grids.
-    One "step" = the whole chain once; every call is bracketed by HIP events on the stream it is launched on.
+    One "step" = the whole chain once; every call is bracketed by HIP events on the stream it is launched on.  The same
+    PSFs through the two fused entries (sdirt_trace2sensor, SDIRT_PSF_NORMALIZE on sdirt_forward_integral) are timed beside
+    it (`fused_calls`).
     Algorithmic bytes per ray: sampler write o, d, ra = 28 B; trace read 28 + write 28; propagate read
     o, d_xyz = 24 + write o = 12; forward_integral read ox, oy, dx, dz, ra = 20 + the grids written once."""
     import ctypes as C
