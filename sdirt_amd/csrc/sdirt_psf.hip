@@ -114,7 +114,7 @@ k_forward_integral_hbm(sdirt_rays R, int64_t S, int64_t N, SplatGeom gm, DevDpPa
 // A workgroup OWNS P consecutive points (one, unless a point has fewer samples than the workgroup has threads)
 // and a slice of the spp axis: their L/R tiles live in LDS for the whole kernel (no global atomics, no memset,
 // each tile stored once, coalesced) -- or, when the few points of a call are cut along spp (nsplit > 1), added
-// once per workgroup to the zeroed output.  Thread t works on sample t % rp of point t / rp (rp = 1024 / P): a wave
+// once per workgroup to the zeroed output.  Thread t works on sample t % rp of point t / rp (rp = 512 / P): a wave
 // reads 64 consecutive samples of one point, 256 contiguous bytes per component (sample-major bundles, the
 // reference's tensor order, gave a workgroup 8 to 32 useful bytes of every 128-byte line: 44.8 M L2 requests and
 // 352 us for the 16.8 M rays of the staged bench at ks 65, profiles/r04/staged_pmc_sample_major.json).
@@ -124,7 +124,7 @@ k_forward_integral_hbm(sdirt_rays R, int64_t S, int64_t N, SplatGeom gm, DevDpPa
 // 8-20 (tools/lds_atomic_bench.hip, profiles/r04/lds_atomic_bench*.txt) -- with eight adds per ray the fp32 form
 // IS the kernel's time (350 of 350 us on 8.4 M rays).  A double sum rounded once on the way out is also nearer to
 // the reference's sequential fp32 sum's exact value than any fp32 summation order, and takes any weight `ra`.
-constexpr int kFiThreads = 1024;
+constexpr int kFiThreads = 512;          // 256 / 512 / 1024 measured on nine batch shapes: 512 is 3-12 % ahead (profiles/r04)
 constexpr int kFiDepth = 2;             // passes whose rays are in flight (2, 4, 8 time within 7 %: profiles/r04)
 struct FiLaunch {
     int P, logRp;         // points per workgroup; log2(samples per pass and point = kFiThreads / P)
@@ -683,9 +683,9 @@ static bool plan_forward_integral(int64_t N, int64_t S, int ks, int ntile, size_
     const size_t per_point = acc * (size_t)fl.stride;
     if (per_point > lds_max) return false;
     // one point per workgroup unless a point has fewer samples than the workgroup has threads (whole waves per
-    // point: at most 16 points), and never more than LDS holds
+    // point: at most kFiThreads / 64 points), and never more than LDS holds
     int P = 1;
-    while (P < 16 && (int64_t)(kFiThreads / (2 * P)) >= S) P *= 2;
+    while (P < kFiThreads / 64 && (int64_t)(kFiThreads / (2 * P)) >= S) P *= 2;
     while (P > 1 && (size_t)P * per_point > lds_max) P /= 2;
     fl.P = P;
     const int rp = kFiThreads / P;

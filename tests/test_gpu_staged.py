@@ -1,7 +1,7 @@
 """The STAGED ray pipeline (rays in HBM as a point-major SoA bundle; deeplens/optics.py:460-494, :638-664,
 deeplens/monte_carlo.py:9-68) through the C ABI: the vectorised sample / propagate kernels against their
 one-ray-per-thread forms bit for bit, forward_integral with the grids in LDS against the CPU oracle's splat
-and against the fused kernel, for every launch shape its planner produces (points per workgroup 1..16,
+and against the fused kernel, for every launch shape its planner produces (points per workgroup 1..8,
 ragged point and sample counts, the spp axis cut or not, float tiles and the HBM fallback above SDIRT_MAX_KS)."""
 import ctypes as C
 
@@ -87,9 +87,9 @@ def _oracle_splat(oracle, st, ray, cen, ks, dp, n):
 
 @pytest.mark.parametrize("n,spp,ks,dp", [
     (300, 1024, 21, DP),          # one point per workgroup, one pass
-    (1100, 200, 9, DP),           # four points per workgroup (fewer samples than threads), N % 4 != 0, ragged rows
+    (1100, 200, 9, DP),           # two points per workgroup (fewer samples than threads), N % 2 != 0 ... ragged rows
     (520, 512, 65, DP),           # two points per workgroup on 135 KB of double accumulators
-    (130, 50, 65, DP),            # sixteen points would not fit: LDS caps the points per workgroup
+    (130, 50, 65, DP),            # eight points would not fit: LDS caps the points per workgroup
     (5, 1024, 120, DP),           # two double tiles no longer fit: float accumulators
     (3, 4096, 65, DP),            # a handful of points: the spp axis cut into slices, tiles added to the output
     (37, 700, 33, None),          # param_list=None: L only, R stays zero

@@ -510,8 +510,8 @@ def test_forward_integral_launch_plan_for_every_grid_and_batch_shape():
             continue
         assert acc == 8 or (tile | 1) * 8 > 160 * 1024 - 1024      # float tiles only when double ones do not fit
         assert lds == acc * P * (tile | 1) <= 160 * 1024 - 1024
-        assert P in (1, 2, 4, 8, 16) and groups == -(-n // P)
-        rp = 1024 // P
+        assert P in (1, 2, 4, 8) and groups == -(-n // P)
+        rp = 512 // P                                               # 512-thread workgroups, whole waves per point
         assert chunk % rp == 0 and chunk >= rp
         assert nsplit == -(-s // chunk) and nsplit * chunk >= s > (nsplit - 1) * chunk
         if P > 1:
