@@ -540,6 +540,7 @@ def also_block(args, lens, device):
     # allocations) dips for some tens of ms shortly after work resumes (tools/clock_ramp.py), longer than five such steps
     qs = copy.copy(q)
     qs.steps, qs.warmup = 10, 40
+    qs.staged_chain = "calls"          # the call-by-call chain; `--workload staged` also times the fused entries
     for name, fn in (("staged", lambda: bench_staged(qs, emit=False, lens=lens)),
                      ("f1", lambda: bench_f1(q, emit=False)),
                      ("c4", lambda: quick_volume("c4", 5, device)),
