@@ -110,9 +110,10 @@ def test_config3_whole_grid_sharded_over_eight_ranks(tmp_path, oracle):
           f"({int((cu > 0).sum())} of {cu.size} differ); max|dL| {dl.max():.3e} (point {int(dl.argmax())}) "
           f"max|dR| {dr.max():.3e} (point {int(dr.argmax())}) of peak 1")
     assert cu.max() <= 1
-    # measured 5.2e-6 / 4.6e-6 (one pixel in 57.8 M): fp32 sums of up to 8192 terms in LDS-atomic order here, in sample
-    # order in the oracle (and in the reference's index_put_) -- 8192 x 4 additions each rounded at ~2^-24 of a peak-sized sum
-    assert dl.max() <= 1e-5 and dr.max() <= 1e-5
+    # measured over four runs: max|dL| 5.2e-6 ... 5.6e-6, max|dR| 4.6e-6 ... 7.2e-6 (the one worst pixel of 57.8 M): fp32 sums of
+    # up to 8192 terms in LDS-atomic order here, in sample order in the oracle (and in the reference's index_put_) -- 8192 x 4
+    # additions each rounded at ~2^-24 of a peak-sized sum; the bound leaves room for the arrival order of another run
+    assert dl.max() <= 1.5e-5 and dr.max() <= 1.5e-5
 
 
 @pytest.mark.gpu
