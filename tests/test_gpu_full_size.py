@@ -63,3 +63,29 @@ def test_whole_batch_against_the_oracle(oracle, case):
           f"(point {int(dr.argmax())}) of peak 1")
     assert cu.max() <= 1
     assert dl.max() <= 5e-6 and dr.max() <= 5e-6
+
+
+def test_staged_chain_equals_the_fused_kernel_on_the_whole_config2_volume():
+    """The reference's own call sequence on rays staged in HBM (sample_from_points -> psf_center -> trace2sensor ->
+    forward_integral -> normalise: 67 M rays = 2.1 GB of point-major SoA) against the fused kernel on the WHOLE config-2
+    volume, same pupil points: the same batch-global trip tables, bit-equal centres, every L and R PSF."""
+    import bench
+    st = load_state("rf50mm")
+    lens = make_lens("rf50mm", DEV, st)
+    pts = bench.volume_points(1, "c2")
+    N = pts.shape[0]
+    torch.manual_seed(77)
+    x2, y2, xc, yc = lens._pupil_samples_pair(4096, lens.entrance_pupil()[1], 2048, lens.entrance_pupil(shrink_pupil=True)[1],
+                                              side_stream=False)
+    cen_f = torch.empty((N, 2), dtype=torch.float32, device=DEV)
+    Lf, Rf = lens.psf_lr(pts, ks=65, dp=DP, pupil_xy=(x2, y2), center_pupil_xy=(xc, yc), center_out=cen_f)
+    t_fused = np.asarray(lens.trips.cache[("psf", 0.589, "lean")])
+    po = lens._points_to_object(pts)
+    cen_s = torch.empty((N, 2), dtype=torch.float32, device=DEV)
+    Ls, Rs = lens._psf_lr_staged(pts, po, N, 65, 0.589, 4096, True, DP, True, True, False, (x2, y2), (xc, yc), None, cen_s, False)
+    t_staged = np.asarray(lens.trips.cache[("trace", 0.589, 0, len(lens.surfaces), True, "lean")])
+    assert np.array_equal(t_fused, t_staged), (t_fused, t_staged)
+    assert torch.equal(cen_f, cen_s)
+    dl, dr = float((Lf - Ls).abs().max()), float((Rf - Rs).abs().max())
+    print(f"whole config 2, staged chain vs fused kernel: trips {t_staged.tolist()}, centres bit-equal, max|dL| {dl:.3e} max|dR| {dr:.3e}")
+    assert dl <= 4e-6 and dr <= 4e-6
