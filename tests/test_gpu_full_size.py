@@ -88,4 +88,4 @@ def test_staged_chain_equals_the_fused_kernel_on_the_whole_config2_volume():
     assert torch.equal(cen_f, cen_s)
     dl, dr = float((Lf - Ls).abs().max()), float((Rf - Rs).abs().max())
     print(f"whole config 2, staged chain vs fused kernel: trips {t_staged.tolist()}, centres bit-equal, max|dL| {dl:.3e} max|dR| {dr:.3e}")
-    assert dl <= 4e-6 and dr <= 4e-6
+    assert dl <= 6e-6 and dr <= 6e-6        # measured 2.7e-6 / 1.9e-6: the fused kernel's fp32 LDS-atomic order (138 M pixels)
