@@ -683,23 +683,26 @@ def main():
         # stream, so a gather issued on the default group would hold back the next step's small
         # pupil broadcast (and with it the next kernel) until 4 GB have moved
         gather_group = dist.new_group() if gather_default else None
-        gather_buf = [tuple(torch.empty((n_total, KS, KS), dtype=torch.float32, device=device)
-                            for _ in range(2)) for _ in range(2)] if gather_default else None
+    # A rank renders into ONE [width, 2, ks, ks] block per step -- point n's left grid at [n, 0], its right grid at
+    # [n, 1] (SDIRT_PSF_INTERLEAVED) -- which is also what the gather sends: one collective per step, no staging copy
+    # (sdirt_amd/dist.py: ShardedPSF.shard_buffer / gather; the library path and the benchmarked path are the same).
+    width = max(b_ - a_ for a_, b_ in sd.shard_bounds(n_total, world))
+    gather_buf = [torch.empty((world * width, 2, KS, KS), dtype=torch.float32, device=device)
+                  for _ in range(2)] if gather_default else None
     step_no = [0]
-    # output buffers are owned by the caller and re-used (the previous steps' PSFs may still be
+    # output blocks are owned by the caller and re-used (the previous steps' PSFs may still be
     # feeding the all-gather / the consumer while the next step renders)
     DEPTH = 8        # calls kept in flight (kernel enqueued, Newton trip check pending): ~80 ms of queued work
-    out_bufs = [tuple(torch.empty((n_local, KS, KS), dtype=torch.float32, device=device)
-                      for _ in range(2)) for _ in range(DEPTH + 1)]
+    out_bufs = [torch.zeros((width, 2, KS, KS), dtype=torch.float32, device=device) for _ in range(DEPTH + 1)]
 
-    gather_done = [None] * (DEPTH + 1)   # per output buffer set: event of the last gather reading it
+    gather_done = [None] * (DEPTH + 1)   # per output block: event of the last gather reading it
     gathers = [0]
     gather_events = []                   # (start, end) on the comm stream, one pair per step's all-gather
     in_flight = []                       # (PendingPSF, out, slot, ready event | None)
 
     def settle(keep=0):
         """Newton trip checks (lens.psf_lr(defer=True)) of all but the `keep` newest steps, each
-        followed -- when the step asked for it -- by the all-gather of its now final shards on
+        followed -- when the step asked for it -- by the all-gather of its now final shard on
         the comm stream.  The host stays `keep` kernels ahead of the GPU: the GPU renders step
         i+1 while the host verifies step i and RCCL moves step i's PSFs, and a descheduled host
         thread (the boxes are shared) does not leave the GPU idle."""
@@ -709,7 +712,7 @@ def main():
             pend.wait()
             if ready is None:
                 continue
-            if lens.trips.relaunches != r0:          # re-rendered: the shards are ready later
+            if lens.trips.relaunches != r0:          # re-rendered: the shard is ready later
                 ready = torch.cuda.Event()
                 ready.record(torch.cuda.current_stream(device))
             buf = gather_buf[gathers[0] % 2]
@@ -718,8 +721,7 @@ def main():
                 comm_stream.wait_event(ready)
                 g0 = torch.cuda.Event(enable_timing=True)
                 g0.record(comm_stream)
-                sd.all_gather_shards(out[0], n_total, world, group=gather_group, out=buf[0])
-                sd.all_gather_shards(out[1], n_total, world, group=gather_group, out=buf[1])
+                sharded.gather(out, n_total, out=buf, group=gather_group)      # ONE collective: [width, 2, ks, ks] per rank
                 done = torch.cuda.Event(enable_timing=True)
                 done.record(comm_stream)
                 gather_events.append((g0, done))
@@ -730,7 +732,7 @@ def main():
         out = out_bufs[slot]
         step_no[0] += 1
         if world == 1:
-            in_flight.append((lens.psf_lr(points_local, ks=KS, spp=SPP, dp=DP, out=out, defer=True),
+            in_flight.append((lens.psf_lr(points_local, ks=KS, spp=SPP, dp=DP, out=out[:n_local], defer=True),
                               out, slot, None))
             settle(keep=DEPTH)
             return out
@@ -739,7 +741,7 @@ def main():
             torch.cuda.current_stream(device).wait_event(gather_done[slot])
             gather_done[slot] = None
         pupil = sd.broadcast_pupil_points(lens, SPP)
-        pend = sharded.render(points_local, pupil, out, defer=True)
+        pend = sharded.render(points_local, pupil, out[:n_local], defer=True)
         ready = None
         if gather:
             ready = torch.cuda.Event()
@@ -913,13 +915,14 @@ def main():
             compute_ms = k_ms[dom]
             res["gather"] = {"algo": os.environ.get("SDIRT_GATHER_ALGO", "allgather"),
                              "backend": dist.get_backend(gather_group), "world_size": dist.get_world_size(gather_group),
-                             "gb_received_per_rank_per_step": gb,
+                             "gb_received_per_rank_per_step": gb, "collectives_per_step": 1,
+                             "block": f"[{width}, 2, {KS}, {KS}] fp32 per rank, rendered in place (SDIRT_PSF_INTERLEAVED)",
                              "ms": gather_ms, "GBps_received_per_rank": gb / (gather_ms * 1e-3) if gather_ms else None,
                              "compute_ms": compute_ms,
                              # the gather runs on its own stream under the next step's kernel: it costs the step
                              # time only when it takes longer than the kernel it hides under
                              "gather_bound": bool(gather_ms is not None and gather_ms > compute_ms),
-                             "what": "ms = mean HIP-event time of one step's two all-gathers (L, R) on the comm stream in the "
+                             "what": "ms = mean HIP-event time of one step's all-gather (L and R in one block) on the comm stream in the "
                                      "timed region, MAX over ranks; compute_ms = this rank's kernel time per step"}
         if dt_sus is not None:
             res["ms_per_step_sustained"] = dt_sus / k_sus * 1e3

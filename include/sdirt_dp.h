@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SDIRT_ABI_VERSION 2
+#define SDIRT_ABI_VERSION 3
 #define SDIRT_MAX_SURFACES 64
 #define SDIRT_MAX_AI 8
 #define SDIRT_NEWTON_MAXITER 10 /* deeplens/surfaces.py:26 */
@@ -123,6 +123,11 @@ typedef struct sdirt_dp_params {
  * enqueue round 2 -- for callers whose speculated tables have been right for a long streak: three empty
  * launches less per call; when the status comes back non-zero the caller launches the correction itself. */
 #define SDIRT_PSF_ONE_ROUND 16u
+/* sdirt_psf_lr / _centered / _verified / sdirt_psf_call: l_psf and r_psf are the two halves of ONE [N, 2, ks, ks] array --
+ * point n's left grid at l_psf + n * 2 * ks * ks, its right grid ks * ks floats behind it; r_psf must be l_psf + ks * ks,
+ * dp != NULL, one wavelength.  A rank of a multi-GPU volume renders its shard straight into the block that ONE all-gather
+ * moves (`[N/8, 2, ks, ks]`), and L = a[:, 0], R = a[:, 1] are views of the gathered array: no staging copy. */
+#define SDIRT_PSF_INTERLEAVED 32u
 
 /* ---- library ------------------------------------------------------------ */
 int sdirt_abi_version(void);
@@ -330,8 +335,12 @@ int sdirt_psf_rgb(const sdirt_lens* const* lens /*host [n_wvln]*/, int32_t n_wvl
 
 /* How sdirt_psf_lr_centered cuts the spp axis for (n_points, spp): 1 = one workgroup per point (the
  * chief-ray pass runs inside the same kernel); > 1 = few points with many samples (the PSFNet
- * fitting loop: 64 points x 20000 spp, deeplens/psfnet.py:101-167), several workgroups per point. */
-int32_t sdirt_psf_spp_slices(int64_t n_points, int64_t spp);
+ * fitting loop: 64 points x 20000 spp, deeplens/psfnet.py:101-167), several workgroups per point.
+ * n_cus > 0: pure host arithmetic for a device with that many compute units (MI355X: 256; a CPU-only caller);
+ * n_cus <= 0: asks the CURRENT device (initialises the HIP runtime) -- what the launching entries use.  The slice
+ * count sets the order in which partial grids are added (global float atomics), so the last bits of a split call's
+ * PSFs depend on the CU count of the device that rendered them. */
+int32_t sdirt_psf_spp_slices(int64_t n_points, int64_t spp, int32_t n_cus);
 
 /* Control block of sdirt_psf_lr_verified: SDIRT_CTL_WORDS uint32 words at the start of `scratch`. */
 #define SDIRT_CTL_STATUS 0     /* 0: the speculated tables were the reference's (round 2 did nothing);       */

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # SDIRT_AMD_LIB overrides the path (kernel-variant A/B runs in tools/kbench.py only)
 LIB_PATH = os.environ.get("SDIRT_AMD_LIB") or os.path.join(HERE, "libsdirt_dp.so")
 
-ABI_VERSION = 2          # SDIRT_ABI_VERSION of include/sdirt_dp.h this binding was written against
+ABI_VERSION = 3          # SDIRT_ABI_VERSION of include/sdirt_dp.h this binding was written against
 MAX_SURFACES = 64
 MAX_AI = 8
 NEWTON_MAXITER = 10
@@ -22,6 +22,7 @@ PSF_NORMALIZE = 1
 PSF_STRICT_IEEE = 4
 TRACE_NO_PREFETCH = 8
 PSF_ONE_ROUND = 16
+PSF_INTERLEAVED = 32
 CTL_STATUS, CTL_ANY_VALID, CTL_TRIPS2, CTL_MASKS, CTL_WORDS = 0, 1, 16, 64, 320
 
 KIND_PLANE, KIND_SPHERE, KIND_ASPHERE = 0, 1, 2
@@ -84,7 +85,7 @@ SIGNATURES = {
                                          _P, _P, _P, _P, _P, _P, _P]),
     "sdirt_psf_rgb": (C.c_int, [C.POINTER(_P), _I32, _P, _I64, _P, _P, _I64, _D, _D, _D, _I32, _P,
                                 C.POINTER(DpParams), C.POINTER(_I32), _U32, _P, _P, _P, _P]),
-    "sdirt_psf_spp_slices": (_I32, [_I64, _I64]),
+    "sdirt_psf_spp_slices": (_I32, [_I64, _I64, _I32]),
     "sdirt_psf_verified_scratch_bytes": (_I64, [_I64, _I64]),
     "sdirt_psf_lr_verified": (C.c_int, [_P, _P, _P, _I64, _P, _P, _I64, _P, _P, _I64, _D, _D, _D, _I32,
                                         C.POINTER(DpParams), C.POINTER(_I32), C.POINTER(_I32), _U32,

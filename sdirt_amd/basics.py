@@ -2,9 +2,11 @@
 
 Mirrors the parts of deeplens/basics.py that the PSF path reads: the module
 constants (basics.py:18-36), Material.ior (basics.py:299-380) and Ray
-(basics.py:216-296).  Ray keeps its state SoA on the GPU (one [8, M] fp32
-buffer: ox oy oz dx dy dz ra obliq) and hands out the reference's [..., 3]
-tensors only on request.
+(basics.py:216-296).  Ray keeps its state SoA on the GPU (one [7, M] fp32
+buffer: ox oy oz dx dy dz ra; the obliquity factor `obliq`, which nothing on
+the PSF path reads -- monte_carlo.py:46-50 computes and drops it --, in an
+array of its own that exists only once somebody asks for it) and hands out the
+reference's [..., 3] tensors only on request.
 """
 import ctypes as C
 import math
@@ -20,6 +22,11 @@ DEPTH = -20000                           # basics.py:28
 GEO_SPP = 2048                           # basics.py:29
 EPSILON = 1e-9                           # basics.py:35
 MAXT = 1e5                               # basics.py:33
+
+#: True = every Ray carries `obliq` from its construction on, as the reference's does (basics.py:240).  Default:
+#: the array is created by the first read or write of `ray.obliq` (before the bundle is traced) -- a bundle that
+#: nobody asked for its obliquity factor moves 28 instead of 32 bytes per ray through every staged kernel.
+TRACK_OBLIQ = False
 
 _AIRLIKE = ("vacuum", "air", "occluder")
 
@@ -163,13 +170,37 @@ class Ray:
         self.wvln = wvln if wvln < 10 else wvln * 1e-3      # basics.py:235
         self.coherent = False
         self.device = torch.device(device)
-        self.soa = torch.empty((8, max(self.numel, 1)), dtype=torch.float32, device=self.device)
+        self.soa = torch.empty((7, max(self.numel, 1)), dtype=torch.float32, device=self.device)
+        # the obliquity factor: its own [M] array, or None = "all ones so far, not stored"; _ob_lost: the bundle has
+        # been traced without it (the products of surfaces.py:674 were not kept)
+        self._ob = None
+        self._ob_lost = False
+        if TRACK_OBLIQ:
+            self._ob = torch.ones(max(self.numel, 1), dtype=torch.float32, device=self.device)
 
     @classmethod
-    def empty(cls, shape, wvln=DEFAULT_WAVE, device=None):
+    def empty(cls, shape, wvln=DEFAULT_WAVE, device=None, obliq=False):
+        """An uninitialised bundle; obliq=True: with an (uninitialised) obliquity array as well."""
         self = cls.__new__(cls)
         self._init_empty(shape, wvln, device if device is not None else default_device())
+        if obliq and self._ob is None:
+            self._ob = torch.empty(max(self.numel, 1), dtype=torch.float32, device=self.device)
         return self
+
+    @property
+    def has_obliq(self):
+        return self._ob is not None
+
+    def _adopt(self, traced):
+        """Take over the storage of `traced` (the out-of-place result of a trace of THIS bundle): the reference's
+        trace rebinds ray.o / ray.d / ray.ra to new tensors in the same way (surfaces.py:425, 676-677).  Views
+        (`ray.ra`, `ray.obliq`) and `c_rays()` pointers taken BEFORE the trace keep showing the untraced bundle."""
+        self.soa, self._ob = traced.soa, traced._ob
+        self._mark_traced()
+
+    def _mark_traced(self):
+        if self._ob is None:
+            self._ob_lost = True
 
     def _n_points(self):
         """Order of the rays in `soa` (include/sdirt_dp.h, sdirt_rays): a 2-D bundle [spp, N] -- the shape of every
@@ -179,8 +210,9 @@ class Ray:
         return self.shape[1] if len(self.shape) == 2 else 1
 
     def _field(self, row):
-        """Row `row` of the SoA buffer as a tensor of the reference's shape (a view: writes go through)."""
-        flat = self.soa[row, :self.numel]
+        """Row `row` of the SoA buffer (7: the obliquity array) as a tensor of the reference's shape (a view: writes
+        go through)."""
+        flat = (self.soa[row] if row < 7 else self._obliq_storage())[:self.numel]
         if len(self.shape) == 2:
             return flat.view(self.shape[1], self.shape[0]).t()
         return flat.view(self.shape)
@@ -189,8 +221,21 @@ class Ray:
         self._field(row).copy_(v.to(self.device, torch.float32).expand(self.shape))
 
     def c_rays(self):
+        """The bundle as the C ABI takes it (include/sdirt_dp.h: sdirt_rays); obliq = NULL unless the array exists."""
         base, stride = self.soa.data_ptr(), self.soa.stride(0) * 4
-        return _lib.Rays(*[C.c_void_p(base + i * stride) for i in range(8)])
+        return _lib.Rays(*([C.c_void_p(base + i * stride) for i in range(7)] + [dptr(self._ob)]))
+
+    def _obliq_storage(self):
+        """The obliquity array, created on first use: all ones for a bundle that has not been traced yet (what the
+        reference's constructor sets, basics.py:240); a bundle that HAS been traced without it cannot make it up."""
+        if self._ob is None:
+            if self._ob_lost:
+                raise _lib.SdirtError(
+                    "ray.obliq: this bundle was traced without its obliquity factor (nothing on the PSF path reads it, so "
+                    "it is only carried on request): read or set ray.obliq BEFORE tracing, construct the Ray with "
+                    "obliq=..., or set sdirt_amd.basics.TRACK_OBLIQ = True to carry it always, as the reference does")
+            self._ob = torch.ones(max(self.numel, 1), dtype=torch.float32, device=self.device)
+        return self._ob
 
     # -- reference-shaped views -----------------------------------------------
     def _aos(self, which):
@@ -235,6 +280,9 @@ class Ray:
 
     @obliq.setter
     def obliq(self, v):
+        if self._ob is None:
+            self._ob_lost = False
+            self._ob = torch.empty(max(self.numel, 1), dtype=torch.float32, device=self.device)
         self._set_field(7, v)
 
     @property
@@ -265,11 +313,14 @@ class Ray:
     def clone(self, device=None):
         c = Ray.empty(self.shape, self.wvln, self.device if device is None else device)
         c.soa.copy_(self.soa)
+        c._ob = None if self._ob is None else self._ob.to(c.device, copy=True)
+        c._ob_lost = self._ob_lost
         return c
 
     def to(self, device):
         device = torch.device(device)
         if device != self.device:
             self.soa = self.soa.to(device)
+            self._ob = None if self._ob is None else self._ob.to(device)
             self.device = device
         return self

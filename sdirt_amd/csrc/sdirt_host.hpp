@@ -57,6 +57,20 @@ inline int device_cus(int* out)
     *out = n;
     return SDIRT_OK;
 }
+// Opt a kernel in to more dynamic LDS than the default 48 KiB allowance (up to the CU's 160 KiB): once per kernel
+// instantiation and device, not once per launch.
+template <auto Kernel>
+inline int allow_large_lds(int bytes = 160 * 1024 - 1024)
+{
+    static bool done[kMaxDevices] = {};
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev >= 0 && dev < kMaxDevices && done[dev]) return SDIRT_OK;
+    HIP_TRY(hipFuncSetAttribute((const void*)Kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    if (dev >= 0 && dev < kMaxDevices) done[dev] = true;
+    return SDIRT_OK;
+}
+
 // for the pure sizing helpers that may be asked before any device exists (sdirt_psf_spp_slices): MI355X's 256
 inline int device_cus_or_default()
 {

@@ -403,7 +403,7 @@ int sdirt_psfnet_mlp(const void* packed, const int32_t* widths, int32_t n_layers
 #define SDIRT_MLP_BD 2
 #endif
     auto kern = k_psfnet_mlp<SDIRT_MLP_AD, SDIRT_MLP_BD>;   // 6 weight fragments, 2 sets of X fragments in flight
-    HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (int rc_ = allow_large_lds<&k_psfnet_mlp<SDIRT_MLP_AD, SDIRT_MLP_BD>>((int)lds)) return rc_;
     int dev = 0, cus = 256;
     HIP_TRY(hipGetDevice(&dev));
     HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));

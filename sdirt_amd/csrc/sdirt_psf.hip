@@ -243,12 +243,13 @@ k_forward_integral_tiles(sdirt_rays R, int64_t S, int64_t N, SplatGeom gm, DevDp
 // optics.py:983-987: one workgroup per point.  LDS_TILE: the tile is read from HBM once, into LDS (grids up to
 // ks 110: 48 KB), its maximum taken there and the quotients written back -- one read and one write per pixel; larger grids
 // are read twice (the second pass mostly out of L2).
+// `stride`: floats between the grids of consecutive points (tile, or 2 * tile for one half of an interleaved [N, 2, ks, ks] array).
 template <bool LDS_TILE>
-__global__ void __launch_bounds__(kBlock) k_psf_normalize(float* __restrict__ psf, int tile)
+__global__ void __launch_bounds__(kBlock) k_psf_normalize(float* __restrict__ psf, int tile, int64_t stride)
 {
     extern __shared__ __attribute__((aligned(16))) float nz_tile[];
     __shared__ float red[kBlock / 64];
-    float* g = psf + (int64_t)blockIdx.x * tile;
+    float* g = psf + (int64_t)blockIdx.x * stride;
     float mx = -INFINITY;
     for (int i = threadIdx.x; i < tile; i += blockDim.x) {
         const float v = g[i];
@@ -435,11 +436,11 @@ struct FinishArgs {
     TripTable tp, tc;          // the tables round 1 ran
 };
 __global__ void __launch_bounds__(kBlock) k_psf_finish(float* __restrict__ l, float* __restrict__ r, int tile,
-                                                       int normalize, FinishArgs fa)
+                                                       int64_t pstride, int normalize, FinishArgs fa)
 {
     __shared__ float red[kBlock / 64];
     if (fa.gate && fa.gate[kCtlStatus] == 0u) return;
-    float* g = (blockIdx.y == 0 ? l : r) + (int64_t)blockIdx.x * tile;
+    float* g = (blockIdx.y == 0 ? l : r) + (int64_t)blockIdx.x * pstride;
     if (normalize) {
         float mx = -INFINITY;
         for (int i = threadIdx.x; i < tile; i += blockDim.x) mx = fmaxf(mx, g[i]);
@@ -487,25 +488,30 @@ struct LensSet {
 struct TripSet {
     TripTable t[SDIRT_MAX_WAVELENGTHS];
 };
-template <bool HAVE_R, bool BIG, class HotMath, bool CENTER>
+// ACC = the accumulator type of the LDS tiles.  float: ds_add_f32, which gfx950 executes lane by lane (~193 cycles
+// of the CU's LDS per wave instruction whatever the addresses, profiles/r04/lds_atomic_bench.txt); double:
+// ds_add_f64 (17-33 cycles), the sum rounded to fp32 once on the way out like k_forward_integral_tiles -- chosen by
+// launch_psf whenever the double tiles still leave room for four workgroups per CU (L + R: ks <= 49).
+template <bool HAVE_R, bool BIG, class HotMath, bool CENTER, class ACC>
 __global__ void __launch_bounds__(kFused, BIG ? 4 : 8)
 k_psf_lr(SplatBlock sb /* kernarg offset 0 */, TripSet trips /* 64 */, TripSet trips_c /* 64 + 64 W */,
          LensSet lens_set, int K, const float* __restrict__ po, const float* __restrict__ x2,
-         const float* __restrict__ y2, int S, int nsplit, int chunk, float pz, float zs, int ks, float tr,
+         const float* __restrict__ y2, int S, int nsplit, int chunk, float pz, float zs, int ks, int pstride, float tr,
          float tl, const float* __restrict__ center, uint32_t flags, float* __restrict__ lout,
          float* __restrict__ rout, uint32_t* __restrict__ conv_mask, CenterArgs ca, SplitArgs sa)
 {
-    extern __shared__ __attribute__((aligned(16))) float tiles[];   // [L | R] ks*ks each
+    extern __shared__ __attribute__((aligned(16))) unsigned char tiles_raw[];
+    ACC* __restrict__ tiles = reinterpret_cast<ACC*>(tiles_raw);    // [L | R] ks*ks each
     if (!CENTER && sa.gate && sa.gate[kCtlStatus] == 0u) return;    // round 2 of a verified call, nothing to redo
     __shared__ uint32_t lds_mask[SDIRT_MAX_SURFACES];
     __shared__ float red[kFused / 64];
     __shared__ float c_sh[2];
     const int tile = ks * ks;
-    float* tl_ = tiles;
-    float* trr = tiles + tile;
+    ACC* tl_ = tiles;
+    ACC* trr = tiles + tile;
     const int n = blockIdx.x / nsplit;
     const int j = blockIdx.x - n * nsplit;
-    const int w = blockIdx.y, W = gridDim.y;
+    const int w = blockIdx.y;
     const int N = gridDim.x / nsplit;
     const DevSurface* __restrict__ lens = lens_set.p[w];
     constexpr int kTripsAt = 64, kTripsCAt = 64 + 64 * SDIRT_MAX_WAVELENGTHS;
@@ -524,7 +530,7 @@ k_psf_lr(SplatBlock sb /* kernarg offset 0 */, TripSet trips /* 64 */, TripSet t
     if (CENTER) {
         // ---- chief-ray centre of this point (same arithmetic and reduction order as
         // k_chief_center; the fp64 scratch aliases the not-yet-used tile memory)
-        double* redd = reinterpret_cast<double*>(tiles);             // [3][kFused]
+        double* redd = reinterpret_cast<double*>(tiles_raw);         // [3][kFused]
         if (threadIdx.x < SDIRT_MAX_SURFACES) lds_mask[threadIdx.x] = 0;
         if (threadIdx.x == 0) c_sh[0] = 0.0f;
         __syncthreads();
@@ -578,7 +584,7 @@ k_psf_lr(SplatBlock sb /* kernarg offset 0 */, TripSet trips /* 64 */, TripSet t
         c_sh[1] = -((float)sy / den);
         if (j == 0) { ca.center_out[2 * n] = c_sh[0]; ca.center_out[2 * n + 1] = c_sh[1]; }
     }
-    for (int i = threadIdx.x; i < (HAVE_R ? 2 : 1) * tile; i += blockDim.x) tiles[i] = 0.0f;
+    for (int i = threadIdx.x; i < (HAVE_R ? 2 : 1) * tile; i += blockDim.x) tiles[i] = (ACC)0;
     if (threadIdx.x < SDIRT_MAX_SURFACES) lds_mask[threadIdx.x] = 0;
     __syncthreads();
 
@@ -604,15 +610,15 @@ k_psf_lr(SplatBlock sb /* kernarg offset 0 */, TripSet trips /* 64 */, TripSet t
         float sl, sr;
         if (BIG) dp_weights_big(dp, x_tan, sl, sr);      // separate instantiation: the rarely
         else dp_weights_small<HotMath>(dp, UDiv<HotMath>::make(dp.fmh), x_tan, sl, sr);   // used r > 0.5 branch costs registers
-        atomicAdd(&tl_[tp.i_tl], tp.w_tl * sl);
-        atomicAdd(&tl_[tp.i_tr], tp.w_tr * sl);
-        atomicAdd(&tl_[tp.i_bl], tp.w_bl * sl);
-        atomicAdd(&tl_[tp.i_br], tp.w_br * sl);
+        atomicAdd(&tl_[tp.i_tl], (ACC)(tp.w_tl * sl));
+        atomicAdd(&tl_[tp.i_tr], (ACC)(tp.w_tr * sl));
+        atomicAdd(&tl_[tp.i_bl], (ACC)(tp.w_bl * sl));
+        atomicAdd(&tl_[tp.i_br], (ACC)(tp.w_br * sl));
         if (HAVE_R) {
-            atomicAdd(&trr[tp.i_tl], tp.w_tl * sr);
-            atomicAdd(&trr[tp.i_tr], tp.w_tr * sr);
-            atomicAdd(&trr[tp.i_bl], tp.w_bl * sr);
-            atomicAdd(&trr[tp.i_br], tp.w_br * sr);
+            atomicAdd(&trr[tp.i_tl], (ACC)(tp.w_tl * sr));
+            atomicAdd(&trr[tp.i_tr], (ACC)(tp.w_tr * sr));
+            atomicAdd(&trr[tp.i_bl], (ACC)(tp.w_bl * sr));
+            atomicAdd(&trr[tp.i_br], (ACC)(tp.w_br * sr));
         }
     };
     for (int s = j * chunk + threadIdx.x; s < s_end; s += blockDim.x) {
@@ -623,35 +629,38 @@ k_psf_lr(SplatBlock sb /* kernarg offset 0 */, TripSet trips /* 64 */, TripSet t
     }
     __syncthreads();
 
-    float* Lg = lout + ((int64_t)n * W + w) * tile;
-    float* Rg = HAVE_R ? rout + ((int64_t)n * W + w) * tile : nullptr;
+    // pstride: floats from one point's grid(s) to the next -- W * tile, or 2 * tile for SDIRT_PSF_INTERLEAVED
+    float* Lg = lout + (int64_t)n * pstride + w * tile;
+    float* Rg = HAVE_R ? rout + (int64_t)n * pstride + w * tile : nullptr;
+    // (double tiles: every sum is rounded to fp32 ONCE here; the maximum and the quotients are taken of the rounded
+    // values, i.e. of exactly what k_psf_normalize would read back)
     if (nsplit == 1) {
         if (flags & SDIRT_PSF_NORMALIZE) {
             float mx = -INFINITY;
-            for (int i = threadIdx.x; i < tile; i += blockDim.x) mx = fmaxf(mx, tl_[i]);
+            for (int i = threadIdx.x; i < tile; i += blockDim.x) mx = fmaxf(mx, (float)tl_[i]);
             const auto div_l = UDiv<HotMath>::make(block_max(mx, red) + 1e-6f);
             auto div_r = div_l;
             if (HAVE_R) {
                 mx = -INFINITY;
-                for (int i = threadIdx.x; i < tile; i += blockDim.x) mx = fmaxf(mx, trr[i]);
+                for (int i = threadIdx.x; i < tile; i += blockDim.x) mx = fmaxf(mx, (float)trr[i]);
                 div_r = UDiv<HotMath>::make(block_max(mx, red) + 1e-6f);
             }
             for (int i = threadIdx.x; i < tile; i += blockDim.x) {
-                Lg[i] = div_l(tl_[i]);
-                if (HAVE_R) Rg[i] = div_r(trr[i]);
+                Lg[i] = div_l((float)tl_[i]);
+                if (HAVE_R) Rg[i] = div_r((float)trr[i]);
             }
         } else {
             for (int i = threadIdx.x; i < tile; i += blockDim.x) {
-                Lg[i] = tl_[i];
-                if (HAVE_R) Rg[i] = trr[i];
+                Lg[i] = (float)tl_[i];
+                if (HAVE_R) Rg[i] = (float)trr[i];
             }
         }
     } else {
         for (int i = threadIdx.x; i < tile; i += blockDim.x) {
-            const float a = tl_[i];
+            const float a = (float)tl_[i];
             if (a != 0.0f) atomicAdd(&Lg[i], a);
             if (HAVE_R) {
-                const float b = trr[i];
+                const float b = (float)trr[i];
                 if (b != 0.0f) atomicAdd(&Rg[i], b);
             }
         }
@@ -660,13 +669,14 @@ k_psf_lr(SplatBlock sb /* kernarg offset 0 */, TripSet trips /* 64 */, TripSet t
         atomicOr(&conv_mask[threadIdx.x], lds_mask[threadIdx.x]);
 }
 
-static void launch_normalize(float* psf, int64_t N, int tile, hipStream_t st)
+static void launch_normalize(float* psf, int64_t N, int tile, hipStream_t st, int64_t stride = 0)
 {
     const size_t lds = sizeof(float) * (size_t)tile;
+    if (stride == 0) stride = tile;
     if (lds <= 48 * 1024 - 64)            // ks <= 110: inside the default dynamic-LDS allowance, two to ten workgroups per CU
-        k_psf_normalize<true><<<(unsigned)N, kBlock, lds, st>>>(psf, tile);
+        k_psf_normalize<true><<<(unsigned)N, kBlock, lds, st>>>(psf, tile, stride);
     else
-        k_psf_normalize<false><<<(unsigned)N, kBlock, 0, st>>>(psf, tile);
+        k_psf_normalize<false><<<(unsigned)N, kBlock, 0, st>>>(psf, tile, stride);
 }
 
 // ---------------------------------------------------------------------------
@@ -759,8 +769,7 @@ int sdirt_forward_integral(sdirt_rays rays, int64_t S, int64_t N, double ps, int
 #define SDIRT_LAUNCH_FI_M(HR, BG, AC, MM)                                                         \
     do {                                                                                          \
         if (lds_bytes > 48 * 1024)                                                                \
-            HIP_TRY(hipFuncSetAttribute((const void*)k_forward_integral_tiles<HR, BG, AC, MM>,    \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024)); \
+            if (int rc_ = allow_large_lds<&k_forward_integral_tiles<HR, BG, AC, MM>>()) return rc_; \
         k_forward_integral_tiles<HR, BG, AC, MM><<<grid, kFiThreads, lds_bytes, st>>>(            \
             rays, S, N, make_geom(ps, ks), dpp, fl, center, l_grid, both ? r_grid : nullptr,      \
             (flags & SDIRT_PSF_NORMALIZE) ? 1 : 0);                                               \
@@ -836,12 +845,14 @@ struct CenterRequest {
     uint32_t* conv_mask_c;        // [W][SDIRT_MAX_SURFACES]
 };
 
-static int spp_split(int64_t N, int64_t S, int* chunk_out)
+constexpr size_t kWideTilesMax = 39 * 1024;
+
+static int spp_split(int64_t N, int64_t S, int* chunk_out, int n_cus = 0)
 {
     // Fill the chip: at least ~4 workgroups per CU; split the spp axis when the
     // number of points alone cannot (e.g. PSFNet training: N=64, S=20000).
     int nsplit = 1;
-    const int64_t want_blocks = (int64_t)device_cus_or_default() * 4;
+    const int64_t want_blocks = (int64_t)(n_cus > 0 ? n_cus : device_cus_or_default()) * 4;
     if (N < want_blocks && S > 2 * kFused) {
         nsplit = (int)((want_blocks + N - 1) / N);
         const int max_split = (int)((S + 2 * kFused - 1) / (2 * kFused));
@@ -888,7 +899,13 @@ static int launch_psf(const sdirt_lens* const* lens, int W, const float* point_o
 {
     const bool have_r = r_psf != nullptr;
     const int tile = ks * ks;
-    const size_t lds = sizeof(float) * tile * (have_r ? 2 : 1);
+    // SDIRT_PSF_INTERLEAVED: l_psf / r_psf are the two halves of ONE [N, 2, ks, ks] array
+    const bool interleaved = (flags & SDIRT_PSF_INTERLEAVED) != 0;
+    if (interleaved && (W != 1 || !dp || !r_psf || r_psf != l_psf + tile))
+        return fail(SDIRT_ERR_INVALID_ARGUMENT, "SDIRT_PSF_INTERLEAVED: one wavelength, dp != NULL and r_psf == l_psf + ks * ks "
+                                                "(the two halves of one [N, 2, ks, ks] array)");
+    const int64_t pstride = interleaved ? 2 * (int64_t)tile : (int64_t)W * tile;
+    if ((int64_t)W * tile > (1ll << 30)) return fail(SDIRT_ERR_INVALID_ARGUMENT, "grids too large");
     // a multi-wavelength launch keeps one workgroup per (point, wavelength): the chief-ray pass
     // stays fused and the whole of psf_rgb is one kernel, also for the few points of a psf_map
     int chunk = ((int)S + kFused - 1) / kFused * kFused;
@@ -914,15 +931,19 @@ static int launch_psf(const sdirt_lens* const* lens, int W, const float* point_o
         center = cen->center_out;
     }
     if (nsplit > 1 && !vr) {
-        HIP_TRY(hipMemsetAsync(l_psf, 0, sizeof(float) * (size_t)N * tile, st));
-        if (have_r) HIP_TRY(hipMemsetAsync(r_psf, 0, sizeof(float) * (size_t)N * tile, st));
+        HIP_TRY(hipMemsetAsync(l_psf, 0, sizeof(float) * (size_t)N * tile * (interleaved ? 2 : 1), st));
+        if (have_r && !interleaved) HIP_TRY(hipMemsetAsync(r_psf, 0, sizeof(float) * (size_t)N * tile, st));
     }
     const SplatGeom gm = make_geom(ps, ks);
     const DevDpParams dpp = make_dp(dp);
     const SplatBlock sblk = make_splat_block(gm, dpp);
     const dim3 grid((unsigned)(N * nsplit), (unsigned)W);
     const bool both = have_r && dpp.have_r;
-    size_t lds_bytes = both ? lds : sizeof(float) * tile;
+    // double accumulators (ACC of k_psf_lr) whenever they leave room for four workgroups per CU, i.e. for the
+    // kernel's 8 waves per SIMD: 4 x (39 KiB + 0.4 KiB of static LDS) <= 160 KiB -- L + R up to ks 49, L alone up to 70
+    const size_t n_acc = (size_t)tile * (both ? 2 : 1);
+    const bool wide = !dpp.big && sizeof(double) * n_acc <= kWideTilesMax;
+    size_t lds_bytes = (wide ? sizeof(double) : sizeof(float)) * n_acc;
     CenterArgs ca;
     TripSet ttc;
     LensSet ls;
@@ -952,44 +973,49 @@ static int launch_psf(const sdirt_lens* const* lens, int W, const float* point_o
         sa.nslice = nslice_c;
         sa.trips_dev = round ? ctl + kCtlTrips2C : nullptr;
         uint32_t* mask_c = ctl + (round ? kCtlMask2C : kCtlMask1C);
-        float* zr = both ? r_psf : nullptr;
+        float* zr = (both && !interleaved) ? r_psf : nullptr;      // interleaved: one run of N * 2 * tile floats
+        const int64_t zn = (int64_t)N * tile * (interleaved ? 2 : 1);
         if (lean)
             k_chief_slices<Lean><<<(int)(N * nslice_c), kFused, 0, st>>>(
                 cen->trips_c.t[0], sa, cen->lens_c->dev, K, point_obj, cen->xc, cen->yc, (int)cen->Sc, chunk_c,
-                (float)pupil_z, (float)d_sensor, vr->part, ctl + kCtlAnyValid, mask_c, l_psf, zr, (int64_t)N * tile);
+                (float)pupil_z, (float)d_sensor, vr->part, ctl + kCtlAnyValid, mask_c, l_psf, zr, zn);
         else
             k_chief_slices<Ieee><<<(int)(N * nslice_c), kFused, 0, st>>>(
                 cen->trips_c.t[0], sa, cen->lens_c->dev, K, point_obj, cen->xc, cen->yc, (int)cen->Sc, chunk_c,
-                (float)pupil_z, (float)d_sensor, vr->part, ctl + kCtlAnyValid, mask_c, l_psf, zr, (int64_t)N * tile);
+                (float)pupil_z, (float)d_sensor, vr->part, ctl + kCtlAnyValid, mask_c, l_psf, zr, zn);
         LAUNCH_CHECK();
         sa.trips_dev = round ? ctl + kCtlTrips2P : nullptr;
         conv_mask = ctl + (round ? kCtlMask2P : kCtlMask1P);
         ca.center_out = cen->center_out;
         center = nullptr;
     }
-#define SDIRT_LAUNCH_PSF(HR, BG, MM, CT)                                                          \
+#define SDIRT_LAUNCH_PSF(HR, BG, MM, CT, AC)                                                      \
     do {                                                                                          \
         if (lds_bytes > 48 * 1024) /* large tiles: opt in to the full 160 KiB of LDS */           \
-            HIP_TRY(hipFuncSetAttribute((const void*)k_psf_lr<HR, BG, MM, CT>,                    \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize,               \
-                                        160 * 1024 - 1024));                                      \
-        k_psf_lr<HR, BG, MM, CT><<<grid, kFused, lds_bytes, st>>>(                                \
+            if (int rc_ = allow_large_lds<&k_psf_lr<HR, BG, MM, CT, AC>>()) return rc_;           \
+        k_psf_lr<HR, BG, MM, CT, AC><<<grid, kFused, lds_bytes, st>>>(                            \
             sblk, tt, ttc, ls, K, point_obj, x2, y2, (int)S, nsplit, chunk, (float)pupil_z,       \
-            (float)d_sensor, ks, dpp.tr, dpp.tl, center, flags, l_psf, both ? r_psf : nullptr,    \
+            (float)d_sensor, ks, (int)pstride, dpp.tr, dpp.tl, center, flags, l_psf,              \
+            both ? r_psf : nullptr,                                                               \
             conv_mask, ca, sa);                                                                   \
     } while (0)
-#define SDIRT_LAUNCH_PSF_C(HR, BG, MM)                                                            \
+#define SDIRT_LAUNCH_PSF_C(HR, BG, MM, AC)                                                        \
     do {                                                                                          \
-        if (fuse_center) SDIRT_LAUNCH_PSF(HR, BG, MM, true); else SDIRT_LAUNCH_PSF(HR, BG, MM, false); \
+        if (fuse_center) SDIRT_LAUNCH_PSF(HR, BG, MM, true, AC); else SDIRT_LAUNCH_PSF(HR, BG, MM, false, AC); \
     } while (0)
-#define SDIRT_LAUNCH_PSF_M(HR, BG)                                                                \
+#define SDIRT_LAUNCH_PSF_M(HR, BG, AC)                                                            \
     do {                                                                                          \
-        if (lean) SDIRT_LAUNCH_PSF_C(HR, BG, Lean); else SDIRT_LAUNCH_PSF_C(HR, BG, Ieee);        \
+        if (lean) SDIRT_LAUNCH_PSF_C(HR, BG, Lean, AC); else SDIRT_LAUNCH_PSF_C(HR, BG, Ieee, AC); \
     } while (0)
+    // the corner-clipped microlens branch runs at 4 waves per SIMD whatever the tiles: float tiles only
     if (both) {
-        if (dpp.big) SDIRT_LAUNCH_PSF_M(true, true); else SDIRT_LAUNCH_PSF_M(true, false);
+        if (dpp.big) SDIRT_LAUNCH_PSF_M(true, true, float);
+        else if (wide) SDIRT_LAUNCH_PSF_M(true, false, double);
+        else SDIRT_LAUNCH_PSF_M(true, false, float);
     } else {
-        if (dpp.big) SDIRT_LAUNCH_PSF_M(false, true); else SDIRT_LAUNCH_PSF_M(false, false);
+        if (dpp.big) SDIRT_LAUNCH_PSF_M(false, true, float);
+        else if (wide) SDIRT_LAUNCH_PSF_M(false, false, double);
+        else SDIRT_LAUNCH_PSF_M(false, false, float);
     }
     LAUNCH_CHECK();
     if (vr) {
@@ -999,7 +1025,7 @@ static int launch_psf(const sdirt_lens* const* lens, int W, const float* point_o
         fa.ctl = round ? nullptr : vr->ctl;
         fa.lens = lens[0]->dev; fa.K = K; fa.tp = tt.t[0]; fa.tc = cen->trips_c.t[0];
         k_psf_finish<<<dim3((unsigned)N, both ? 2u : 1u), kBlock, 0, st>>>(
-            l_psf, r_psf, tile, (flags & SDIRT_PSF_NORMALIZE) ? 1 : 0, fa);
+            l_psf, r_psf, tile, pstride, (flags & SDIRT_PSF_NORMALIZE) ? 1 : 0, fa);
         LAUNCH_CHECK();
     }
     }   // rounds
@@ -1009,8 +1035,8 @@ static int launch_psf(const sdirt_lens* const* lens, int W, const float* point_o
     // param_list=None leaves the R grid all-zero (monte_carlo.py:230-235)
     if (!both && have_r) HIP_TRY(hipMemsetAsync(r_psf, 0, sizeof(float) * (size_t)N * W * tile, st));
     if (!vr && nsplit > 1 && (flags & SDIRT_PSF_NORMALIZE)) {
-        launch_normalize(l_psf, N, tile, st);
-        if (have_r && dpp.have_r) launch_normalize(r_psf, N, tile, st);
+        launch_normalize(l_psf, N, tile, st, pstride);
+        if (have_r && dpp.have_r) launch_normalize(r_psf, N, tile, st, pstride);
         LAUNCH_CHECK();
     }
     return SDIRT_OK;
@@ -1105,10 +1131,10 @@ int sdirt_psf_rgb_centered(const sdirt_lens* const* lens, int32_t W, const sdirt
                       flags, l_psf, r_psf, conv_mask, stream);
 }
 
-int32_t sdirt_psf_spp_slices(int64_t N, int64_t S)
+int32_t sdirt_psf_spp_slices(int64_t N, int64_t S, int32_t n_cus)
 {
     if (N < 1 || S < 1) return 1;
-    return spp_split(N, S, nullptr);
+    return spp_split(N, S, nullptr, n_cus);
 }
 
 static size_t ctl_bytes() { return (sizeof(uint32_t) * SDIRT_CTL_WORDS + 63) / 64 * 64; }

@@ -663,8 +663,7 @@ int sdirt_local_psf_render(const float* img, const float* psf, int32_t B, int32_
 #define SDIRT_RENDER_T(CC, HF, PP)                                                               \
     do {                                                                                         \
         if (lds_tile > 48 * 1024)                                                                \
-            HIP_TRY(hipFuncSetAttribute((const void*)k_local_psf_render_rows<CC, HF, PP, 0>,     \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)); \
+            if (int rc_ = allow_large_lds<&k_local_psf_render_rows<CC, HF, PP, 0>>(64 * 1024)) return rc_; \
         k_local_psf_render_rows<CC, HF, PP, 0><<<grid_t, kBlock, lds_tile, st>>>(                \
             img, psf, H, W, ks, out_l, out_r);                                                   \
     } while (0)
@@ -718,8 +717,7 @@ int sdirt_psfnet_render(const float* img, const void* raw_l, const void* raw_r, 
         const size_t lds = per_pixel * PP;                                                       \
         const int grid = (int)std::min<int64_t>((P + PP - 1) / PP, 256 * 64);                    \
         if (lds > 48 * 1024)                                                                     \
-            HIP_TRY(hipFuncSetAttribute((const void*)k_psfnet_render<CC, PP, KK>,                \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)); \
+            if (int rc_ = allow_large_lds<&k_psfnet_render<CC, PP, KK>>(64 * 1024)) return rc_;  \
         k_psfnet_render<CC, PP, KK><<<grid, kBlock, lds, st>>>(img, rl, rr, B, H, W, ks, out_l,  \
                                                                out_r);                           \
     } while (0)

@@ -10,9 +10,13 @@ reference call over the whole grid is
   * the batch-global Newton trip counts (surfaces.py:547): the per-surface
     convergence masks are OR-reduced over the ranks before the trip table is
     verified (newton.py), so every rank takes the same decision;
-  * optionally the result: one all-gather of the [N/world, 2, ks, ks] shards
+  * optionally the result: ONE all-gather of the [N/world, 2, ks, ks] shards
     (`torch.distributed` backend "nccl" is RCCL on ROCm; xGMI is point-to-point,
-    a gather of a few hundred MB per rank keeps all 7 links of a GPU busy).
+    a gather of a few hundred MB per rank keeps all 7 links of a GPU busy).  A
+    rank renders its shard straight into that block (SDIRT_PSF_INTERLEAVED: the
+    kernel writes point n's left grid at [n, 0] and its right grid at [n, 1]),
+    and L = volume[:, 0], R = volume[:, 1] are views of the gathered array: no
+    staging copy on either side of the collective.
 
 Nothing here touches the data path on a single GPU.
 """
@@ -69,10 +73,11 @@ def broadcast_pupil_points(lens, spp, n_center=GEO_SPP, group=None, src=0):
             buf[2 * spp + n_center:])
 
 
-def all_gather_shards(local, n_total, world, group=None, out=None, algo=None):
+def all_gather_shards(local, n_total, world, group=None, out=None, algo=None, padded=False):
     """local: [n_local, ...] shard of a contiguous partition (shard_bounds) ->
     [n_total, ...] on every rank.  Shards are padded to the largest one so a
-    single all_gather_into_tensor moves everything.
+    single all_gather_into_tensor moves everything (padded=True: `local` already
+    has the largest shard's width, its own rows first -- ShardedPSF.shard_buffer).
 
     algo (or env SDIRT_GATHER_ALGO): 'allgather' (default) = one RCCL all-gather;
     'direct' = every rank posts one send and one receive per peer in a single
@@ -84,6 +89,8 @@ def all_gather_shards(local, n_total, world, group=None, out=None, algo=None):
     bounds = shard_bounds(n_total, world)
     width = max(b - a for a, b in bounds)
     tail = tuple(local.shape[1:])
+    if padded and local.shape[0] != width:
+        raise ValueError(f"padded shard has {local.shape[0]} rows, the largest shard of the partition {width}")
     if local.shape[0] != width:
         pad = torch.zeros((width,) + tail, dtype=local.dtype, device=local.device)
         pad[:local.shape[0]] = local
@@ -119,12 +126,14 @@ class ShardedPSF:
 
     render(points_local, u) -> (L, R) is normally Lensgroup-backed
     (`from_lens`); tests substitute a CPU stand-in to exercise the partition /
-    broadcast / gather logic under gloo.
+    broadcast / gather logic under gloo.  ks given: render(points_local, u, out=block)
+    fills a [n_local, 2, ks, ks] block in place (what the Lensgroup-backed one does) and
+    the gathered volume is assembled from those blocks by one collective.
     """
 
-    def __init__(self, render, device, group=None):
+    def __init__(self, render, device, group=None, ks=None):
         self.render, self.device, self.group = render, torch.device(device), group
-        self.lens = None
+        self.lens, self.ks = None, ks
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
 
@@ -135,11 +144,32 @@ class ShardedPSF:
         def render(points_local, pupil, out=None, defer=False):
             # defer=True: every rank enqueues the same kernels and collectives in the same order
             # and takes the same re-launch decision later (the masks are reduced over ranks)
+            # out: (L, R) [n, ks, ks] each, or ONE [n, 2, ks, ks] block (the form the gather moves)
             return lens.psf_lr(points_local, ks=ks, wvln=wvln, dp=dp, pupil_xy=(pupil[0], pupil[1]),
                                center_pupil_xy=(pupil[2], pupil[3]), out=out, defer=defer)
-        self = cls(render, lens.device, group)
+        self = cls(render, lens.device, group, ks=ks)
         self.lens = lens
         return self
+
+    def shard_buffer(self, n_total):
+        """The [width, 2, ks, ks] block this rank renders into and the gather sends: `width` = the largest shard of
+        the partition (so that one all_gather_into_tensor moves everything), this rank's points in its first rows
+        (rows beyond them -- uneven partitions only -- are zero)."""
+        bounds = shard_bounds(n_total, self.world)
+        width = max(b - a for a, b in bounds)
+        n_local = bounds[self.rank][1] - bounds[self.rank][0]
+        block = torch.empty((width, 2, self.ks, self.ks), dtype=torch.float32, device=self.device)
+        if n_local < width:
+            block[n_local:].zero_()
+        return block
+
+    def gather(self, block, n_total, out=None, group=None):
+        """ONE collective: every rank's [width, 2, ks, ks] block (`shard_buffer`, filled by `render(..., out=block[:n])`)
+        -> the [n_total, 2, ks, ks] volume on every rank; L = volume[:, 0], R = volume[:, 1] are views of it.
+        group: the communicator the gather runs on (bench.py gives it its own, so that it does not hold back the next
+        step's small broadcast on the default group's stream)."""
+        return all_gather_shards(block, n_total, self.world, self.group if group is None else group, out=out,
+                                 padded=True)
 
     def local_slice(self, n_total):
         return shard_bounds(n_total, self.world)[self.rank]
@@ -153,9 +183,14 @@ class ShardedPSF:
             u = broadcast_pupil_points(self.lens, spp, group=self.group)
         else:
             u = broadcast_uniforms(spp, self.device, group=self.group)
-        L, R = self.render(points[a:b], u)
-        if not gather or self.world == 1:
-            return L, R
-        both = torch.stack((L, R), dim=1)                   # [n_local, 2, ks, ks]
-        full = all_gather_shards(both, n_total, self.world, self.group)
+        if self.ks is None or not gather or self.world == 1:
+            L, R = self.render(points[a:b], u)
+            if not gather or self.world == 1:
+                return L, R
+            block = torch.stack((L, R), dim=1)              # (a CPU stand-in renders two tensors)
+        else:
+            # the kernel writes the shard straight into the block the collective sends: no torch.stack
+            block = self.shard_buffer(n_total)
+            self.render(points[a:b], u, out=block[:b - a])
+        full = all_gather_shards(block, n_total, self.world, self.group)
         return full[:, 0], full[:, 1]

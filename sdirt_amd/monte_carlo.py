@@ -81,7 +81,6 @@ def _assign(points, ks, x_range, ra, x_tan, param_list, big, precision="lean"):
     ray.soa[4, :S] = 0.0
     ray.soa[5, :S] = 1.0
     ray.soa[6, :S] = ra.to(torch.float32).reshape(S)
-    ray.soa[7, :S] = 1.0
     center = torch.zeros((1, 2), dtype=torch.float32, device=dev)
     if big and param_list is None:
         param_list = [0.78, 1.44, 0.3, 0.5, "l"]

@@ -190,7 +190,7 @@ class Lensgroup:
     # nn.Module-style switches: the reference's Lensgroup / PSFNet inherit them from DeepObj(nn.Module)
     # (basics.py:165-213) and its scripts call them (dfdp/factory.py:15,31-32: lens.to(device), lens.eval())
     _DEVICE_CACHES = ("_stage_ring", "_sample_stream", "_readback_stream", "_ctl_pools", "_p2o_cache", "_ctl_host",
-                      "_right_streak")
+                      "_right_streak", "_n_cus")
 
     def train(self, mode=True):
         """The PSF network (if this lens carries one) in training / evaluation mode; -> self."""
@@ -508,8 +508,12 @@ class Lensgroup:
 
     # ----------------------------------------------------------------- tracing
     def trace(self, ray, lens_range=None, record=False, forward=None, _to_sensor=None):
-        """optics.py:601-627: in place; returns (ray, valid, oss).  Direction is
+        """optics.py:601-627: updates `ray` and returns (ray, valid, oss).  Direction is
         taken from the first ray's d_z like the reference unless `forward` is given.
+        Under trip_policy 'reference' the trace runs OUT OF PLACE and `ray`'s storage is rebound to the traced
+        bundle (the reference rebinds ray.o / ray.d / ray.ra to new tensors too, surfaces.py:425, 676-677): views
+        (`ray.ra`, `ray.obliq`) and `c_rays()` pointers taken BEFORE the call keep showing the untraced rays --
+        re-fetch them after trace / trace2sensor.  ('max' / 'adaptive' trace in place.)
         _to_sensor = z: trace2sensor's form -- forward through all surfaces and on to the plane z in the same pass
         (sdirt_trace2sensor)."""
         self._require_gpu()
@@ -537,7 +541,7 @@ class Lensgroup:
             # into a second bundle (sdirt_trace_to) which then becomes the ray's storage -- the reference's trace
             # rebinds ray.o / ray.d / ray.ra to new tensors in the same way (surfaces.py:425, 676-677); copying the
             # bundle first to trace in place cost as much memory traffic as the trace itself
-            dst = Ray.empty(ray.shape, ray.wvln, self.device)
+            dst = Ray.empty(ray.shape, ray.wvln, self.device, obliq=ray.has_obliq)
 
             def enqueue_to(trips, mask_ptr):
                 if _to_sensor is not None:
@@ -550,9 +554,10 @@ class Lensgroup:
                                                      mask_ptr, stream_ptr(self.device)))
             key = ("trace", round(float(ray.wvln), 6), first, last, forward, self.precision)
             self._run_with_trips(key, order, enqueue_to)
-            ray.soa = dst.soa
+            ray._adopt(dst)
         else:
             self._run_with_trips(None, order, enqueue)
+            ray._mark_traced()
             if _to_sensor is not None:
                 ray.propagate_to(_to_sensor)
         valid = ray.ra == 1
@@ -578,7 +583,7 @@ class Lensgroup:
         return ray, ray.ra == 1, oss
 
     def trace2sensor(self, ray, record=False, ignore_invalid=False):
-        """optics.py:638-664.  record=True: (p, oss) -- the sensor-plane positions [M,3] and the
+        """optics.py:638-664 (the ray's storage is rebound like trace()'s).  record=True: (p, oss) -- the sensor-plane positions [M,3] and the
         recorded paths, each live ray's sensor point appended (twice, as the reference's two loops do)."""
         if not record:
             if bool(ray.soa[5, 0].item() > 0):                   # forward (optics.py:618): one pass, sdirt_trace2sensor
@@ -739,6 +744,13 @@ class Lensgroup:
             return PendingPSF(lambda: pick(res.wait()))
         return pick(res)
 
+    def _spp_slices(self, N, spp):
+        """sdirt_psf_spp_slices for THIS lens's GPU (its CU count, whatever the caller's current device is)."""
+        ncu = self.__dict__.get("_n_cus")
+        if ncu is None:
+            ncu = self.__dict__["_n_cus"] = int(torch.cuda.get_device_properties(self.device).multi_processor_count)
+        return _lib.lib().sdirt_psf_spp_slices(N, spp, ncu)
+
     def _centre_buffer(self, center_out, N):
         """The [N, 2] centre tensor of a psf call: the caller's (checked) or a fresh one."""
         if center_out is None:
@@ -750,7 +762,15 @@ class Lensgroup:
 
     def _psf_buffers(self, out, N, ks, need_r):
         """(L, R) [N, ks, ks] of a psf call: the caller's `out` pair (checked) or fresh tensors; R is None when
-        the call fills no right grid."""
+        the call fills no right grid.  out = ONE float32 CUDA [N, 2, ks, ks] tensor: L = out[:, 0], R = out[:, 1]
+        (SDIRT_PSF_INTERLEAVED: the block a multi-GPU volume gathers with one collective, dist.py)."""
+        if torch.is_tensor(out):
+            if not (out.is_cuda and out.dtype == torch.float32 and out.is_contiguous()
+                    and tuple(out.shape) == (N, 2, ks, ks)):
+                raise ValueError("out as ONE tensor must be contiguous float32 CUDA [N, 2, ks, ks]")
+            if not need_r:
+                raise ValueError("out=[N, 2, ks, ks] holds a left AND a right grid per point: needs dp and want_r")
+            return out[:, 0], out[:, 1]
         if out is None:
             L = torch.empty((N, ks, ks), dtype=torch.float32, device=self.device)
             return L, (torch.empty_like(L) if need_r else None)
@@ -777,7 +797,9 @@ class Lensgroup:
 
         out: optional (L, R) float32 CUDA tensors [N,ks,ks] to write into -- a consumer
         that renders batch after batch (PSFNet fitting) re-uses its buffers instead of
-        asking the caching allocator for two 277 MB blocks per call.
+        asking the caching allocator for two 277 MB blocks per call.  Or ONE [N,2,ks,ks]
+        tensor: the returned L and R are its views out[:, 0] and out[:, 1] (a rank of a
+        sharded volume renders straight into the block that one all-gather moves).
 
         center_out: optional float32 CUDA [N,2] tensor that receives the PSF centres the splat used
         (the chief-ray centres of optics.py:969 with center=True).
@@ -794,6 +816,8 @@ class Lensgroup:
         if single_point:
             points = points.unsqueeze(0)
         N = points.shape[0]
+        if torch.is_tensor(out) and (dp is None or _default_r_zero or not want_r):
+            raise ValueError("out=[N, 2, ks, ks] holds a left AND a right grid per point: needs dp and want_r")
         if N == 0 and not (self.mask_reduce is not None and center
                            and self.trip_policy == "reference"):
             # empty batch: nothing to trace, no random numbers drawn
@@ -808,13 +832,13 @@ class Lensgroup:
         pupilz, pupilr = self.entrance_pupil()
         if ks > _lib.MAX_KS:
             # a point's two grids no longer fit in LDS (draw_mtf: ks 256): the staged chain
-            if defer:
-                raise ValueError(f"defer=True needs ks <= {_lib.MAX_KS}")
+            if defer or torch.is_tensor(out):
+                raise ValueError(f"defer=True / out=[N, 2, ks, ks] need ks <= {_lib.MAX_KS}")
             return self._psf_lr_staged(points, po, N, ks, wvln, spp, center, dp, normalize, want_r,
                                        _default_r_zero, pupil_xy, center_pupil_xy, out, center_out, single_point)
         if (center and not defer and pupil_xy is None and center_pupil_xy is None and N > 0
                 and self.trip_policy == "reference" and self.mask_reduce is None and self.pupil_mapping == "device"
-                and self.kernel_events is None and _lib.lib().sdirt_psf_spp_slices(N, spp) > 1):
+                and self.kernel_events is None and self._spp_slices(N, spp) > 1):
             # the synchronous call of the fitting shape (few points, many samples): launch-latency-bound,
             # so everything between the random draw and the stream synchronisation is ONE library call
             return self._psf_call_one(points, po, N, ks, wvln, spp, dp, normalize, want_r, _default_r_zero, out,
@@ -853,7 +877,8 @@ class Lensgroup:
         dpp = None if (dp is None or _default_r_zero) else _lib.DpParams(*[float(v) for v in dp])
         dp_ref = C.byref(dpp) if dpp is not None else None
         handle = self.dev_lens(wvln)
-        flags = (_lib.PSF_NORMALIZE if normalize else 0) | self._math_flags()
+        flags = (_lib.PSF_NORMALIZE if normalize else 0) | self._math_flags() \
+            | (_lib.PSF_INTERLEAVED if torch.is_tensor(out) else 0)
         wkey = round(float(wvln if wvln < 10 else wvln * 1e-3), 6)
         K = len(self.surfaces)
         if center:
@@ -865,7 +890,7 @@ class Lensgroup:
             # one control block: [primary masks | chief-ray masks | any-valid flag] -> one readback
             reference = self.trip_policy == "reference"
             verified = (reference and self.mask_reduce is None and N > 0
-                        and _lib.lib().sdirt_psf_spp_slices(N, spp) > 1)
+                        and self._spp_slices(N, spp) > 1)
             ctl = None if verified else self._zeroed_control_block(2 * MS + 1)
 
             def enqueue2(tp, tc):
@@ -1088,7 +1113,8 @@ class Lensgroup:
         dpp = None if (dp is None or default_r_zero) else _lib.DpParams(*[float(v) for v in dp])
         dp_ref = C.byref(dpp) if dpp is not None else None
         handle, handle_c = self.dev_lens(wvln), self.dev_lens(DEFAULT_WAVE)
-        flags = (_lib.PSF_NORMALIZE if normalize else 0) | self._math_flags()
+        flags = (_lib.PSF_NORMALIZE if normalize else 0) | self._math_flags() \
+            | (_lib.PSF_INTERLEAVED if torch.is_tensor(out) else 0)
         wkey = round(float(wvln if wvln < 10 else wvln * 1e-3), 6)
         keys = [("psf", wkey, self.precision), ("center", self.precision)]
         curved = self._curved()

@@ -58,7 +58,8 @@ class Aspheric:
 
     def ray_reaction(self, ray):
         """surfaces.py:391-520: intersect `ray` with THIS surface and refract it; the ray object is updated and also
-        returned, as in the reference.  Newton intersection with the batch-wide trip count of the reference's loop
+        returned, as in the reference (its storage is REBOUND to the traced bundle, like the reference's ray.o / d / ra:
+        views and c_rays() pointers taken before the call keep showing the untraced rays -- re-fetch them).  Newton intersection with the batch-wide trip count of the reference's loop
         (surfaces.py:547, speculated and verified like Lensgroup.trace does it), position / weight update of the rays
         that hit inside the aperture, refraction unless the surface is a plane between equal media.  The direction
         of travel is the reference's test, sum(d_z * ra) > 0 (surfaces.py:399-405: n1/n2 forward, n2/n1 backward).
@@ -84,7 +85,7 @@ class Aspheric:
         forward = bool(float((ray._field(5) * ray.ra).sum()) > 0)
         curved = [self.kind != _lib.KIND_PLANE]
         mask = torch.zeros(_lib.MAX_SURFACES, dtype=torch.int32, device=dev)
-        dst = Ray.empty(ray.shape, ray.wvln, dev)           # out of place: a re-launch with a corrected count re-reads `ray`
+        dst = Ray.empty(ray.shape, ray.wvln, dev, obliq=ray.has_obliq)   # out of place: a re-launch with a corrected count re-reads `ray`
 
         def launch(trips):
             mask.zero_()
@@ -92,7 +93,7 @@ class Aspheric:
                                                  ray.c_rays(), dst.c_rays(), ray.numel, dptr(mask), stream_ptr(dev)))
             return mask[:1].cpu().numpy().astype(np.int64) & 0xFFFFFFFF
         planner.run(("ray_reaction", forward), curved, [0], launch)
-        ray.soa = dst.soa                                   # the reference rebinds ray.o / ray.d / ray.ra as well (:425, :676)
+        ray._adopt(dst)                                     # the reference rebinds ray.o / ray.d / ray.ra as well (:425, :676)
         return ray
 
     def surface(self, x, y):

@@ -32,11 +32,13 @@ def main():
     a, b = sd.shard_bounds(n_total, world)[rank]
     pupil = [torch.from_numpy(v).to("cuda:0") for v in np.load(os.path.join(out_dir, "pupil.npy"), allow_pickle=True)]
     lens = make_lens("rf50mm", "cuda:0")
-    sd.ShardedPSF.from_lens(lens, ks, dp=dp)             # installs the mask reduction over the ranks
+    sharded = sd.ShardedPSF.from_lens(lens, ks, dp=dp)   # installs the mask reduction over the ranks
     cen = torch.empty((b - a, 2), dtype=torch.float32, device="cuda:0")
-    L, R = lens.psf_lr(points[a:b], ks=ks, dp=dp, pupil_xy=(pupil[0], pupil[1]),
-                       center_pupil_xy=(pupil[2], pupil[3]), center_out=cen)
-    full = sd.all_gather_shards(torch.stack((L, R), dim=1), n_total, world)
+    # the shard is rendered straight into the [n_local, 2, ks, ks] block that ONE all-gather moves (SDIRT_PSF_INTERLEAVED)
+    block = sharded.shard_buffer(n_total)
+    lens.psf_lr(points[a:b], ks=ks, dp=dp, pupil_xy=(pupil[0], pupil[1]), center_pupil_xy=(pupil[2], pupil[3]),
+                center_out=cen, out=block[:b - a])
+    full = sharded.gather(block, n_total)
     cen_all = sd.all_gather_shards(cen, n_total, world)
     tables = {"psf": lens.trips.cache[("psf", 0.589, "lean")].tolist(), "center": lens.trips.cache[("center", "lean")].tolist()}
     gathered = [None] * world

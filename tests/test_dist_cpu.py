@@ -44,6 +44,20 @@ def _worker(rank, world, port, n_total, ks, out_dir):
     a, b = sharded.local_slice(n_total)
     L, R = sharded.psf_volume(pts, spp=16, gather=True)
     Ll, Rl = sharded.psf_volume(pts, spp=16, gather=False)
+    # the form the Lensgroup-backed renderer takes: the shard is rendered IN PLACE into the [width, 2, ks, ks] block
+    # that ONE collective sends (no torch.stack), L / R are views of the gathered volume
+    torch.manual_seed(100 + rank)
+
+    def render_into(p, u, out=None):
+        l, r = fake_psf(p, u, ks)
+        out[:, 0], out[:, 1] = l, r
+    blocked = sd.ShardedPSF(render_into, "cpu", ks=ks)
+    Lb, Rb = blocked.psf_volume(pts, spp=16, gather=True)
+    assert torch.equal(Lb, L) and torch.equal(Rb, R)
+    if n_total % world == 0:
+        assert Lb._base is not None and Lb._base is Rb._base and Lb._base.shape == (n_total, 2, ks, ks)   # views
+    with pytest.raises(ValueError, match="largest shard"):
+        sd.all_gather_shards(torch.zeros(n_total + 1, 2), n_total, world, padded=True)
     # the point-to-point ("direct") gather must reassemble the same tensor as the collective
     mine = torch.arange(b - a, dtype=torch.float32).reshape(-1, 1) + 100 * rank
     g1 = sd.all_gather_shards(mine, n_total, world, algo="allgather")
@@ -67,7 +81,7 @@ def _worker(rank, world, port, n_total, ks, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_total", [(2, 10), (2, 7), (8, 65536 + 3), (8, 5)])
+@pytest.mark.parametrize("world,n_total", [(2, 10), (2, 7), (8, 65536 + 3), (8, 5), (8, 64)])
 def test_sharded_volume_gloo(tmp_path, world, n_total):
     """world 2 and world 8 (the node size of BASELINE config 3): uneven shards (65539 = 8 x 8192 + 3)
     and EMPTY shards (5 points over 8 ranks: three ranks render nothing but must still enter every

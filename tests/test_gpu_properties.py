@@ -730,7 +730,7 @@ def test_split_path_shapes_agree_with_the_host_verified_path(n, spp, ks):
     one point, 1023 points, tiles beyond 48 KB of LDS -- through the one-call device-verified path and through
     the host-verified path of round 2: same PSFs, centres, trip tables."""
     from sdirt_amd import _lib
-    assert _lib.lib().sdirt_psf_spp_slices(n, spp) > 1
+    assert _lib.lib().sdirt_psf_spp_slices(n, spp, 0) > 1
     g = torch.Generator().manual_seed(n * 7 + spp)
     pts = torch.stack([(torch.rand(n, generator=g) - 0.5) * 1.9, (torch.rand(n, generator=g) - 0.5) * 1.9,
                        -(200 + torch.rand(n, generator=g) * 19800)], -1)
@@ -772,6 +772,72 @@ def test_ownership_and_mutation_follow_the_reference(lens):
     assert lens.trace2sensor(ray2) is ray2
     assert float(ray2.ra.sum()) > 0
     assert torch.allclose(ray2.o[..., 2][ray2.ra > 0], torch.tensor(float(lens.d_sensor), device=DEV))
+
+
+@pytest.mark.parametrize("n,spp,ks,mode", [(600, 1024, 33, "fused"), (2048, 2048, 65, "fused"), (64, 20000, 21, "sync"),
+                                           (64, 20000, 21, "defer"), (48, 6000, 33, "reduced"), (300, 512, 17, "uncentred")])
+def test_one_interleaved_block_equals_the_two_output_tensors(lens, n, spp, ks, mode):
+    """SDIRT_PSF_INTERLEAVED (psf_lr(out=ONE [N, 2, ks, ks] tensor)): point n's left grid at [n, 0], its right grid at
+    [n, 1] -- the block a rank of a sharded volume sends with one collective (sdirt_amd/dist.py) -- through every
+    launch shape: one workgroup per point (chief-ray pass fused), few points x many samples verified on the device
+    (synchronous sdirt_psf_call / deferred sdirt_psf_lr_verified), the host-verified split path a mask reduction
+    forces, and center=False.  Same pupil points -> the same PSFs as the two-tensor form (fp32 summation order only)."""
+    g = torch.Generator().manual_seed(n + ks)
+    pts = torch.stack([(torch.rand(n, generator=g) - 0.5) * 1.8, (torch.rand(n, generator=g) - 0.5) * 1.8,
+                       -(300 + torch.rand(n, generator=g) * 5000)], -1).to(DEV)
+    kw = dict(ks=ks, spp=spp, dp=DP)
+    if mode == "uncentred":
+        kw["center"] = False
+    if mode == "reduced":
+        lens.mask_reduce = lambda m: m                   # what ShardedPSF installs: forces the host-verified path
+    try:
+        def run(out):
+            torch.manual_seed(11)
+            if mode == "defer":
+                return lens.psf_lr(pts, out=out, defer=True, **kw).wait()
+            return lens.psf_lr(pts, out=out, **kw)
+        block = torch.full((n, 2, ks, ks), float("nan"), device=DEV)
+        Lb, Rb = run(block)
+        assert Lb.data_ptr() == block.data_ptr() and Rb.data_ptr() == block[:, 1].data_ptr()
+        L, R = run(None)
+    finally:
+        lens.mask_reduce = None
+    assert torch.isfinite(block).all()
+    assert float(L.max()) > 0.99 and float((block[:, 0] - L).abs().max()) < 2e-6 and float((block[:, 1] - R).abs().max()) < 2e-6
+    with pytest.raises(ValueError, match="left AND a right grid"):
+        lens.psf_lr(pts, ks=ks, spp=spp, dp=None, out=block)
+
+
+def test_obliquity_factor_is_carried_only_on_request(lens, monkeypatch):
+    """basics.py:240 / surfaces.py:674: the reference's Ray always carries `obliq`, and nothing on the PSF path reads
+    it (monte_carlo.py:46-50 computes and drops it).  Here the array exists once somebody asks for it: a bundle nobody
+    asked moves 28 instead of 32 bytes per ray through every staged kernel (sdirt_rays.obliq = NULL at the C ABI);
+    asked BEFORE the trace it is the reference's product of cosines; asked only AFTER a trace that did not carry it,
+    the call says so instead of inventing ones."""
+    from sdirt_amd import Ray, _lib, basics
+    pts = [[0.0, 0.0, -1000.0], [5.0, 0.0, -1000.0]]
+    torch.manual_seed(3)
+    a = lens.sample_from_points(o=pts, spp=64)
+    assert not a.has_obliq and a.c_rays().obliq is None and a.soa.shape[0] == 7
+    b = a.clone()
+    assert torch.all(b.obliq == 1) and b.has_obliq and b.c_rays().obliq is not None      # asked before the trace
+    lens.trace(a)
+    lens.trace(b)
+    assert torch.equal(a.soa.view(torch.int32), b.soa.view(torch.int32))                 # the same rays either way
+    ob = b.obliq
+    live = b.ra > 0
+    assert ob.shape == (64, 2) and bool(torch.all(ob[live] > 0.5)) and bool(torch.any(ob[live] < 1.0))
+    with pytest.raises(_lib.SdirtError, match="traced without its obliquity factor"):
+        a.obliq
+    a.obliq = torch.full((64, 2), 0.5, device=DEV)                                        # a caller may still SET it
+    assert float(a.clone().obliq.mean()) == 0.5
+    c = Ray(torch.zeros(4, 3), torch.tensor([0.0, 0.0, 1.0]), obliq=torch.full((4,), 0.25), device=DEV)
+    assert c.has_obliq and float(c.obliq.sum()) == 1.0
+    monkeypatch.setattr(basics, "TRACK_OBLIQ", True)                                      # the reference's behaviour
+    d = lens.sample_from_points(o=pts, spp=64)
+    assert d.has_obliq and torch.all(d.obliq == 1)
+    lens.trace2sensor(d)
+    assert d.has_obliq and bool(torch.any(d.obliq < 1.0))
 
 
 def test_a_failed_library_selftest_is_remembered(monkeypatch):

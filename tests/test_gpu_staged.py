@@ -59,7 +59,7 @@ def test_vectorised_sampler_and_propagate_equal_the_scalar_kernels_bit_for_bit(l
     assert torch.equal(a.soa[0, :a.numel].view(n, spp).t(), a.o[..., 0])
 
     def bits(r, k):
-        return torch.stack([r._field(c)[:k] for c in range(8)]).contiguous().view(torch.int32)
+        return torch.stack([r._field(c)[:k] for c in range(7)]).contiguous().view(torch.int32)
     assert torch.equal(bits(a, spp - 1), bits(b, spp - 1))
     assert torch.all(a.ra == 1) and torch.all(a.obliq == 1)
     a.propagate_to(-3.25)
@@ -211,7 +211,7 @@ def test_fused_calls_equal_the_two_step_forms_bit_for_bit(lens, precision):
         for n, ks in ((96, 33), (3, 21)):                      # a workgroup per point / few points: the spp axis is cut
             cen = torch.zeros((n, 2), device=DEV)
             sub = Ray.empty((1500, n), 0.589, DEV)
-            sub.soa.copy_(a.soa.view(8, 96, 1500)[:, :n].reshape(8, -1))
+            sub.soa.copy_(a.soa.view(7, 96, 1500)[:, :n].reshape(7, -1))
             _lib.check(h.sdirt_center_from_rays(sub.c_rays(), 1500, n, dptr(cen), None, st))
             L1, R1 = torch.empty((n, ks, ks), device=DEV), torch.empty((n, ks, ks), device=DEV)
             L2, R2 = torch.empty_like(L1), torch.empty_like(R1)

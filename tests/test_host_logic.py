@@ -185,7 +185,7 @@ def test_library_exports_every_declared_symbol():
     h = _lib.lib()                                                # loads, or raises loudly
     for s in syms:
         assert hasattr(h, s), f"libsdirt_dp.so does not export {s}"
-    assert h.sdirt_abi_version() == 2
+    assert h.sdirt_abi_version() == 3
     # ... and nothing but them (no kernel stubs, no experiment hooks)
     import subprocess
     out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH], text=True)
@@ -200,7 +200,7 @@ def test_python_constants_match_the_c_header():
     macros = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define\s+SDIRT_([A-Z0-9_]+)\s+(-?\d+)u?\b", txt)}
     mirrored = {k: v for k, v in macros.items() if hasattr(_lib, k)}
     assert {"MAX_SURFACES", "MAX_KS", "MAX_KS_STAGED", "PSF_NORMALIZE", "PSF_ONE_ROUND", "CTL_WORDS",
-            "TRACE_NO_PREFETCH", "NEWTON_MAXITER", "MAX_WAVELENGTHS"} <= set(mirrored)
+            "TRACE_NO_PREFETCH", "NEWTON_MAXITER", "MAX_WAVELENGTHS", "PSF_INTERLEAVED"} <= set(mirrored)
     for k, v in mirrored.items():
         assert getattr(_lib, k) == v, (k, v, getattr(_lib, k))
 
