@@ -62,7 +62,7 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s HBM3E
 VALU_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: vector fp32 (FMA counted as 2; the parity contract forbids contraction)
 # the two workloads either side of the hot path: not PSF-volume renders
-EXTRA_WORKLOADS = ("f1", "tcp", "staged")
+EXTRA_WORKLOADS = ("f1", "tcp", "staged", "sweep", "c5")
 
 
 def source_hash():
@@ -315,7 +315,7 @@ def bench_f1(args, emit=True):
     return res
 
 
-# 4096 points x 4096 spp x 32 B = 537 MB of rays: twice the 256 MiB Infinity Cache, so that the streaming kernels
+# 4096 points x 4096 spp x 28 B = 470 MB of rays (32 B = 537 MB with the obliquity array): well beyond the 256 MiB Infinity Cache, so that the streaming kernels
 # of the chain are timed against HBM and not against the cache
 STAGED_N, STAGED_SPP = 4096, 4096
 KERNEL_OF = {"sample_rays": "k_sample_rays", "trace": "k_trace", "propagate_to": "k_propagate",
@@ -325,7 +325,8 @@ KERNEL_OF = {"sample_rays": "k_sample_rays", "trace": "k_trace", "propagate_to":
 def bench_staged(args, emit=True, lens=None, ks_list=None):
     """The API-compatible STAGED sequence of the reference (optics.py:460-494 sample_from_points, :889-904 psf_center,
     :638-664 trace2sensor, monte_carlo.py:9-68 forward_integral, optics.py:983-987 normalise) as the library calls a
-    caller of those functions makes, rays held in HBM as a point-major SoA bundle (8 arrays of 4 bytes per ray):
+    caller of those functions makes, rays held in HBM as a point-major SoA bundle (7 arrays of 4 bytes per ray: o, d, ra; the obliquity
+    array, which nothing on this path reads, is not carried):
         sdirt_sample_rays -> sdirt_chief_center -> sdirt_trace -> sdirt_propagate_to -> sdirt_forward_integral ->
         sdirt_psf_normalize (L, R)
     on 4096 points of the config-2 volume (every 4th: all 16 depth planes) x 4096 spp, for 65x65 and 21x21 grids.
@@ -496,6 +497,166 @@ def bench_staged(args, emit=True, lens=None, ks_list=None):
     return res
 
 
+def bench_sweep(args, emit=True, lens=None):
+    """--workload sweep: the COMPUTE side of strong scaling, on the one GPU a box of this pool has.  Config 2 cut to
+    16384 / 8192 / 4096 / 2048 points per step (what a rank renders at world 1 / 2 / 4 / 8 under `--scaling strong`),
+    each through the loop `--gpus N` runs (VolumeLoop with force=True): pupil broadcast, deferred trip check behind a
+    mask all-reduce, the shard rendered into its [n, 2, ks, ks] block and that block all-gathered on the comm stream --
+    every collective really issued, on a world-1 RCCL process group (sdirt_amd.dist.FORCE_COLLECTIVES).  What a 1-GPU box
+    cannot show is the xGMI side: a rank of an 8-GPU run RECEIVES 7 blocks where this stand-in copies its own.
+    Every k-th point of the volume (all depth planes, all field positions), so that the batch-global Newton trip
+    tables are the whole volume's.  compute_efficiency = (ms of the plain 16384-point single-GPU step x n / 16384) /
+    ms_per_step: 1.0 = a rank of an N-GPU run would take exactly 1/N of the single-GPU step."""
+    import socket
+    import torch.distributed as dist
+    from sdirt_amd import dist as sd
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback exists)"
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    own_group = not dist.is_initialized()
+    if own_group:
+        sock = socket.socket()
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+        sock.close()
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+    sd.FORCE_COLLECTIVES = True
+    try:
+        if lens is None:
+            lens = build_lens(dev)
+        pts_all = volume_points(1, "c2").to(dev)
+        n_full = pts_all.shape[0]
+        steps = max(50, args.steps)
+        ks, spp = WORKLOADS["c2"]["ks"], WORKLOADS["c2"]["spp"]
+        rows = {}
+
+        def run(points, force, label):
+            loop = VolumeLoop(lens, points, points.shape[0], 1, dev, ks, spp, gather=force, force=force)
+            try:
+                loop.step()
+                loop.settle()                                    # trip-table discovery for this batch
+                for _ in range(10):
+                    loop.step()
+                loop.fence()
+                lens.kernel_events = {}
+                del loop.gather_events[:]
+                r0, c0 = lens.trips.relaunches, time.process_time()
+                dt = loop.timed(steps)
+                cpu_s = time.process_time() - c0
+                ev, lens.kernel_events = lens.kernel_events, None
+                k_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev["psf_lr_centered"]]))
+                row = {"points_per_step": points.shape[0], "steps": steps, "ms_per_step": dt / steps * 1e3, "kernel_ms": k_ms,
+                       "gpu_idle_us_per_step": (dt / steps * 1e3 - k_ms) * 1e3,
+                       "host_cpu_us_per_step": cpu_s / steps * 1e6,
+                       "rays_per_s": points.shape[0] * spp * steps / dt,
+                       "relaunches_in_timed_region": lens.trips.relaunches - r0,
+                       "trip_tables": {"psf": [int(v) for v in lens.trips.cache[("psf", 0.589, lens.precision)]],
+                                       "center": [int(v) for v in lens.trips.cache[("center", lens.precision)]]}}
+                if loop.gather_events:
+                    row["gather_ms"] = float(np.mean([a_.elapsed_time(b_) for a_, b_ in loop.gather_events]))
+                    row["gather_block_mb"] = points.shape[0] * 2 * ks * ks * 4 / 1e6
+                rows[label] = row
+                return row
+            finally:
+                loop.close()
+                del loop
+                torch.cuda.empty_cache()
+        import gc
+        base = run(pts_all, False, "single_gpu_loop_16384")       # the headline's own loop: no process group in the way
+        gc.collect()
+        gc.freeze()
+        for k in (1, 2, 4, 8):
+            row = run(pts_all[::k].contiguous(), True, f"world{k}_shard_{n_full // k}")
+            row["as_rank_of_world"] = k
+            row["compute_efficiency"] = base["ms_per_step"] * (row["points_per_step"] / n_full) / row["ms_per_step"]
+            row["trip_tables_equal_full_batch"] = row.pop("trip_tables") == base["trip_tables"]
+    finally:
+        sd.FORCE_COLLECTIVES = False
+        if own_group:
+            dist.destroy_process_group()
+    last = rows[f"world8_shard_{n_full // 8}"]
+    res = {"metric": "rays/sec rf50mm 65x65 DP-PSF @4096spp, strong-scaling compute side on one GPU (2048-point step of a rank of 8)",
+           "value": last["rays_per_s"], "unit": "rays/s", "n_gpus": 1, "steps": steps, "warmup": 10,
+           "ms_per_step": last["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+           "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "config 2 (rf50mm 32x32x16, 4096 spp, 65x65 L+R) cut to every k-th point, k = 1, 2, 4, 8: the step of "
+                                  "one rank of a k-GPU strong-scaling run, all collectives issued on a world-1 RCCL group",
+                      "name": "sweep", "backend": "nccl (RCCL), world 1",
+                      "not_measured": "xGMI: a rank of world k receives k - 1 blocks; here the gather copies the rank's own"},
+           "shard_sweep": rows}
+    if emit:
+        print(json.dumps(res), flush=True)
+    return res
+
+
+def bench_c5(args, emit=True):
+    """BASELINE config 5 on one GPU, end to end (2_dfdp_net.py's image simulation, then its depth network): a synthetic
+    512 x 768 RGB-D frame (NYUv2 is not in the reference's repository) -> PSFNet.render (psfnet.py:645-714: per-pixel
+    L/R kernels from the PSF network, per-pixel convolution; ks 21, full-size MLP with seeded weights -- the
+    reference's checkpoints are missing) -> DfDPNet forward under fp16 autocast (dfdp/dddnet/dddnet.py:122-152).
+    MIOpen's find mode (torch.backends.cudnn.benchmark) is OFF: the convolutions run with MIOpen's immediate-mode picks."""
+    from sdirt_amd.dfdp import DfDPNet
+    from sdirt_amd.psfnet import PSFNet
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback exists)"
+    dev = torch.device("cuda", 0)
+    find_mode = bool(torch.backends.cudnn.benchmark)
+    H, W, ks = 512, 768, 21
+    torch.manual_seed(0)
+    m = PSFNet(os.path.join(ROOT, "sdirt_amd", "data", "rf50mm.json"), sensor_res=(H, W), kernel_size=ks, device=dev)
+    m.refocus(-1000 + m.d_sensor)
+    with torch.no_grad():
+        m.psfnet.net[-2].bias.add_(0.02)        # seeded weights: keep the raw kernels away from an all-zero sum
+    g = torch.Generator(device=dev).manual_seed(0)
+    img = torch.rand(1, 3, H, W, device=dev, generator=g)
+    depth = -(500 + 4500 * torch.rand(1, 1, H, W, device=dev, generator=g))       # 0.5 ... 5 m
+    foc = torch.tensor([-1000.0], device=dev)
+    torch.manual_seed(1)
+    net = DfDPNet().to(dev).eval()
+    stream = torch.cuda.current_stream(dev)
+    ev = {"render": [], "dfdp_forward": []}
+
+    def chain(record=False):
+        with torch.no_grad():
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if record else None
+            if record:
+                e[0].record(stream)
+            pair = m.render(img, depth, foc)
+            if record:
+                e[1].record(stream)
+            left, right = pair[:, :3].contiguous(), pair[:, 3:].contiguous()
+            with torch.autocast("cuda", dtype=torch.float16):
+                disp = net(left, right)
+            if record:
+                e[2].record(stream)
+                ev["render"].append((e[0], e[1]))
+                ev["dfdp_forward"].append((e[1], e[2]))
+        return disp
+    t0 = time.perf_counter()
+    for _ in range(max(args.warmup, 3)):
+        disp = chain()
+    torch.cuda.synchronize(dev)
+    warm_s = time.perf_counter() - t0
+    steps = max(args.steps, 5)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        disp = chain(True)
+    torch.cuda.synchronize(dev)
+    wall = (time.perf_counter() - t0) / steps * 1e3
+    assert bool(torch.isfinite(disp).all())
+    ms = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in ev.items()}
+    res = {"metric": "frames/sec config 5: RGB-D 512x768 -> PSFNet.render (DP pair) -> DfDP net forward, 1 GPU",
+           "value": 1e3 / wall, "unit": "frames/s", "n_gpus": 1, "steps": steps, "warmup": max(args.warmup, 3),
+           "ms_per_step": wall, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16",
+           "data": "synthetic",
+           "config": {"workload": "synthetic RGB-D frame 1x3x512x768 (depth U[0.5, 5] m, focus 1 m) -> PSFNet.render, ks 21, full-size PSF "
+                                  "network (seeded weights) -> DfDPNet forward (fp16 autocast), rf50mm", "name": "c5",
+                      "miopen_find_mode": find_mode, "first_calls_s": warm_s},
+           "kernels_ms": ms}
+    if emit:
+        print(json.dumps(res), flush=True)
+    return res
+
+
 def quick_volume(workload, steps, device):
     """K steps of another PSF-volume workload (WORKLOADS) with the stepping of the headline loop -- calls kept in
     flight, Newton trip check of step i under step i + 1 -- for the `also` block of the default line."""
@@ -529,9 +690,10 @@ def quick_volume(workload, steps, device):
 
 
 def also_block(args, lens, device):
-    """The other driver-timed lines of the default run (3-5 steps each): the staged SoA chain (HBM-bound kernels), the
-    per-pixel PSF convolution f1 (HBM-bound), config 4 (rf35mm, the second prescription), one GPU's share of config 3
-    (8192 points x 8192 spp, 21 x 21) and the reference's own timing harness (tcp)."""
+    """The other driver-timed lines of the default run: the staged SoA chain (HBM-bound kernels; call by call and through
+    the fused entries), the per-pixel PSF convolution f1 (HBM-bound), config 4 (rf35mm, the second prescription), one
+    GPU's share of config 3 (8192 points x 8192 spp, 21 x 21), the reference's own timing harness (tcp), config 5 end to
+    end (c5) -- five steps each -- and the strong-scaling compute side (shard_sweep: 50 steps per shard size)."""
     import copy
     q = copy.copy(args)
     q.steps, q.warmup, q.sustain_seconds = 5, 2, 0.0
@@ -540,17 +702,20 @@ def also_block(args, lens, device):
     # allocations) dips for some tens of ms shortly after work resumes (tools/clock_ramp.py), longer than five such steps
     qs = copy.copy(q)
     qs.steps, qs.warmup = 10, 40
-    qs.staged_chain = "calls"          # the call-by-call chain; `--workload staged` also times the fused entries
+    qs.staged_chain = "both"           # the call-by-call chain and the one through the fused entries (`fused_calls`)
     for name, fn in (("staged", lambda: bench_staged(qs, emit=False, lens=lens)),
                      ("f1", lambda: bench_f1(q, emit=False)),
                      ("c4", lambda: quick_volume("c4", 5, device)),
                      ("c3", lambda: quick_volume("c3", 5, device)),
-                     ("tcp", lambda: bench_tcp(q, emit=False))):
+                     ("tcp", lambda: bench_tcp(q, emit=False)),
+                     ("c5", lambda: bench_c5(q, emit=False)),
+                     # last: it opens (and closes) a world-1 RCCL process group in this process
+                     ("shard_sweep", lambda: bench_sweep(q, emit=False, lens=lens))):
         t0 = time.perf_counter()
         try:
             r = fn()
             keep = ("metric", "value", "unit", "steps", "ms_per_step", "config", "roofline", "kernels_ms", "staged",
-                    "value_pcie_inclusive", "reference_harness")
+                    "value_pcie_inclusive", "reference_harness", "shard_sweep")
             out[name] = {k: r[k] for k in keep if k in r}
         except Exception as e:       # a broken side line must not cost the headline
             out[name] = {"error": f"{type(e).__name__}: {e}"}
@@ -599,6 +764,131 @@ def bench_tcp(args, emit=True):
     return res
 
 
+class VolumeLoop:
+    """The stepping of one rank of a PSF-volume render: `step()` enqueues one psf_lr call over the rank's points with
+    the speculated Newton trip tables (defer=True) and keeps DEPTH calls in flight; `settle()` verifies them in order
+    and -- when the step asked for it -- sends the now final shard through the all-gather on the comm stream;
+    `timed(k)` = k steps between two fences (barrier + device synchronisation), MAX over ranks.
+
+    world > 1 (or force=True: the single-rank stand-in of `--workload sweep`, every collective issued on a world-1
+    process group): the ranks share the pupil sample set (48 KB broadcast per step) and the batch-global trip check
+    (mask all-reduce, sdirt_amd/dist.py) and the shard is gathered to every rank.
+
+    A rank renders into ONE [width, 2, ks, ks] block per step -- point n's left grid at [n, 0], its right grid at
+    [n, 1] (SDIRT_PSF_INTERLEAVED) -- which is also what the gather sends: one collective per step, no staging copy
+    (ShardedPSF.shard_buffer / gather: the library path and the benchmarked path are the same)."""
+    DEPTH = 8        # calls kept in flight (kernel enqueued, Newton trip check pending): ~80 ms of queued work
+
+    def __init__(self, lens, points_local, n_total, world, device, ks, spp, gather, force=False):
+        import torch.distributed as dist
+        from sdirt_amd import dist as sd
+        self.lens, self.points, self.n_total, self.world, self.device = lens, points_local, n_total, world, device
+        self.ks, self.spp, self.gather, self.dist, self.sd = ks, spp, gather, dist, sd
+        self.n_local = points_local.shape[0]
+        self.multi = world > 1 or force
+        self.gather_group = self.comm_stream = self.sharded = None
+        if self.multi:
+            self.sharded = sd.ShardedPSF.from_lens(lens, ks, dp=DP)
+            # the all-gather of step i runs on its own stream underneath the kernels of step i+1
+            # (double-buffered: xGMI copy engines / RCCL channels vs. VALU-bound compute)
+            self.comm_stream = torch.cuda.Stream(device)
+            # its own communicator: PyTorch runs all collectives of one process group on one internal
+            # stream, so a gather issued on the default group would hold back the next step's small
+            # pupil broadcast (and with it the next kernel) until 4 GB have moved
+            self.gather_group = dist.new_group() if gather else None
+        self.width = max(b_ - a_ for a_, b_ in sd.shard_bounds(n_total, world))
+        self.gather_buf = [torch.empty((world * self.width, 2, ks, ks), dtype=torch.float32, device=device)
+                           for _ in range(2)] if (gather and self.multi) else None
+        self.step_no = 0
+        # output blocks are owned by the caller and re-used (the previous steps' PSFs may still be
+        # feeding the all-gather / the consumer while the next step renders)
+        self.out_bufs = [torch.zeros((self.width, 2, ks, ks), dtype=torch.float32, device=device)
+                         for _ in range(self.DEPTH + 1)]
+        self.gather_done = [None] * (self.DEPTH + 1)   # per output block: event of the last gather reading it
+        self.gathers = 0
+        self.gather_events = []                        # (start, end) on the comm stream, one pair per step's all-gather
+        self.in_flight = []                            # (PendingPSF, out, slot, ready event | None)
+
+    def close(self):
+        """Hand the lens back to single-rank use."""
+        if self.multi:
+            self.lens.mask_reduce = None
+
+    def settle(self, keep=0):
+        """Newton trip checks (lens.psf_lr(defer=True)) of all but the `keep` newest steps, each
+        followed -- when the step asked for it -- by the all-gather of its now final shard on
+        the comm stream.  The host stays `keep` kernels ahead of the GPU: the GPU renders step
+        i+1 while the host verifies step i and RCCL moves step i's PSFs, and a descheduled host
+        thread (the boxes are shared) does not leave the GPU idle."""
+        lens, device = self.lens, self.device
+        while len(self.in_flight) > keep:
+            pend, out, slot, ready = self.in_flight.pop(0)
+            r0 = lens.trips.relaunches
+            pend.wait()
+            if ready is None:
+                continue
+            if lens.trips.relaunches != r0:          # re-rendered: the shard is ready later
+                ready = torch.cuda.Event()
+                ready.record(torch.cuda.current_stream(device))
+            buf = self.gather_buf[self.gathers % 2]
+            self.gathers += 1
+            with torch.cuda.stream(self.comm_stream):
+                self.comm_stream.wait_event(ready)
+                g0 = torch.cuda.Event(enable_timing=True)
+                g0.record(self.comm_stream)
+                self.sharded.gather(out, self.n_total, out=buf, group=self.gather_group)   # ONE collective
+                done = torch.cuda.Event(enable_timing=True)
+                done.record(self.comm_stream)
+                self.gather_events.append((g0, done))
+            self.gather_done[slot] = done
+
+    def step(self, gather=None):
+        gather = self.gather if gather is None else gather
+        lens, device, n_local = self.lens, self.device, self.n_local
+        slot = self.step_no % (self.DEPTH + 1)
+        out = self.out_bufs[slot]
+        self.step_no += 1
+        if not self.multi:
+            self.in_flight.append((lens.psf_lr(self.points, ks=self.ks, spp=self.spp, dp=DP, out=out[:n_local], defer=True),
+                                   out, slot, None))
+            self.settle(keep=self.DEPTH)
+            return out
+        if self.gather_done[slot] is not None:
+            # an earlier gather may still read this block on the comm stream
+            torch.cuda.current_stream(device).wait_event(self.gather_done[slot])
+            self.gather_done[slot] = None
+        pupil = self.sd.broadcast_pupil_points(lens, self.spp)
+        pend = self.sharded.render(self.points, pupil, out[:n_local], defer=True)
+        ready = None
+        if gather:
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(device))
+        self.in_flight.append((pend, out, slot, ready))
+        self.settle(keep=3 if gather else self.DEPTH)   # gathers trail by three steps: a host hiccup on one rank stalls nobody
+        return out
+
+    def fence(self):
+        self.settle()
+        torch.cuda.synchronize(self.device)          # all streams of the device, the gather one too
+        if self.multi:
+            self.dist.barrier()
+            torch.cuda.synchronize(self.device)
+
+    def timed(self, k, gather=None):
+        """k steps between two fences; wall time = MAX over ranks."""
+        self.fence()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            self.step(gather)
+        self.fence()
+        dt = time.perf_counter() - t0
+        if self.multi:
+            tmax = torch.tensor([dt], dtype=torch.float64, device=self.device)
+            self.dist.all_reduce(tmax, op=self.dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        return dt
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -624,7 +914,9 @@ def main():
                     help="c2 (default, the headline) / c3 / c3k65 / c4: PSF-volume renders; f1: per-pixel DP-PSF "
                          "convolution of a 512x768 frame (render_psf.py:120-155); tcp: the reference's own "
                          "timing harness PSFNet.time_compare_psf (psfnet.py:570-586); staged: the reference's own "
-                         "call sequence sample -> trace -> propagate -> forward_integral on SoA rays in HBM")
+                         "call sequence sample -> trace -> propagate -> forward_integral on SoA rays in HBM; sweep: config 2 "
+                         "cut to the step of one rank of a 1 / 2 / 4 / 8-GPU strong-scaling run, collectives on a world-1 RCCL "
+                         "group; c5: config 5 end to end (RGB-D frame -> PSFNet.render -> DfDP net forward)")
     ap.add_argument("--staged-ks", default="65,21", help="--workload staged: the grid sizes to run the chain for")
     ap.add_argument("--staged-chain", choices=("both", "calls"), default="both",
                     help="--workload staged: `calls` times the call-by-call chain only (the profiling recipe: one kernel "
@@ -632,7 +924,7 @@ def main():
     args = ap.parse_args()
     if args.workload in EXTRA_WORKLOADS:
         assert args.gpus == 1, f"--workload {args.workload} is a single-GPU measurement"
-        return {"f1": bench_f1, "tcp": bench_tcp, "staged": bench_staged}[args.workload](args)
+        return {"f1": bench_f1, "tcp": bench_tcp, "staged": bench_staged, "sweep": bench_sweep, "c5": bench_c5}[args.workload](args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
     global KS, SPP, GRID_Z
@@ -673,103 +965,9 @@ def main():
     points_local = points_all[a:b].to(device)
     n_local = b - a
     gather_default = world > 1 and not args.no_gather
-
-    if world > 1:
-        sharded = sd.ShardedPSF.from_lens(lens, KS, dp=DP)
-        # the all-gather of step i runs on its own stream underneath the kernels of step i+1
-        # (double-buffered: xGMI copy engines / RCCL channels vs. VALU-bound compute)
-        comm_stream = torch.cuda.Stream(device)
-        # its own communicator: PyTorch runs all collectives of one process group on one internal
-        # stream, so a gather issued on the default group would hold back the next step's small
-        # pupil broadcast (and with it the next kernel) until 4 GB have moved
-        gather_group = dist.new_group() if gather_default else None
-    # A rank renders into ONE [width, 2, ks, ks] block per step -- point n's left grid at [n, 0], its right grid at
-    # [n, 1] (SDIRT_PSF_INTERLEAVED) -- which is also what the gather sends: one collective per step, no staging copy
-    # (sdirt_amd/dist.py: ShardedPSF.shard_buffer / gather; the library path and the benchmarked path are the same).
-    width = max(b_ - a_ for a_, b_ in sd.shard_bounds(n_total, world))
-    gather_buf = [torch.empty((world * width, 2, KS, KS), dtype=torch.float32, device=device)
-                  for _ in range(2)] if gather_default else None
-    step_no = [0]
-    # output blocks are owned by the caller and re-used (the previous steps' PSFs may still be
-    # feeding the all-gather / the consumer while the next step renders)
-    DEPTH = 8        # calls kept in flight (kernel enqueued, Newton trip check pending): ~80 ms of queued work
-    out_bufs = [torch.zeros((width, 2, KS, KS), dtype=torch.float32, device=device) for _ in range(DEPTH + 1)]
-
-    gather_done = [None] * (DEPTH + 1)   # per output block: event of the last gather reading it
-    gathers = [0]
-    gather_events = []                   # (start, end) on the comm stream, one pair per step's all-gather
-    in_flight = []                       # (PendingPSF, out, slot, ready event | None)
-
-    def settle(keep=0):
-        """Newton trip checks (lens.psf_lr(defer=True)) of all but the `keep` newest steps, each
-        followed -- when the step asked for it -- by the all-gather of its now final shard on
-        the comm stream.  The host stays `keep` kernels ahead of the GPU: the GPU renders step
-        i+1 while the host verifies step i and RCCL moves step i's PSFs, and a descheduled host
-        thread (the boxes are shared) does not leave the GPU idle."""
-        while len(in_flight) > keep:
-            pend, out, slot, ready = in_flight.pop(0)
-            r0 = lens.trips.relaunches
-            pend.wait()
-            if ready is None:
-                continue
-            if lens.trips.relaunches != r0:          # re-rendered: the shard is ready later
-                ready = torch.cuda.Event()
-                ready.record(torch.cuda.current_stream(device))
-            buf = gather_buf[gathers[0] % 2]
-            gathers[0] += 1
-            with torch.cuda.stream(comm_stream):
-                comm_stream.wait_event(ready)
-                g0 = torch.cuda.Event(enable_timing=True)
-                g0.record(comm_stream)
-                sharded.gather(out, n_total, out=buf, group=gather_group)      # ONE collective: [width, 2, ks, ks] per rank
-                done = torch.cuda.Event(enable_timing=True)
-                done.record(comm_stream)
-                gather_events.append((g0, done))
-            gather_done[slot] = done
-
-    def step(gather):
-        slot = step_no[0] % (DEPTH + 1)
-        out = out_bufs[slot]
-        step_no[0] += 1
-        if world == 1:
-            in_flight.append((lens.psf_lr(points_local, ks=KS, spp=SPP, dp=DP, out=out[:n_local], defer=True),
-                              out, slot, None))
-            settle(keep=DEPTH)
-            return out
-        if gather_done[slot] is not None:
-            # an earlier gather may still read these tensors on the comm stream
-            torch.cuda.current_stream(device).wait_event(gather_done[slot])
-            gather_done[slot] = None
-        pupil = sd.broadcast_pupil_points(lens, SPP)
-        pend = sharded.render(points_local, pupil, out[:n_local], defer=True)
-        ready = None
-        if gather:
-            ready = torch.cuda.Event()
-            ready.record(torch.cuda.current_stream(device))
-        in_flight.append((pend, out, slot, ready))
-        settle(keep=3 if gather else DEPTH)   # gathers trail by three steps: a host hiccup on one rank stalls nobody
-        return out
-
-    def fence():
-        settle()
-        torch.cuda.synchronize(device)          # all streams of the device, the gather one too
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize(device)
-
-    def timed(k, gather):
-        """k steps between two fences; wall time = MAX over ranks."""
-        fence()
-        t0 = time.perf_counter()
-        for _ in range(k):
-            step(gather)
-        fence()
-        dt = time.perf_counter() - t0
-        if world > 1:
-            tmax = torch.tensor([dt], dtype=torch.float64, device=device)
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            dt = float(tmax.item())
-        return dt
+    loop = VolumeLoop(lens, points_local, n_total, world, device, KS, SPP, gather_default)
+    step, settle, timed = loop.step, loop.settle, loop.timed
+    gather_events, gather_group, width, out_bufs = loop.gather_events, loop.gather_group, loop.width, loop.out_bufs
 
     # one-off initialisation, like loading the library: the first call on a lens discovers the
     # Newton trip tables (a launch with 10 trips everywhere, then the verified table); they are
@@ -837,15 +1035,18 @@ def main():
             traffic = counters.get("k_psf_lr_hbm_bytes_per_launch")
             n_instr = counters.get("k_psf_lr_valu_wave_instructions_per_launch")
             if n_instr:
-                # vector-instruction issue: peak = one full-rate wave64 instruction per 2 cycles per SIMD
-                # (1024 SIMDs, 2.4 GHz); half-rate forms and v_rcp / v_rsq make the reachable figure lower
-                peak = 1024 * 2.4e9 / 2
+                # vector-instruction issue: peak = one full-rate wave64 instruction per 2 cycles per SIMD (4 SIMDs per
+                # compute unit of THIS device, at the 2.4 GHz peak clock the 157.3 TFLOP/s figure is quoted for);
+                # half-rate forms and v_rcp / v_rsq make the reachable figure lower
+                n_simd = 4 * int(torch.cuda.get_device_properties(device).multi_processor_count)
+                peak = n_simd * 2.4e9 / 2
                 n_all = n_instr + (counters.get("salu_wave_instructions_per_launch") or 0) \
                     + (counters.get("smem_instructions_per_launch") or 0)
                 clk = counters.get("shader_clock_ghz") or 2.38
                 valu = {"wave_instructions_per_launch": n_instr,
                         "all_instructions_per_launch": n_all,
-                        "cycles_per_vector_instruction_per_simd": k_ms[dom] * 1e-3 * clk * 1e9 * 1024 / n_instr,
+                        "simds": n_simd,
+                        "cycles_per_vector_instruction_per_simd": k_ms[dom] * 1e-3 * clk * 1e9 * n_simd / n_instr,
                         "plain_fp32_cycles_per_instruction": 2.25,
                         "achieved_per_s": n_instr / (k_ms[dom] * 1e-3), "peak_per_s": peak,
                         "frac": n_instr / (k_ms[dom] * 1e-3) / peak,
@@ -853,7 +1054,7 @@ def main():
                         # (profiles/r02/form_bench.txt: v_fma / v_mul / v_add 2.25 cycles, v_rcp / v_rsq / v_sqrt
                         # 8.2) x the counted instructions, over the SIMD cycles the launch had
                         "issue_bound": _issue_bound(n_instr, counters.get("trans_f32_instructions_per_launch"),
-                                                    k_ms[dom] * 1e-3 * clk * 1e9 * 1024),
+                                                    k_ms[dom] * 1e-3 * clk * 1e9 * n_simd),
                         "stale": bool(counters["stale"]),
                         "source": {"kind": "carried: SQ_INSTS_VALU of a separate rocprofv3 --pmc run "
                                            "of this command, divided by THIS run's kernel time",

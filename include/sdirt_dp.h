@@ -39,7 +39,7 @@ extern "C" {
 #define SDIRT_NEWTON_MAXITER 10 /* deeplens/surfaces.py:26 */
 #define SDIRT_MAX_WAVELENGTHS 3 /* wavelength slots of one fused launch (psf_rgb) */
 #define SDIRT_MAX_KS 141        /* two ks*ks fp32 tiles + 1 KiB of bookkeeping fit in 160 KiB of LDS */
-#define SDIRT_MAX_KS_STAGED 1024 /* sdirt_forward_integral above SDIRT_MAX_KS adds into the grids in HBM: no LDS bound
+#define SDIRT_MAX_KS_STAGED 1024 /* sdirt_forward_integral adds into the grids in HBM once its tiles no longer fit LDS: no LDS bound
                                    (the reference's draw_mtf asks for ks 256, optics.py:2056) */
 
 typedef enum sdirt_status {
@@ -231,10 +231,13 @@ int sdirt_center_from_rays(sdirt_rays rays, int64_t spp, int64_t n_points,
 /* forward_integral + assign_points_to_pixels_small_r / _big_r,
  * deeplens/monte_carlo.py:9-68, 135-240, 242-372: sensor-plane rays -> RAW left
  * and right grids [N,ks,ks] (fully overwritten).  r_grid may be NULL.  Point-major bundle (ray (s, n) = element
- * n * spp + s).  ps = pixel size; center = pointc_ref [N,2].  ks up to SDIRT_MAX_KS_STAGED: up to SDIRT_MAX_KS a
- * point's grids are summed in LDS (in float64 up to ks 99) and written once, above that they are added to in HBM
- * (the fused sdirt_psf_* entries stop at SDIRT_MAX_KS; the staged chain sample -> trace -> chief centre ->
- * forward_integral -> normalize is the path for larger grids).  SDIRT_PSF_NORMALIZE: the grids leave max-normalised
+ * n * spp + s).  ps = pixel size; center = pointc_ref [N,2].  ks up to SDIRT_MAX_KS_STAGED.  Where a point's grids are
+ * summed is decided by what fits 159 KiB of LDS (sdirt_forward_integral_plan says which): float64 accumulators whenever
+ * ntile * ks * ks of them fit (ntile = 2 with an R grid, else 1: L + R up to ks 100, L alone up to ks 142), summed in
+ * arrival order and rounded to fp32 once; else float accumulators (L + R up to ks 142 -- SDIRT_MAX_KS and one more --, L
+ * alone up to ks 201); else the contributions are added to the grids in HBM with float atomics.  (The fused
+ * sdirt_psf_* entries stop at SDIRT_MAX_KS; the staged chain sample -> trace -> chief centre -> forward_integral ->
+ * normalize is the path for larger grids.)  SDIRT_PSF_NORMALIZE: the grids leave max-normalised
  * (deeplens/optics.py:983-987, what sdirt_psf_normalize does) -- straight from the tiles in LDS when a workgroup holds a
  * point's whole sum: the 2 x 4 bytes per pixel of the separate pass are never read back. */
 int sdirt_forward_integral(sdirt_rays rays, int64_t spp, int64_t n_points, double ps, int32_t ks,

@@ -26,6 +26,15 @@ import torch.distributed as dist
 from .basics import GEO_SPP
 
 
+#: True: issue every collective even on a world-1 process group (bench.py --workload sweep: the per-step host work and
+#: collective launches of a rank of an N-GPU run, measured on the one GPU a box has).  Default: a lone rank skips them.
+FORCE_COLLECTIVES = False
+
+
+def _alone(group):
+    return dist.get_world_size(group) == 1 and not FORCE_COLLECTIVES
+
+
 def shard_bounds(n, world):
     """Contiguous, balanced partition of range(n): list of (start, stop)."""
     return [(n * r // world, n * (r + 1) // world) for r in range(world)]
@@ -34,7 +43,7 @@ def shard_bounds(n, world):
 def reduce_masks_or(mask, group=None):
     """Bitwise OR of int32 masks over ranks.  NCCL/RCCL has no BOR: expand the
     (at most 11 used) bits into 0/1 lanes and take MAX."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()) or _alone(group):
         return mask
     bits = torch.arange(0, 11, device=mask.device, dtype=torch.int32)
     lanes = ((mask.to(torch.int32).unsqueeze(-1) >> bits) & 1).contiguous()
@@ -52,7 +61,7 @@ def broadcast_uniforms(spp, device, n_center=GEO_SPP, group=None, src=0):
                        torch.rand(n_center)]).to(device)
     else:
         u = torch.empty(total, dtype=torch.float32, device=device)
-    if dist.get_world_size(group) > 1:
+    if not _alone(group):
         dist.broadcast(u, src=src, group=group)
     return u[:spp], u[spp:2 * spp], u[2 * spp:2 * spp + n_center], u[2 * spp + n_center:]
 
@@ -67,7 +76,7 @@ def broadcast_pupil_points(lens, spp, n_center=GEO_SPP, group=None, src=0):
         x2, y2 = lens._pupil_samples(spp, pr)
         xc, yc = lens._pupil_samples(n_center, pr * 0.25)
         buf.copy_(torch.cat([x2, y2, xc, yc]))
-    if dist.get_world_size(group) > 1:
+    if not _alone(group):
         dist.broadcast(buf, src=src, group=group)
     return (buf[:spp], buf[spp:2 * spp], buf[2 * spp:2 * spp + n_center],
             buf[2 * spp + n_center:])

@@ -190,7 +190,7 @@ class Lensgroup:
     # nn.Module-style switches: the reference's Lensgroup / PSFNet inherit them from DeepObj(nn.Module)
     # (basics.py:165-213) and its scripts call them (dfdp/factory.py:15,31-32: lens.to(device), lens.eval())
     _DEVICE_CACHES = ("_stage_ring", "_sample_stream", "_readback_stream", "_ctl_pools", "_p2o_cache", "_ctl_host",
-                      "_right_streak", "_n_cus")
+                      "_right_streak", "_n_cus", "_pinned_out")
 
     def train(self, mode=True):
         """The PSF network (if this lens carries one) in training / evaluation mode; -> self."""
@@ -743,6 +743,26 @@ class Lensgroup:
         if _defer:
             return PendingPSF(lambda: pick(res.wait()))
         return pick(res)
+
+    def to_host(self, t):
+        """`t.to('cpu')` at PCIe speed: the copy goes into a PAGE-LOCKED buffer kept on the lens (one per shape and
+        dtype, the two most recent kept) and the caller's stream is waited for -- a pageable destination, what
+        Tensor.to('cpu') allocates, moved the 42.5 MB of the reference's timing harness (psfnet.py:570-586) at ~7 GB/s,
+        a third of its span.  The returned CPU tensor IS that buffer: valid until the next to_host() of the same shape;
+        `.clone()` it to keep it."""
+        if not t.is_cuda:
+            return t
+        pool = self.__dict__.setdefault("_pinned_out", {})
+        key = (tuple(t.shape), t.dtype)
+        host = pool.pop(key, None)
+        if host is None:
+            while len(pool) >= 2:
+                pool.pop(next(iter(pool)))
+            host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        pool[key] = host                                    # most recent last
+        host.copy_(t, non_blocking=True)
+        torch.cuda.current_stream(t.device).synchronize()
+        return host
 
     def _spp_slices(self, N, spp):
         """sdirt_psf_spp_slices for THIS lens's GPU (its CU count, whatever the caller's current device is)."""

@@ -414,7 +414,8 @@ class PSFNet(Lensgroup):
         points (x, y in [0, 1), z2depth of a uniform z), 2 * GEO_SPP = 4096 spp, kernel size of the
         model, the PSFs copied to the host INSIDE the timed span; then one network prediction for a
         128 x 192 field, copied to the host likewise.  Wall-clock seconds, as the reference prints
-        them -> (ray_tracing_seconds, network_seconds)."""
+        them -> (ray_tracing_seconds, network_seconds).  The reference's `.to('cpu')` is Lensgroup.to_host here:
+        the same copy into page-locked memory (a pageable destination was a third of the ray-tracing span)."""
         import time
         from .basics import GEO_SPP
         inp = torch.rand(512 * 768 // 16, 3)
@@ -422,14 +423,14 @@ class PSFNet(Lensgroup):
         if self.device.type == "cuda":
             torch.cuda.synchronize(self.device)
         start_time = time.time()
-        psfl = self.psf(points=inp, ks=self.kernel_size, center=True, spp=GEO_SPP * 2).to("cpu")
+        psfl = self.to_host(self.psf(points=inp, ks=self.kernel_size, center=True, spp=GEO_SPP * 2))
         t_trace = time.time() - start_time
         if verbose:
             print(f"ray_tracing time cost: {t_trace}s")
         inp = torch.rand(1, 512 // 4, 768 // 4, 3).to(self.device)
         start_time = time.time()
         with torch.no_grad():
-            psf2 = self.pred(inp).detach().to("cpu")
+            psf2 = self.to_host(self.pred(inp).detach())
         t_net = time.time() - start_time
         if verbose:
             print(f"network time cost: {t_net}s")

@@ -126,12 +126,14 @@ def test_own_geometric_optics_against_reference_state(name):
     m = dict(d_sensor=abs(lens.d_sensor - st["d_sensor"]), hfov=abs(lens.hfov / st["hfov"] - 1),
              foclen=abs(lens.foclen / st["foclen"] - 1), fnum=abs(lens.fnum / st["fnum"] - 1))
     print(name, "after refocus (seed 0): d_sensor", lens.d_sensor, "ref", st["d_sensor"], "MEASURED", m)
-    # measured (MI355X box, EPYC host): 0.0 mm -- the reference's 62.25132751464844 / 81.8495864868164 to the last
-    # fp32 digit -- and 0 / 0 / 8e-8 relative
-    assert m["d_sensor"] < 1e-5
-    assert m["hfov"] < 1e-5
-    assert m["foclen"] < 1e-5
-    assert m["fnum"] < 1e-5
+    # measured (MI355X box, EPYC host, torch 2.10 / numpy 2.2): 0.0 mm -- the reference's 62.25132751464844 /
+    # 81.8495864868164 to the last fp32 digit -- and 0 / 0 / 8e-8 relative.  The bound leaves room for another host:
+    # the result rests on the CPU generator's stream and on host-side fp reductions (np.mean, lstsq), which a
+    # different CPU, torch build or BLAS may round differently with no defect in the product
+    assert m["d_sensor"] < 1e-4
+    assert m["hfov"] < 1e-4
+    assert m["foclen"] < 1e-4
+    assert m["fnum"] < 1e-4
     # with the sensor pinned to the reference's value hfov agrees tightly (same 100 rays)
     lens.d_sensor = st["d_sensor"]
     lens.post_computation()

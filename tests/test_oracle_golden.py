@@ -11,6 +11,8 @@ a <=1-ulp vector pow, and torch.sum's reduction order over the spp axis depends
 on the CPU's vector width.  The oracle is the IEEE evaluation of the same
 operation sequence.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -324,3 +326,21 @@ def test_draw_psf_radial_fields(oracle):
         lit = g["psfs"][i] > 1e-3
         assert np.abs(lg - g["psfs_log"][i])[lit].max() < 2e-3
         assert np.array_equal(lg == 0, g["psfs_log"][i] == 0)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="needs the reference checkout (build container only)")
+def test_the_fixtures_regenerate_byte_for_byte(tmp_path):
+    """oracle/gen_golden.py, run afresh against the reference, reproduces every file it owns under tests/golden/ byte for
+    byte -- lens_state_*.json included: the reference's paraxial pupil estimate (an fp32 lstsq that lands on different
+    values run to run, oracle/ref_pupil_variation.py) is frozen at the committed value, and the fresh estimate is checked
+    to lie within that spread (the generator asserts it).  Build container only; a few seconds."""
+    import filecmp
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call([sys.executable, os.path.join(root, "oracle", "gen_golden.py"), "--out", str(tmp_path)],
+                          stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
+    names = sorted(os.listdir(tmp_path))
+    assert len(names) >= 14 and "lens_state_rf50mm.json" in names
+    different = [n for n in names if not filecmp.cmp(tmp_path / n, os.path.join(root, "tests", "golden", n), shallow=False)]
+    assert not different, different
