@@ -65,6 +65,29 @@ VALU_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: vector fp32 (FMA counted as 
 EXTRA_WORKLOADS = ("f1", "tcp", "staged", "sweep", "c5")
 
 
+_JSON_FD = None
+
+
+def claim_stdout():
+    """The contract is ONE JSON line on stdout.  Native libraries print there too (RCCL greets with a five-line version
+    banner when its first communicator comes up; MIOpen logs): from here on file descriptor 1 leads to stderr, and the
+    JSON line goes to the descriptor stdout had when the process started."""
+    global _JSON_FD
+    if _JSON_FD is None:
+        sys.stdout.flush()
+        _JSON_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit_line(res):
+    line = (json.dumps(res) + "\n").encode()
+    if _JSON_FD is None:
+        sys.stdout.write(line.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_JSON_FD, line)
+
+
 def source_hash():
     """Hash of what the loaded library was built from (csrc/*.hip, *.hpp, the Makefile with its flags, the ABI header):
     carried PMC counters name the hash they were collected on; a mismatch is reported as `stale`."""
@@ -311,7 +334,7 @@ def bench_f1(args, emit=True):
     if sus is not None:
         res["ms_per_step_sustained"] = sus
     if emit:
-        print(json.dumps(res), flush=True)
+        emit_line(res)
     return res
 
 
@@ -493,7 +516,7 @@ def bench_staged(args, emit=True, lens=None, ks_list=None):
                         "note": "the slowest of the chain's HBM-bound kernels; k_trace and k_chief_center are bound by vector "
                                 "ALU time like the fused kernel (per-kernel figures under `staged`)"}}
     if emit:
-        print(json.dumps(res), flush=True)
+        emit_line(res)
     return res
 
 
@@ -540,14 +563,16 @@ def bench_sweep(args, emit=True, lens=None):
                 loop.fence()
                 lens.kernel_events = {}
                 del loop.gather_events[:]
-                r0, c0 = lens.trips.relaunches, time.process_time()
+                r0 = lens.trips.relaunches
+                loop.t_step = loop.t_wait = 0.0
                 dt = loop.timed(steps)
-                cpu_s = time.process_time() - c0
                 ev, lens.kernel_events = lens.kernel_events, None
                 k_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev["psf_lr_centered"]]))
                 row = {"points_per_step": points.shape[0], "steps": steps, "ms_per_step": dt / steps * 1e3, "kernel_ms": k_ms,
                        "gpu_idle_us_per_step": (dt / steps * 1e3 - k_ms) * 1e3,
-                       "host_cpu_us_per_step": cpu_s / steps * 1e6,
+                       # wall time the host spends enqueueing a step (draw, upload, launches, collectives' host side,
+                       # verification arithmetic), without the time it sits blocked waiting for a result
+                       "host_us_per_step": (loop.t_step - loop.t_wait) / steps * 1e6,
                        "rays_per_s": points.shape[0] * spp * steps / dt,
                        "relaunches_in_timed_region": lens.trips.relaunches - r0,
                        "trip_tables": {"psf": [int(v) for v in lens.trips.cache[("psf", 0.589, lens.precision)]],
@@ -585,7 +610,7 @@ def bench_sweep(args, emit=True, lens=None):
                       "not_measured": "xGMI: a rank of world k receives k - 1 blocks; here the gather copies the rank's own"},
            "shard_sweep": rows}
     if emit:
-        print(json.dumps(res), flush=True)
+        emit_line(res)
     return res
 
 
@@ -653,7 +678,7 @@ def bench_c5(args, emit=True):
                       "miopen_find_mode": find_mode, "first_calls_s": warm_s},
            "kernels_ms": ms}
     if emit:
-        print(json.dumps(res), flush=True)
+        emit_line(res)
     return res
 
 
@@ -760,7 +785,7 @@ def bench_tcp(args, emit=True):
                       "points_per_gpu": n, "spp": spp, "ks": ks},
            "kernels_ms": {"psf_lr synchronous call (events)": kern}}
     if emit:
-        print(json.dumps(res), flush=True)
+        emit_line(res)
     return res
 
 
@@ -796,6 +821,11 @@ class VolumeLoop:
             # stream, so a gather issued on the default group would hold back the next step's small
             # pupil broadcast (and with it the next kernel) until 4 GB have moved
             self.gather_group = dist.new_group() if gather else None
+            # ... and the pupil broadcast of step i+1 on a third one, on a side stream: it depends on nothing that is
+            # queued, so it runs beside step i's kernel (on the default group it would queue behind step i's mask
+            # all-reduce, i.e. behind step i's kernel: 0.16-0.35 ms of idle GPU per step, `--workload sweep`)
+            self.pupil_group = dist.new_group()
+            self.pupil_stream = torch.cuda.Stream(device)
         self.width = max(b_ - a_ for a_, b_ in sd.shard_bounds(n_total, world))
         self.gather_buf = [torch.empty((world * self.width, 2, ks, ks), dtype=torch.float32, device=device)
                            for _ in range(2)] if (gather and self.multi) else None
@@ -808,6 +838,7 @@ class VolumeLoop:
         self.gathers = 0
         self.gather_events = []                        # (start, end) on the comm stream, one pair per step's all-gather
         self.in_flight = []                            # (PendingPSF, out, slot, ready event | None)
+        self.t_step = self.t_wait = 0.0                # wall seconds inside step() / of them blocked in PendingPSF.wait()
 
     def close(self):
         """Hand the lens back to single-rank use."""
@@ -824,7 +855,9 @@ class VolumeLoop:
         while len(self.in_flight) > keep:
             pend, out, slot, ready = self.in_flight.pop(0)
             r0 = lens.trips.relaunches
+            t_w = time.perf_counter()
             pend.wait()
+            self.t_wait += time.perf_counter() - t_w
             if ready is None:
                 continue
             if lens.trips.relaunches != r0:          # re-rendered: the shard is ready later
@@ -843,6 +876,13 @@ class VolumeLoop:
             self.gather_done[slot] = done
 
     def step(self, gather=None):
+        t0 = time.perf_counter()
+        try:
+            return self._step(gather)
+        finally:
+            self.t_step += time.perf_counter() - t0
+
+    def _step(self, gather=None):
         gather = self.gather if gather is None else gather
         lens, device, n_local = self.lens, self.device, self.n_local
         slot = self.step_no % (self.DEPTH + 1)
@@ -857,7 +897,7 @@ class VolumeLoop:
             # an earlier gather may still read this block on the comm stream
             torch.cuda.current_stream(device).wait_event(self.gather_done[slot])
             self.gather_done[slot] = None
-        pupil = self.sd.broadcast_pupil_points(lens, self.spp)
+        pupil = self.sd.broadcast_pupil_points(lens, self.spp, group=self.pupil_group, stream=self.pupil_stream)
         pend = self.sharded.render(self.points, pupil, out[:n_local], defer=True)
         ready = None
         if gather:
@@ -922,6 +962,8 @@ def main():
                     help="--workload staged: `calls` times the call-by-call chain only (the profiling recipe: one kernel "
                          "per name), `both` also the chain through sdirt_trace2sensor / SDIRT_PSF_NORMALIZE")
     args = ap.parse_args()
+    if not (args.gpus > 1 and "WORLD_SIZE" not in os.environ):      # (the self-launching parent relays its children's output)
+        claim_stdout()
     if args.workload in EXTRA_WORKLOADS:
         assert args.gpus == 1, f"--workload {args.workload} is a single-GPU measurement"
         return {"f1": bench_f1, "tcp": bench_tcp, "staged": bench_staged, "sweep": bench_sweep, "c5": bench_c5}[args.workload](args)
@@ -1135,7 +1177,7 @@ def main():
             res["also"] = also_block(args, lens, device)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(lens, points_all, pupil_last)
-        print(json.dumps(res), flush=True)
+        emit_line(res)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

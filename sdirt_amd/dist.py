@@ -66,18 +66,36 @@ def broadcast_uniforms(spp, device, n_center=GEO_SPP, group=None, src=0):
     return u[:spp], u[spp:2 * spp], u[2 * spp:2 * spp + n_center], u[2 * spp + n_center:]
 
 
-def broadcast_pupil_points(lens, spp, n_center=GEO_SPP, group=None, src=0):
+def broadcast_pupil_points(lens, spp, n_center=GEO_SPP, group=None, src=0, stream=None):
     """Rank `src` draws and maps the primary and the chief-ray pupil sample sets exactly as a
     single-GPU Lensgroup.psf_lr call would (same RNG order, same mapping); every rank
-    receives the same points: (x2, y2, xc, yc)."""
-    buf = torch.empty(2 * spp + 2 * n_center, dtype=torch.float32, device=lens.device)
-    if dist.get_rank(group) == src:
-        _, pr = lens.entrance_pupil()
-        x2, y2 = lens._pupil_samples(spp, pr)
-        xc, yc = lens._pupil_samples(n_center, pr * 0.25)
-        buf.copy_(torch.cat([x2, y2, xc, yc]))
-    if not _alone(group):
-        dist.broadcast(buf, src=src, group=group)
+    receives the same points: (x2, y2, xc, yc).
+
+    stream: a side stream for the whole of it (draw, mapping, broadcast) -- it depends on nothing the caller has
+    queued, so it can run beside the previous step's kernel; the caller's stream waits for its event only.  Give the
+    broadcast its own `group` then: collectives of one process group share one internal stream, and behind the
+    previous step's mask all-reduce the broadcast would wait for that step's kernel after all."""
+    main = torch.cuda.current_stream(lens.device) if stream is not None else None
+
+    def run():
+        buf = torch.empty(2 * spp + 2 * n_center, dtype=torch.float32, device=lens.device)
+        if dist.get_rank(group) == src:
+            _, pr = lens.entrance_pupil()
+            x2, y2 = lens._pupil_samples(spp, pr)
+            xc, yc = lens._pupil_samples(n_center, pr * 0.25)
+            buf.copy_(torch.cat([x2, y2, xc, yc]))
+        if not _alone(group):
+            dist.broadcast(buf, src=src, group=group)
+        return buf
+    if stream is None:
+        buf = run()
+    else:
+        with torch.cuda.stream(stream):
+            buf = run()
+            done = torch.cuda.Event()
+            done.record(stream)
+        main.wait_event(done)
+        buf.record_stream(main)
     return (buf[:spp], buf[spp:2 * spp], buf[2 * spp:2 * spp + n_center],
             buf[2 * spp + n_center:])
 

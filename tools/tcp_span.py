@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Where the ray-tracing span of the reference's timing harness (PSFNet.time_compare_psf, psfnet.py:570-586) goes:
+24576 random points x 4096 spp, ks 21, L only, the PSFs copied to the host inside the span.  Wall-clock pieces."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from sdirt_amd.psfnet import PSFNet  # noqa: E402
+
+dev = torch.device("cuda", 0)
+torch.manual_seed(0)
+m = PSFNet(os.path.join(ROOT, "sdirt_amd", "data", "rf50mm.json"), sensor_res=(512, 768), kernel_size=21, device=dev)
+m.refocus(-1000 + m.d_sensor)
+n, spp, ks = 24576, 4096, 21
+
+
+def wall(fn, reps=10):
+    fn(); fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    return np.median(ts) * 1e3
+
+
+inp = torch.rand(n, 3)
+inp[:, 2] = m.z2depth(inp[:, 2])
+ind = inp.to(dev)
+out = m.psf(points=ind, ks=ks, spp=spp)
+print(f"psf(device points)            {wall(lambda: m.psf(points=ind, ks=ks, spp=spp)):7.3f} ms")
+print(f"psf(host points)              {wall(lambda: m.psf(points=inp, ks=ks, spp=spp)):7.3f} ms")
+print(f"to_host (page-locked, cached) {wall(lambda: m.to_host(out)):7.3f} ms  ({out.numel() * 4 / 1e6:.1f} MB)")
+print(f".to('cpu') (pageable)         {wall(lambda: out.to('cpu')):7.3f} ms")
+print(f"psf(host points) + to_host    {wall(lambda: m.to_host(m.psf(points=inp, ks=ks, spp=spp))):7.3f} ms")
+tt = [m.time_compare_psf(verbose=False)[0] for _ in range(10)]
+print(f"time_compare_psf span         {np.median(tt) * 1e3:7.3f} ms -> {n * spp / np.median(tt) / 1e9:.2f} G rays/s PCIe-inclusive")
