@@ -529,7 +529,8 @@ def bench_sweep(args, emit=True, lens=None):
     cannot show is the xGMI side: a rank of an 8-GPU run RECEIVES 7 blocks where this stand-in copies its own.
     Every k-th point of the volume (all depth planes, all field positions), so that the batch-global Newton trip
     tables are the whole volume's.  compute_efficiency = (ms of the plain 16384-point single-GPU step x n / 16384) /
-    ms_per_step: 1.0 = a rank of an N-GPU run would take exactly 1/N of the single-GPU step."""
+    ms_per_step: 1.0 = a rank of an N-GPU run would take exactly 1/N of the single-GPU step (marginal cost of a step,
+    from two region lengths; `fences_ms` is what the barrier + synchronisation pair around a timed region adds)."""
     import socket
     import torch.distributed as dist
     from sdirt_amd import dist as sd
@@ -549,7 +550,7 @@ def bench_sweep(args, emit=True, lens=None):
             lens = build_lens(dev)
         pts_all = volume_points(1, "c2").to(dev)
         n_full = pts_all.shape[0]
-        steps = max(50, args.steps)
+        steps = max(100, args.steps)
         ks, spp = WORKLOADS["c2"]["ks"], WORKLOADS["c2"]["spp"]
         rows = {}
 
@@ -564,12 +565,17 @@ def bench_sweep(args, emit=True, lens=None):
                 lens.kernel_events = {}
                 del loop.gather_events[:]
                 r0 = lens.trips.relaunches
+                # two region lengths: the slope is the cost of a step, the intercept what the two fences of a timed
+                # region cost (pipeline drain, the last steps' verification and gathers, barrier, device synchronisation)
+                dt_short = loop.timed(steps // 4)
                 loop.t_step = loop.t_wait = 0.0
                 dt = loop.timed(steps)
+                marginal = (dt - dt_short) / (steps - steps // 4) * 1e3
                 ev, lens.kernel_events = lens.kernel_events, None
                 k_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev["psf_lr_centered"]]))
-                row = {"points_per_step": points.shape[0], "steps": steps, "ms_per_step": dt / steps * 1e3, "kernel_ms": k_ms,
-                       "gpu_idle_us_per_step": (dt / steps * 1e3 - k_ms) * 1e3,
+                row = {"points_per_step": points.shape[0], "steps": steps, "ms_per_step": dt / steps * 1e3,
+                       "ms_per_step_marginal": marginal, "fences_ms": dt * 1e3 - marginal * steps, "kernel_ms": k_ms,
+                       "gpu_idle_us_per_step": (marginal - k_ms) * 1e3,
                        # wall time the host spends enqueueing a step (draw, upload, launches, collectives' host side,
                        # verification arithmetic), without the time it sits blocked waiting for a result
                        "host_us_per_step": (loop.t_step - loop.t_wait) / steps * 1e6,
@@ -593,7 +599,10 @@ def bench_sweep(args, emit=True, lens=None):
         for k in (1, 2, 4, 8):
             row = run(pts_all[::k].contiguous(), True, f"world{k}_shard_{n_full // k}")
             row["as_rank_of_world"] = k
-            row["compute_efficiency"] = base["ms_per_step"] * (row["points_per_step"] / n_full) / row["ms_per_step"]
+            # marginal step against marginal step: what a long run converges to; `..._incl_fences`: this 100-step region
+            row["compute_efficiency"] = base["ms_per_step_marginal"] * (row["points_per_step"] / n_full) / row["ms_per_step_marginal"]
+            row["compute_efficiency_incl_fences"] = base["ms_per_step"] * (row["points_per_step"] / n_full) / row["ms_per_step"]
+            row["kernel_efficiency"] = base["kernel_ms"] * (row["points_per_step"] / n_full) / row["kernel_ms"]
             row["trip_tables_equal_full_batch"] = row.pop("trip_tables") == base["trip_tables"]
     finally:
         sd.FORCE_COLLECTIVES = False
@@ -730,8 +739,8 @@ def also_block(args, lens, device):
     qs.staged_chain = "both"           # the call-by-call chain and the one through the fused entries (`fused_calls`)
     for name, fn in (("staged", lambda: bench_staged(qs, emit=False, lens=lens)),
                      ("f1", lambda: bench_f1(q, emit=False)),
-                     ("c4", lambda: quick_volume("c4", 5, device)),
-                     ("c3", lambda: quick_volume("c3", 5, device)),
+                     ("c4", lambda: quick_volume("c4", 20, device)),
+                     ("c3", lambda: quick_volume("c3", 20, device)),
                      ("tcp", lambda: bench_tcp(q, emit=False)),
                      ("c5", lambda: bench_c5(q, emit=False)),
                      # last: it opens (and closes) a world-1 RCCL process group in this process
@@ -839,6 +848,7 @@ class VolumeLoop:
         self.gather_events = []                        # (start, end) on the comm stream, one pair per step's all-gather
         self.in_flight = []                            # (PendingPSF, out, slot, ready event | None)
         self.t_step = self.t_wait = 0.0                # wall seconds inside step() / of them blocked in PendingPSF.wait()
+        self.in_step = False
 
     def close(self):
         """Hand the lens back to single-rank use."""
@@ -857,7 +867,8 @@ class VolumeLoop:
             r0 = lens.trips.relaunches
             t_w = time.perf_counter()
             pend.wait()
-            self.t_wait += time.perf_counter() - t_w
+            if self.in_step:
+                self.t_wait += time.perf_counter() - t_w
             if ready is None:
                 continue
             if lens.trips.relaunches != r0:          # re-rendered: the shard is ready later
@@ -877,9 +888,11 @@ class VolumeLoop:
 
     def step(self, gather=None):
         t0 = time.perf_counter()
+        self.in_step = True
         try:
             return self._step(gather)
         finally:
+            self.in_step = False
             self.t_step += time.perf_counter() - t0
 
     def _step(self, gather=None):

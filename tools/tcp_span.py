@@ -42,3 +42,23 @@ print(f".to('cpu') (pageable)         {wall(lambda: out.to('cpu')):7.3f} ms")
 print(f"psf(host points) + to_host    {wall(lambda: m.to_host(m.psf(points=inp, ks=ks, spp=spp))):7.3f} ms")
 tt = [m.time_compare_psf(verbose=False)[0] for _ in range(10)]
 print(f"time_compare_psf span         {np.median(tt) * 1e3:7.3f} ms -> {n * spp / np.median(tt) / 1e9:.2f} G rays/s PCIe-inclusive")
+r0 = m.trips.relaunches
+tt = [m.time_compare_psf(verbose=False)[0] * 1e3 for _ in range(10)]
+print("time_compare_psf spans (ms):", " ".join(f"{t:.2f}" for t in tt), " host re-launches:", m.trips.relaunches - r0)
+# the same batch again and again through the harness' own statements
+spans = []
+for _ in range(10):
+    torch.cuda.synchronize()
+    t0 = time.time()
+    psfl = m.to_host(m.psf(points=inp, ks=ks, center=True, spp=spp))
+    spans.append((time.time() - t0) * 1e3)
+print("same statements, one fixed batch (ms):", " ".join(f"{t:.2f}" for t in spans))
+import cProfile
+import pstats
+pr = cProfile.Profile()
+pr.enable()
+for _ in range(20):
+    m.psf(points=inp, ks=ks, spp=spp)
+torch.cuda.synchronize()
+pr.disable()
+pstats.Stats(pr).sort_stats("cumulative").print_stats(22)
