@@ -37,6 +37,12 @@ import time
 os.environ.setdefault("OMP_WAIT_POLICY", "passive")
 # the pool's host driver only supports dmabuf IPC (RCCL between processes needs it)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# HIP maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and packets of one hardware queue
+# run in order: a rank of a multi-GPU run has eight streams (render, pupil, read-back, gather, three RCCL
+# communicators, sampling), and on four queues the next step's kernel sat behind the previous step's mask all-reduce
+# although their streams are independent -- 0.09 ms of idle GPU per step, 4 us with 16 queues (`--workload sweep`,
+# profiles/r05/sweep_hw_queues.txt).  Read when the HIP runtime initialises, i.e. before anything touches the GPU.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 import numpy as np
 import torch
@@ -397,8 +403,10 @@ def bench_staged(args, emit=True, lens=None, ks_list=None):
     stream = torch.cuda.current_stream(dev)
     out = {}
     for ks in ks_list:
-        L = torch.empty((N, ks, ks), dtype=torch.float32, device=dev)
-        R = torch.empty_like(L)
+        # L and R as the two halves of one buffer: a caller who owns both normalises them with ONE sdirt_psf_normalize
+        # launch over 2 N tiles (each tile by its own maximum, optics.py:983-987)
+        LR = torch.empty((2, N, ks, ks), dtype=torch.float32, device=dev)
+        L, R = LR[0], LR[1]
         calls = [
             ("sample_rays", lambda: h.sdirt_sample_rays(dptr(po), N, dptr(x2), dptr(y2), S, float(pupilz), ray.c_rays(), st)),
             ("chief_center", lambda: h.sdirt_chief_center(handle, dptr(po), N, dptr(xc), dptr(yc), 2048, float(pupilz_c),
@@ -408,7 +416,7 @@ def bench_staged(args, emit=True, lens=None, ks_list=None):
             ("propagate_to", lambda: h.sdirt_propagate_to(float(lens.d_sensor), ray.c_rays(), M, st)),
             ("forward_integral", lambda: h.sdirt_forward_integral(ray.c_rays(), S, N, float(lens.pixel_size), ks, dptr(cen),
                                                                   C.byref(dp), flags, dptr(L), dptr(R), st)),
-            ("psf_normalize", lambda: (h.sdirt_psf_normalize(dptr(L), N, ks, st) or h.sdirt_psf_normalize(dptr(R), N, ks, st))),
+            ("psf_normalize", lambda: h.sdirt_psf_normalize(dptr(LR), 2 * N, ks, st)),
         ]
 
         # the same work with the two fused entries: trace2sensor in one pass, grids normalised out of the LDS tiles
@@ -482,7 +490,7 @@ def bench_staged(args, emit=True, lens=None, ks_list=None):
                 gbs = alg[name] / (t * 1e-3) / 1e9
                 k.update({"algorithmic_bytes": alg[name], "achieved_GBps": gbs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS})
                 c = ((carried or {}).get("kernels") or {}).get(KERNEL_OF[name])
-                nl = 2 if name == "psf_normalize" else 1          # L and R are normalised by one launch each
+                nl = 1                                            # (L and R are normalised by one launch over 2 N tiles)
                 if nl > 1:
                     k["launches"] = nl
                 if c and c.get("hbm_bytes_per_dispatch_mean_last3") and (carried.get("n_points"), carried.get("spp")) == (N, S):

@@ -31,6 +31,9 @@ from .basics import GEO_SPP
 FORCE_COLLECTIVES = False
 
 
+_BITS = {}      # device -> arange(11): the bit lanes of reduce_masks_or
+
+
 def _alone(group):
     return dist.get_world_size(group) == 1 and not FORCE_COLLECTIVES
 
@@ -45,7 +48,9 @@ def reduce_masks_or(mask, group=None):
     (at most 11 used) bits into 0/1 lanes and take MAX."""
     if not (dist.is_available() and dist.is_initialized()) or _alone(group):
         return mask
-    bits = torch.arange(0, 11, device=mask.device, dtype=torch.int32)
+    bits = _BITS.get(mask.device)
+    if bits is None:
+        bits = _BITS[mask.device] = torch.arange(0, 11, device=mask.device, dtype=torch.int32)
     lanes = ((mask.to(torch.int32).unsqueeze(-1) >> bits) & 1).contiguous()
     dist.all_reduce(lanes, op=dist.ReduceOp.MAX, group=group)
     return (lanes << bits).sum(-1).to(mask.dtype)
@@ -78,12 +83,19 @@ def broadcast_pupil_points(lens, spp, n_center=GEO_SPP, group=None, src=0, strea
     main = torch.cuda.current_stream(lens.device) if stream is not None else None
 
     def run():
-        buf = torch.empty(2 * spp + 2 * n_center, dtype=torch.float32, device=lens.device)
+        total = 2 * spp + 2 * n_center
         if dist.get_rank(group) == src:
+            # one draw, one upload, one device block [x2 | y2 | xc | yc] -- value for value the reference's four
+            # consecutive draws (Lensgroup._pupil_samples_pair) -- which is the broadcast buffer as it stands
             _, pr = lens.entrance_pupil()
-            x2, y2 = lens._pupil_samples(spp, pr)
-            xc, yc = lens._pupil_samples(n_center, pr * 0.25)
-            buf.copy_(torch.cat([x2, y2, xc, yc]))
+            parts = lens._pupil_samples_pair(spp, pr, n_center, pr * 0.25, side_stream=False)
+            base = parts[0]._base
+            if base is not None and base.numel() == total and base.is_contiguous() and parts[0].data_ptr() == base.data_ptr():
+                buf = base
+            else:                                              # pupil_mapping='host': four separate tensors
+                buf = torch.cat(parts)
+        else:
+            buf = torch.empty(total, dtype=torch.float32, device=lens.device)
         if not _alone(group):
             dist.broadcast(buf, src=src, group=group)
         return buf

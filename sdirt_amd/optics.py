@@ -692,7 +692,12 @@ class Lensgroup:
             n = points.shape[0]
             stage, uploaded = self._staging(max(n, 1), depth=4, rows=3)
             host = stage.view(-1)[:3 * n].view(n, 3)
-            host.copy_(points)
+            if points.dtype == torch.float32 and points.is_contiguous() and not points.requires_grad:
+                # a plain memcpy: torch's CPU copy_ is an OpenMP-parallel op whose worker threads spin afterwards --
+                # inside a CPU-quota'd container that can cost the calling thread its time slice (tools/tcp_span.py)
+                np.copyto(host.numpy(), points.numpy())
+            else:
+                host.copy_(points)
             pts = host.to(self.device, non_blocking=True)
             uploaded.record(torch.cuda.current_stream(self.device))
         else:
