@@ -808,6 +808,25 @@ def test_one_interleaved_block_equals_the_two_output_tensors(lens, n, spp, ks, m
         lens.psf_lr(pts, ks=ks, spp=spp, dp=None, out=block)
 
 
+def test_to_host_is_the_reference_s_to_cpu_into_page_locked_memory(lens):
+    """Lensgroup.to_host(t) == t.to('cpu') (psfnet.py:570-586 copies its PSFs to the host inside the timed span), into a
+    page-locked buffer kept on the lens: the same values, pinned, the SAME buffer again for the same shape (valid until
+    the next call of that shape), the two most recent shapes kept."""
+    a = torch.rand(300, 21, 21, device=DEV)
+    h = lens.to_host(a)
+    assert h.device.type == "cpu" and h.is_pinned() and torch.equal(h, a.cpu())
+    b = torch.rand(300, 21, 21, device=DEV)
+    h2 = lens.to_host(b)
+    assert h2.data_ptr() == h.data_ptr() and torch.equal(h2, b.cpu())            # re-used: `h` now shows b
+    lens.to_host(torch.rand(7, device=DEV))
+    lens.to_host(torch.rand(9, device=DEV))                                      # a third shape evicts the oldest
+    assert len(lens.__dict__["_pinned_out"]) == 2
+    strided = torch.rand(50, 2, 5, 5, device=DEV)[:, 1]
+    assert torch.equal(lens.to_host(strided), strided.cpu())
+    cpu = torch.rand(3)
+    assert lens.to_host(cpu) is cpu
+
+
 def test_obliquity_factor_is_carried_only_on_request(lens, monkeypatch):
     """basics.py:240 / surfaces.py:674: the reference's Ray always carries `obliq`, and nothing on the PSF path reads
     it (monte_carlo.py:46-50 computes and drops it).  Here the array exists once somebody asks for it: a bundle nobody

@@ -520,3 +520,19 @@ def test_forward_integral_launch_plan_for_every_grid_and_batch_shape():
             assert groups < 2 * cus
     assert seen == {0, 4, 8}
     assert h.sdirt_forward_integral_plan(0, 10, 21, 1, 256, plan) != 0 and b"bad argument" in h.sdirt_last_error()
+
+
+def test_bench_keeps_stdout_for_its_one_json_line(tmp_path):
+    """The driver reads ONE JSON line from bench.py's stdout.  Native libraries print there too (RCCL's version banner when
+    its first communicator comes up): bench.claim_stdout() points file descriptor 1 at stderr and emit_line() writes to
+    the descriptor stdout had at start-up."""
+    import subprocess
+    import sys
+    code = ("import os, sys, json; sys.path.insert(0, %r); import bench; bench.claim_stdout(); "
+            "os.write(1, b'RCCL version : banner\\n'); print('a stray print'); bench.emit_line({'metric': 'm', 'value': 1.5}); "
+            "os.write(1, b'more noise\\n')" % ROOT)
+    p = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and __import__("json").loads(lines[0]) == {"metric": "m", "value": 1.5}, p.stdout
+    assert "RCCL version : banner" in p.stderr and "a stray print" in p.stderr and "more noise" in p.stderr
