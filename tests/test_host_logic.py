@@ -536,3 +536,16 @@ def test_bench_keeps_stdout_for_its_one_json_line(tmp_path):
     lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1 and __import__("json").loads(lines[0]) == {"metric": "m", "value": 1.5}, p.stdout
     assert "RCCL version : banner" in p.stderr and "a stray print" in p.stderr and "more noise" in p.stderr
+
+
+def test_spp_slices_is_host_arithmetic_with_an_explicit_cu_count():
+    """sdirt_psf_spp_slices(n_points, spp, n_cus) with n_cus > 0 touches no device (this suite runs without one): one
+    workgroup per point once the points alone give four workgroups per CU, the spp axis cut otherwise -- and the cut
+    depends on the CU count (so do, in their last bits, the PSFs of a split call: include/sdirt_dp.h)."""
+    from sdirt_amd import _lib
+    h = _lib.lib()
+    assert h.sdirt_psf_spp_slices(16384, 4096, 256) == 1 and h.sdirt_psf_spp_slices(1024, 4096, 256) == 1
+    assert h.sdirt_psf_spp_slices(64, 20000, 256) == 16          # the PSFNet fitting shape on an MI355X: 16 x 1280 samples
+    assert h.sdirt_psf_spp_slices(64, 20000, 32) == 2            # one XCD of a partitioned chip
+    assert h.sdirt_psf_spp_slices(1023, 4096, 256) == 2 and h.sdirt_psf_spp_slices(64, 1024, 256) == 1
+    assert h.sdirt_psf_spp_slices(0, 4096, 256) == 1 and h.sdirt_psf_spp_slices(64, 0, 256) == 1
