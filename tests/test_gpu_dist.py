@@ -184,6 +184,7 @@ def test_bench_strong_scaling_config2_with_eight_ranks_on_one_gpu(algo):
     assert g["algo"] == algo and g["world_size"] == 8 and g["backend"] == "gloo"
     assert abs(g["gb_received_per_rank_per_step"] - 2 * 7 * 2048 * 65 * 65 * 4 / 1e9) < 1e-9
     assert g["ms"] > 0 and g["compute_ms"] > 0 and isinstance(g["gather_bound"], bool)
+    assert g["collectives_per_step"] == 1                      # one [2048, 2, 65, 65] block per rank, rendered in place
     log = os.environ.get("SDIRT_TEST_LOG_DIR")
     if log:
         with open(os.path.join(log, f"bench_gpus8_dryrun_c2_strong_{algo}.log"), "w") as f:
@@ -198,3 +199,30 @@ def test_rccl_backend_accepts_the_collectives_of_the_multi_gpu_path():
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
     assert p.returncode == 0, p.stderr[-3000:]
     assert "rccl single-rank collectives ok" in p.stdout
+
+
+@pytest.mark.gpu
+def test_the_multi_rank_step_over_rccl_on_one_gpu():
+    """`bench.py --workload sweep`: the loop `--gpus N` runs, with every collective issued on a world-1 RCCL process group --
+    pupil broadcast on its own communicator and stream, the mask all-reduce on the read-back stream, the shard rendered in
+    place into the [n, 2, ks, ks] block that ONE all-gather moves -- for config 2 cut to the step of a rank of 1 / 2 / 4 / 8.
+    Every k-th point keeps the whole volume's batch-global trip tables; ONE JSON line on stdout (RCCL's banner goes to stderr)."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "sweep"], env=_env(),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    rows = d["shard_sweep"]
+    assert set(rows) == {"single_gpu_loop_16384", "world1_shard_16384", "world2_shard_8192", "world4_shard_4096", "world8_shard_2048"}
+    for name, r in rows.items():
+        assert r["relaunches_in_timed_region"] == 0 and r["kernel_ms"] > 0, (name, r)
+        if name.startswith("world"):
+            assert r["trip_tables_equal_full_batch"] and r["gather_ms"] > 0, (name, r)
+            # measured 0.986 / 0.982 / 0.951 / 0.903 (profiles/r05/bench_c2.json); the bound is the kernel's 0.13 ms per launch
+            assert 0.8 < r["compute_efficiency"] < 1.05, (name, r)
+    assert rows["world8_shard_2048"]["points_per_step"] == 2048
+    log = os.environ.get("SDIRT_TEST_LOG_DIR")
+    if log:
+        with open(os.path.join(log, "bench_sweep.json"), "w") as f:
+            f.write(lines[0] + "\n")
