@@ -1089,7 +1089,7 @@ class Lensgroup:
                        pupil_xy, center_pupil_xy, out, center_out, single_point):
         """psf_lr for SDIRT_MAX_KS < ks <= SDIRT_MAX_KS_STAGED: the reference's own sequence of optics.py:962-987
         as five library calls -- sample_from_points, psf_center, trace2sensor, forward_integral (adds into the
-        grids in HBM instead of LDS), normalise -- on [spp, N] rays held in HBM (32 bytes per ray).  Same rays,
+        grids in HBM instead of LDS), normalise -- on [spp, N] rays held in HBM (28 bytes per ray).  Same rays,
         centres and trip tables as the fused kernel; the plots that ask for such grids (draw_mtf) trace a
         handful of points."""
         if not 2 <= ks <= _lib.MAX_KS_STAGED:
