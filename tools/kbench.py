@@ -27,6 +27,9 @@ def main():
     ap.add_argument("--ks", type=int, default=65)
     ap.add_argument("--lens", default="rf50mm")
     ap.add_argument("--flags", type=int, default=0, help="4 = SDIRT_PSF_STRICT_IEEE")
+    ap.add_argument("--order", default="volume", choices=("volume", "shuffle", "sorted_depth", "same"),
+                    help="order of the points in the launch: volume (z-major, as bench.py), shuffle (random permutation), "
+                         "same (every point = the first one: equal work per workgroup)")
     ap.add_argument("--trips", type=int, default=None,
                     help="this many Newton trips on EVERY curved surface of both passes (for the per-trip "
                          "cost: time two values and divide the difference)")
@@ -38,7 +41,12 @@ def main():
     dev = torch.device("cuda:0")
     st = load_state(args.lens)
     lens = make_lens(args.lens, "cuda:0", st)
-    pts = bench.volume_points(1)[:: max(1, 16384 // args.n)][: args.n].to(dev)
+    pts = bench.volume_points(1)[:: max(1, 16384 // args.n)][: args.n]
+    if args.order == "shuffle":
+        pts = pts[torch.randperm(pts.shape[0], generator=torch.Generator().manual_seed(5))]
+    elif args.order == "same":
+        pts = pts[pts.shape[0] // 2 + 17].expand_as(pts)
+    pts = pts.contiguous().to(dev)
     po = lens._points_to_object(pts)
     g = torch.Generator().manual_seed(123)
     u = torch.rand(4, max(args.spp, 2048), generator=g).to(dev)
@@ -84,7 +92,7 @@ def main():
     torch.cuda.synchronize()
     sha = lambda t: hashlib.sha1(t.cpu().numpy().tobytes()).hexdigest()[:12]
     # L/R are sums of LDS float atomics: order-dependent in the last bits -> also print a robust digest
-    print(f"lib={os.path.basename(_lib.LIB_PATH)} N={N} spp={args.spp} ks={ks} "
+    print(f"lib={os.path.basename(_lib.LIB_PATH)} order={args.order} N={N} spp={args.spp} ks={ks} "
           f"center_ms={tcm:.3f} (min {tcmin:.3f}) psf_ms={tpm:.3f} (min {tpmin:.3f}) "
           f"total={tcm + tpm:.3f} cen_sha={sha(cen)} L_sum={L.double().sum().item():.6f} "
           f"R_sum={R.double().sum().item():.6f} mask={mask[:K].tolist()}")
