@@ -558,7 +558,7 @@ def bench_sweep(args, emit=True, lens=None):
             lens = build_lens(dev)
         pts_all = volume_points(1, "c2").to(dev)
         n_full = pts_all.shape[0]
-        steps = max(100, args.steps)
+        steps = max(60, args.steps)
         ks, spp = WORKLOADS["c2"]["ks"], WORKLOADS["c2"]["spp"]
         rows = {}
 
@@ -744,7 +744,7 @@ def also_block(args, lens, device):
     end (c5) -- five steps each -- and the strong-scaling compute side (shard_sweep: 50 steps per shard size)."""
     import copy
     q = copy.copy(args)
-    q.steps, q.warmup, q.sustain_seconds = 5, 2, 0.0
+    q.steps, q.warmup, q.sustain_seconds = 20, 2, 0.0
     out = {}
     # the staged chain's steps are 3 ms: warmed for ~0.1 s first -- the clock of a chip that has just been idle (set-up,
     # allocations) dips for some tens of ms shortly after work resumes (tools/clock_ramp.py), longer than five such steps
