@@ -1,12 +1,12 @@
 #!/bin/bash
 # Profiling recipe for `bench.py --workload staged` (run on the GPU box through gpurun):
-#   tools/profile_staged.sh <commit> [round-dir, default r04] [ks, default 65]
+#   tools/profile_staged.sh <commit> [round-dir, default r05] [ks, default 65]
 # Pass 1: kernel trace + stats.  Then PMC counters, each group in its own run (never trace domains together
 # with --pmc on this pool).  Output: gpurun_out/prof_<round>_staged/{trace,pmc_*}/, summary.json and the condensed
 # pmc_staged_ks<ks>.json (bench.py reads it from profiles/<round>/) (per kernel: rocprofv3 average duration, HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE as
 # MI355X_MICROARCH.md prescribes for gfx950, L2 hit rate).
 set -u
-COMMIT=${1:-unknown}; RND=${2:-r04}; KS=${3:-65}
+COMMIT=${1:-unknown}; RND=${2:-r05}; KS=${3:-65}
 OUT=gpurun_out/prof_${RND}_staged_ks${KS}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
