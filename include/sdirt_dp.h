@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SDIRT_ABI_VERSION 3
+#define SDIRT_ABI_VERSION 4
 #define SDIRT_MAX_SURFACES 64
 #define SDIRT_MAX_AI 8
 #define SDIRT_NEWTON_MAXITER 10 /* deeplens/surfaces.py:26 */
@@ -301,7 +301,23 @@ int sdirt_psf_lr_centered(const sdirt_lens* lens, const sdirt_lens* lens_center,
                           uint32_t flags, float* center /*dev [N,2], out*/,
                           int32_t* any_valid /*dev or NULL*/, float* l_psf /*dev [N,ks,ks]*/,
                           float* r_psf /*dev or NULL*/, uint32_t* conv_mask /*dev [K] or NULL*/,
-                          uint32_t* conv_mask_center /*dev [K] or NULL*/, void* stream);
+                          uint32_t* conv_mask_center /*dev [K] or NULL*/,
+                          void* tail_ws /*dev, sdirt_psf_tail_bytes(), or NULL*/, void* stream);
+
+/* The end of a launch.  A launch with one workgroup per point ends at falling occupancy: the last workgroups on every
+ * compute unit run with nothing younger beside them (0.13 ms of a config-2 launch whatever its length: 1.4 % of 16384
+ * points, 10 % of the 2048 points a rank of 8 renders; profiles/r05/launch_fixed_cost.txt).  With tail_ws != NULL
+ * sdirt_psf_lr_centered renders the LAST 4 x CUs points of such a launch in smaller units -- their chief-ray passes in the
+ * first blocks of the launch, their primary passes cut into <= 4 slices of spp in its last blocks; a slice leaves its
+ * partial tiles in tail_ws and the last slice of a point to finish adds them in slice order, normalises and stores --
+ * all inside the ONE kernel launch.  Chief-ray centres, rays and trip masks are the same; a tail point's grids are the
+ * sum of <= 4 partial sums (float64 partial sums rounded ONCE wherever the tiles are float64, ks <= 49: then the grids
+ * equal the unsplit call's up to float64 rounding; fp32 partial sums above).
+ * sdirt_psf_tail_bytes: device bytes such a launch needs (0: no tail for this shape -- fewer points than the chip holds
+ * workgroups, or too few samples to cut): 4 x CUs state words, then the partial tiles (138 MB for ks 65, L + R, on 256
+ * CUs).  The state words -- or simply the whole block -- are handed over ZEROED and come back zeroed: one block per
+ * stream serves every launch on that stream.  both: r_psf != NULL and dp != NULL.  n_cus as in sdirt_psf_spp_slices. */
+int64_t sdirt_psf_tail_bytes(int64_t n_points, int64_t spp, int32_t ks, int32_t both, int32_t n_cus);
 
 /* Lensgroup.psf_rgb, deeplens/optics.py:999-1015 (and psf_map, :1018-1041, on top of it), as ONE
  * kernel launch: n_wvln (<= SDIRT_MAX_WAVELENGTHS) independent psf_diff calls -- one lens table,

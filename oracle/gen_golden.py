@@ -12,12 +12,14 @@ No reference source text is stored, only numbers.
 Discipline: torch.set_num_threads(1); every case is generated
 twice and asserted bit-equal; the non-deterministic paraxial pupil
 (optics.py:1335-1376, lstsq on near-parallel lines: values drift run-to-run by
-~1e-5 relative (entrance) / ~2e-4 (exit) even single-threaded) is FROZEN at the
-values the committed tests/golden/lens_state_<lens>.json records, so that a
-fresh run reproduces every committed file byte for byte; the reference's fresh
-estimate is asserted to lie within its own run-to-run spread of the frozen one
-(oracle/ref_pupil_variation.py).  --refreeze draws new pupil values from the
-reference (once per lens) instead -- every fixture downstream then changes.
+~1e-5 relative (entrance) / ~2e-4 (exit) even single-threaded) -- and hfov,
+foclen and fnum, which the reference computes from fresh estimates -- are FROZEN
+at the values oracle/frozen_lens_scalars.json records (one run of the reference
+per lens, kept outside tests/golden/), so that a fresh run reproduces every
+committed file byte for byte; the reference's fresh values are asserted to lie
+within its own run-to-run spread of the frozen ones (oracle/ref_pupil_variation.py).
+--refreeze draws new values from the reference (once per lens) instead -- every
+fixture downstream then changes.
 
 Usage:  python oracle/gen_golden.py [--out tests/golden] [--refreeze]
 """
@@ -47,8 +49,50 @@ DP_DEFAULT = [0.78, 1.44, 0.3, 0.5]  # h, f, w, r  (monte_carlo.py:157-164)
 # lens construction with frozen pupil
 # --------------------------------------------------------------------------
 COMMITTED = os.path.join(HERE, "..", "tests", "golden")
-# the reference's estimator against itself, run to run (oracle/ref_pupil_variation.py; VERDICT r04: 2.0e-4 on the exit pupil)
-PUPIL_SPREAD = {"entrance": 1e-4, "exit": 1e-3}
+# One run of the reference per lens, kept OUTSIDE tests/golden/ (the fixtures are then reproduced FROM these numbers, not
+# from themselves); provenance and the reference's own run-to-run spread are recorded in the file.
+FROZEN_FILE = os.path.join(HERE, "frozen_lens_scalars.json")
+
+
+def frozen_scalars(name):
+    with open(FROZEN_FILE) as f:
+        d = json.load(f)
+    return d.get(name), d["_spread"]
+
+
+def freeze(lens, name, refreeze=False):
+    """Pin the run-to-run-unstable scalars of a reference lens (paraxial pupils, and hfov / foclen / fnum, which are
+    computed from fresh pupil estimates: optics.py:1193-1196, 1203-1230) at the values of oracle/frozen_lens_scalars.json,
+    after checking that this run's fresh values lie within the reference's own spread of them.  refreeze: record this
+    run's values as the new frozen ones instead."""
+    ent_z, ent_r = lens.calc_entrance_pupil_paraxial(entrance=True)
+    ext_z, ext_r = lens.calc_entrance_pupil_paraxial(entrance=False)
+    fresh = dict(pupil_z=float(ent_z), pupil_r=float(ent_r), exit_pupil_z=float(ext_z), exit_pupil_r=float(ext_r),
+                 hfov=float(lens.hfov), foclen=float(lens.foclen), fnum=float(lens.fnum))
+    st, spread = frozen_scalars(name)
+    if refreeze or st is None:
+        with open(FROZEN_FILE) as f:
+            d = json.load(f)
+        d[name] = st = fresh
+        with open(FROZEN_FILE, "w") as f:
+            json.dump(d, f, indent=1)
+        print(f"{name}: froze this run's scalars {fresh}")
+    tol = dict(pupil_z=spread["entrance"], pupil_r=spread["entrance"], exit_pupil_z=spread["exit"],
+               exit_pupil_r=spread["exit"], hfov=spread["hfov"], foclen=spread["foclen"], fnum=spread["fnum"])
+    for k, v in fresh.items():
+        assert abs(v / st[k] - 1) <= tol[k], \
+            f"{name}: the reference's fresh {k} = {v!r} is not within its run-to-run spread ({tol[k]:g}) of the frozen {st[k]!r}"
+    drift = {k: f"{fresh[k] / st[k] - 1:+.1e}" for k in fresh if fresh[k] != st[k]}
+    print(f"{name}: scalars frozen at oracle/frozen_lens_scalars.json (this run's relative drift: {drift or 'none'})")
+    lens.hfov, lens.foclen, lens.fnum = st["hfov"], st["foclen"], st["fnum"]
+
+    def frozen(M=32, entrance=True, shrink_pupil=False):
+        z, r = (st["pupil_z"], st["pupil_r"]) if entrance else (st["exit_pupil_z"], st["exit_pupil_r"])
+        if shrink_pupil:
+            r = r * 0.25                         # optics.py:1394-1395
+        return z, r
+    lens.entrance_pupil = frozen
+    return lens
 
 
 def build_lens(name, refreeze=False):
@@ -56,32 +100,7 @@ def build_lens(name, refreeze=False):
     lens = PSFNet(filename=f"/root/reference/lenses/{name}/lens_web.json",
                   sensor_res=(512, 768), kernel_size=21, device="cpu")
     lens.refocus(-1000 + lens.d_sensor)          # 1_fit_psfnet.py:23-25
-    ent_z, ent_r = lens.calc_entrance_pupil_paraxial(entrance=True)
-    ext_z, ext_r = lens.calc_entrance_pupil_paraxial(entrance=False)
-    frozen_file = os.path.join(COMMITTED, f"lens_state_{name}.json")
-    if not refreeze and os.path.exists(frozen_file):
-        with open(frozen_file) as f:
-            st = json.load(f)
-        for kind, fresh, kept in (("entrance", (ent_z, ent_r), (st["pupil_z"], st["pupil_r"])),
-                                  ("exit", (ext_z, ext_r), (st["exit_pupil_z"], st["exit_pupil_r"]))):
-            for a, b in zip(fresh, kept):
-                assert abs(a / b - 1) <= PUPIL_SPREAD[kind], \
-                    f"{name}: the reference's {kind} pupil {fresh} is not within its run-to-run spread of the frozen {kept}"
-        print(f"{name}: pupils frozen at the committed values (fresh estimate: entrance {ent_z:.6f} / {ent_r:.6f}, "
-              f"exit {ext_z:.6f} / {ext_r:.6f})")
-        ent_z, ent_r, ext_z, ext_r = st["pupil_z"], st["pupil_r"], st["exit_pupil_z"], st["exit_pupil_r"]
-        # fnum = foclen / (2 x the pupil radius of ANOTHER fresh estimate, optics.py:1193-1196): it inherits the
-        # estimator's spread (one run in ~12 lands 2.3e-5 off) and nothing on the hot path reads it -- frozen as well
-        assert abs(float(lens.fnum) / st["fnum"] - 1) <= PUPIL_SPREAD["entrance"], (name, float(lens.fnum), st["fnum"])
-        lens.fnum = st["fnum"]
-
-    def frozen(M=32, entrance=True, shrink_pupil=False):
-        z, r = (ent_z, ent_r) if entrance else (ext_z, ext_r)
-        if shrink_pupil:
-            r = r * 0.25                         # optics.py:1394-1395
-        return z, r
-    lens.entrance_pupil = frozen
-    return lens
+    return freeze(lens, name, refreeze)
 
 
 def lens_state(lens, wvlns):

@@ -97,18 +97,19 @@ def main():
     ap.add_argument("--out", default=os.path.join(HERE, "..", "tests", "golden"))
     args = ap.parse_args()
     rf50 = gg.build_lens("rf50mm")
-    # the paraxial pupil estimate drifts from process to process (an ill-conditioned fp32 lstsq,
-    # optics.py:1500): pin it to the values the committed fixtures were generated with
+    # (gen_golden.build_lens has frozen the run-to-run-unstable pupils at oracle/frozen_lens_scalars.json.)
+    # Prerequisites -- the lens state and fixture f8, both written by gen_golden.py -- from --out when this run's
+    # gen_golden.py wrote them there (check_regenerable.py: a clean directory, generators in order), else the committed ones
     import json
-    with open(os.path.join(args.out, "lens_state_rf50mm.json")) as f:
+
+    def prerequisite(name):
+        p = os.path.join(args.out, name)
+        return p if os.path.exists(p) else os.path.join(gg.COMMITTED, name)
+    with open(prerequisite("lens_state_rf50mm.json")) as f:
         st = json.load(f)
     assert st["d_sensor"] == float(rf50.d_sensor) and st["hfov"] == float(rf50.hfov)
-
-    def frozen(M=32, entrance=True, shrink_pupil=False):
-        z, r = (st["pupil_z"], st["pupil_r"]) if entrance else (st["exit_pupil_z"], st["exit_pupil_r"])
-        return z, (r * 0.25 if shrink_pupil else r)
-    rf50.entrance_pupil = frozen
-    f8 = np.load(os.path.join(args.out, "f8_rf50_mini_c2.npz"))
+    assert (st["pupil_z"], st["pupil_r"]) == tuple(rf50.entrance_pupil())
+    f8 = np.load(prerequisite("f8_rf50_mini_c2.npz"))
 
     def case():
         d = gg.run_psf_case(rf50, f8["points"].tolist(), ks=65, spp=4096, wvln=0.589, seed=8,
@@ -135,14 +136,10 @@ def main():
     # F20 = the same hand-off on rf35mm (21 surfaces, stop at index 7, an even asphere): 12 of the
     # 27 points, 4096 spp, ks 65, with the correctly-rounded-math re-run
     rf35 = gg.build_lens("rf35mm")
-    with open(os.path.join(args.out, "lens_state_rf35mm.json")) as f:
+    with open(prerequisite("lens_state_rf35mm.json")) as f:
         st35 = json.load(f)
     assert st35["d_sensor"] == float(rf35.d_sensor) and st35["hfov"] == float(rf35.hfov)
-
-    def frozen35(M=32, entrance=True, shrink_pupil=False):
-        z, r = (st35["pupil_z"], st35["pupil_r"]) if entrance else (st35["exit_pupil_z"], st35["exit_pupil_r"])
-        return z, (r * 0.25 if shrink_pupil else r)
-    rf35.entrance_pupil = frozen35
+    assert (st35["pupil_z"], st35["pupil_r"]) == tuple(rf35.entrance_pupil())
     pts35 = f8["points"][::2][:12].tolist()
 
     def case35():

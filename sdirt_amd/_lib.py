@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # SDIRT_AMD_LIB overrides the path (kernel-variant A/B runs in tools/kbench.py only)
 LIB_PATH = os.environ.get("SDIRT_AMD_LIB") or os.path.join(HERE, "libsdirt_dp.so")
 
-ABI_VERSION = 3          # SDIRT_ABI_VERSION of include/sdirt_dp.h this binding was written against
+ABI_VERSION = 4          # SDIRT_ABI_VERSION of include/sdirt_dp.h this binding was written against
 MAX_SURFACES = 64
 MAX_AI = 8
 NEWTON_MAXITER = 10
@@ -79,7 +79,8 @@ SIGNATURES = {
                                C.POINTER(DpParams), C.POINTER(_I32), _U32, _P, _P, _P, _P]),
     "sdirt_psf_lr_centered": (C.c_int, [_P, _P, _P, _I64, _P, _P, _I64, _P, _P, _I64, _D, _D, _D, _I32,
                                         C.POINTER(DpParams), C.POINTER(_I32), C.POINTER(_I32), _U32,
-                                        _P, _P, _P, _P, _P, _P, _P]),
+                                        _P, _P, _P, _P, _P, _P, _P, _P]),
+    "sdirt_psf_tail_bytes": (_I64, [_I64, _I64, _I32, _I32, _I32]),
     "sdirt_psf_rgb_centered": (C.c_int, [C.POINTER(_P), _I32, _P, _P, _I64, _P, _P, _I64, _P, _P, _I64, _D, _D, _D,
                                          _I32, C.POINTER(DpParams), C.POINTER(_I32), C.POINTER(_I32), _U32,
                                          _P, _P, _P, _P, _P, _P, _P]),

@@ -185,7 +185,7 @@ def test_library_exports_every_declared_symbol():
     h = _lib.lib()                                                # loads, or raises loudly
     for s in syms:
         assert hasattr(h, s), f"libsdirt_dp.so does not export {s}"
-    assert h.sdirt_abi_version() == 3
+    assert h.sdirt_abi_version() == 4
     # ... and nothing but them (no kernel stubs, no experiment hooks)
     import subprocess
     out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH], text=True)
