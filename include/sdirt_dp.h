@@ -128,6 +128,12 @@ typedef struct sdirt_dp_params {
  * dp != NULL, one wavelength.  A rank of a multi-GPU volume renders its shard straight into the block that ONE all-gather
  * moves (`[N/8, 2, ks, ks]`), and L = a[:, 0], R = a[:, 1] are views of the gathered array: no staging copy. */
 #define SDIRT_PSF_INTERLEAVED 32u
+/* sdirt_psf_call only: the call clears the control block itself (inside its pupil-mapping launch) -- for a caller that
+ * keeps ONE scratch block per in-flight step and reuses it step after step. */
+#define SDIRT_PSF_ZERO_CTL 64u
+/* sdirt_psf_call only (one workgroup per point): leave the trip rule unevaluated -- the masks of a rank of a sharded
+ * batch say nothing before they are OR-ed with the other ranks' (sdirt_ctl_to_lanes, all-reduce, sdirt_ctl_from_lanes). */
+#define SDIRT_PSF_NO_VERIFY 128u /* (needs SDIRT_PSF_ZERO_CTL) */
 
 /* ---- library ------------------------------------------------------------ */
 int sdirt_abi_version(void);
@@ -301,23 +307,7 @@ int sdirt_psf_lr_centered(const sdirt_lens* lens, const sdirt_lens* lens_center,
                           uint32_t flags, float* center /*dev [N,2], out*/,
                           int32_t* any_valid /*dev or NULL*/, float* l_psf /*dev [N,ks,ks]*/,
                           float* r_psf /*dev or NULL*/, uint32_t* conv_mask /*dev [K] or NULL*/,
-                          uint32_t* conv_mask_center /*dev [K] or NULL*/,
-                          void* tail_ws /*dev, sdirt_psf_tail_bytes(), or NULL*/, void* stream);
-
-/* The end of a launch.  A launch with one workgroup per point ends at falling occupancy: the last workgroups on every
- * compute unit run with nothing younger beside them (0.13 ms of a config-2 launch whatever its length: 1.4 % of 16384
- * points, 10 % of the 2048 points a rank of 8 renders; profiles/r05/launch_fixed_cost.txt).  With tail_ws != NULL
- * sdirt_psf_lr_centered renders the LAST 4 x CUs points of such a launch in smaller units -- their chief-ray passes in the
- * first blocks of the launch, their primary passes cut into <= 4 slices of spp in its last blocks; a slice leaves its
- * partial tiles in tail_ws and the last slice of a point to finish adds them in slice order, normalises and stores --
- * all inside the ONE kernel launch.  Chief-ray centres, rays and trip masks are the same; a tail point's grids are the
- * sum of <= 4 partial sums (float64 partial sums rounded ONCE wherever the tiles are float64, ks <= 49: then the grids
- * equal the unsplit call's up to float64 rounding; fp32 partial sums above).
- * sdirt_psf_tail_bytes: device bytes such a launch needs (0: no tail for this shape -- fewer points than the chip holds
- * workgroups, or too few samples to cut): 4 x CUs state words, then the partial tiles (138 MB for ks 65, L + R, on 256
- * CUs).  The state words -- or simply the whole block -- are handed over ZEROED and come back zeroed: one block per
- * stream serves every launch on that stream.  both: r_psf != NULL and dp != NULL.  n_cus as in sdirt_psf_spp_slices. */
-int64_t sdirt_psf_tail_bytes(int64_t n_points, int64_t spp, int32_t ks, int32_t both, int32_t n_cus);
+                          uint32_t* conv_mask_center /*dev [K] or NULL*/, void* stream);
 
 /* Lensgroup.psf_rgb, deeplens/optics.py:999-1015 (and psf_map, :1018-1041, on top of it), as ONE
  * kernel launch: n_wvln (<= SDIRT_MAX_WAVELENGTHS) independent psf_diff calls -- one lens table,
@@ -365,6 +355,9 @@ int32_t sdirt_psf_spp_slices(int64_t n_points, int64_t spp, int32_t n_cus);
 #define SDIRT_CTL_STATUS 0     /* 0: the speculated tables were the reference's (round 2 did nothing);       */
                                /* else bit 0 | bit 1 (primary table corrected) | bit 2 (chief-ray table corrected) */
 #define SDIRT_CTL_ANY_VALID 1  /* 1 if any chief ray reached the sensor (optics.py:902)                      */
+#define SDIRT_CTL_UNIFORM_SUM 2 /* sdirt_psf_call with SDIRT_PSF_NO_VERIFY: sum of the uniforms' bit patterns (30 bits), */
+                               /* word 3 its complement to 0x3fffffff: ranks that all drew the same numbers read, after */
+                               /* the MAX-reduction of sdirt_ctl_to_lanes / _from_lanes, two words that still add up      */
 #define SDIRT_CTL_TRIPS2 16    /* 16 + 16 words: the tables round 2 ran, one signed byte per surface         */
 #define SDIRT_CTL_MASKS 64     /* 4 x 64 words: convergence masks of round 1 (primary, chief), round 2 (same) */
 #define SDIRT_CTL_WORDS 320
@@ -392,14 +385,22 @@ int sdirt_psf_lr_verified(const sdirt_lens* lens, const sdirt_lens* lens_center,
                           float* center /*dev [N,2], out*/, float* l_psf /*dev [N,ks,ks]*/,
                           float* r_psf /*dev or NULL*/, void* scratch /*dev*/, void* stream);
 
-/* One whole psf call of the fitting shape enqueued by ONE library call (a Python caller pays per call
- * into the library, and this shape is launch-latency-bound): upload the 2 * spp + 2 * spp_center
- * uniforms the caller drew (u_host, page-locked, in the reference's draw order -- theta[spp], r2[spp] of
- * Lensgroup.sample_from_points, optics.py:483-484, then theta[spp_center], r2[spp_center] of the same lines
- * inside psf_center, optics.py:898), map them onto the pupil and the shrunk pupil (sdirt_pupil_samples),
- * run sdirt_psf_lr_verified, and copy the control block to ctl_host (page-locked, SDIRT_CTL_WORDS words).
- * The caller synchronises the stream and reads ctl_host.  scratch: dev, 8-byte aligned,
- * sdirt_psf_call_scratch_bytes(n_points, spp, spp_center) bytes, the first SDIRT_CTL_WORDS words zeroed. */
+/* One whole psf call enqueued by ONE library call (a Python caller pays per call into the library; a C caller needs
+ * nothing else): upload the 2 * spp + 2 * spp_center uniforms the caller drew (u_host, page-locked, in the reference's
+ * draw order -- theta[spp], r2[spp] of Lensgroup.sample_from_points, optics.py:483-484, then theta[spp_center],
+ * r2[spp_center] of the same lines inside psf_center, optics.py:898), map them onto the pupil and the shrunk pupil, render
+ * with the speculated tables, evaluate the reference's batch-wide trip rule ON THE DEVICE, and copy the control block to
+ * ctl_host (page-locked, SDIRT_CTL_WORDS words; NULL: no copy).  The caller synchronises the stream and reads ctl_host:
+ *   - few points with many samples (sdirt_psf_spp_slices > 1): sdirt_psf_lr_verified -- a wrong table has already been
+ *     corrected and re-rendered behind round 1 (unless SDIRT_PSF_ONE_ROUND);
+ *   - one workgroup per point (sdirt_psf_spp_slices == 1; any batch from one point to a whole volume): ONE fused launch;
+ *     SDIRT_CTL_STATUS != 0 means the tables were not the reference's for this batch: call again with the tables in
+ *     SDIRT_CTL_TRIPS2 (one signed byte per surface: primary at word 16, chief-ray at word 32) until the status is 0 --
+ *     a table speculated from above (10 trips on curved surfaces, what NULL-free first calls should pass) is corrected
+ *     exactly in one round.  No host-side rule is needed: tests/c_client/psf_client.c renders fixture F1 this way.
+ * scratch: dev, 8-byte aligned, sdirt_psf_call_scratch_bytes(n_points, spp, spp_center) bytes: [control block | chief-ray
+ * partial sums | uniforms | pupil points x2, y2, xc, yc]; its first SDIRT_CTL_WORDS words zeroed by the caller, or by
+ * the call itself under SDIRT_PSF_ZERO_CTL. */
 int64_t sdirt_psf_call_scratch_bytes(int64_t n_points, int64_t spp, int64_t spp_center);
 int sdirt_psf_call(const sdirt_lens* lens, const sdirt_lens* lens_center, const float* point_obj /*dev [N,3]*/,
                    int64_t n_points, const float* u_host /*host, page-locked*/, int64_t spp, int64_t spp_center,
@@ -407,7 +408,20 @@ int sdirt_psf_call(const sdirt_lens* lens, const sdirt_lens* lens_center, const 
                    const sdirt_dp_params* dp /*host or NULL*/, const int32_t* trips /*host [K]*/,
                    const int32_t* trips_center /*host [K]*/, uint32_t flags, float* center /*dev [N,2], out*/,
                    float* l_psf /*dev [N,ks,ks]*/, float* r_psf /*dev or NULL*/, void* scratch /*dev*/,
-                   uint32_t* ctl_host /*host, page-locked, out*/, void* stream);
+                   uint32_t* ctl_host /*host, page-locked, out, or NULL*/, void* stream);
+
+/* A batch sharded over ranks: the reference's trip rule is batch-wide, so the ranks' masks are OR-ed
+ * before it is evaluated.  RCCL has no bitwise OR: sdirt_ctl_to_lanes spreads round 1's masks and the any-valid flag of
+ * a control block (sdirt_psf_call with SDIRT_PSF_NO_VERIFY) into SDIRT_CTL_LANES int32 lanes -- 0 / 1 lanes [primary |
+ * chief-ray][SDIRT_MAX_SURFACES][bit 0..10], the flag, then the two SDIRT_CTL_UNIFORM_SUM words as they are --, the caller all-reduces them with MAX, and
+ * sdirt_ctl_from_lanes folds them back into the control block, evaluates the rule there (lens != NULL: status word and
+ * corrected tables as sdirt_psf_call leaves them; trips / trips_center = the tables that ran) and copies the block to
+ * ctl_host (page-locked, or NULL).  Every rank then reads the same status.  Device pointers + stream, no allocation. */
+#define SDIRT_CTL_LANES 1411   /* 2 * SDIRT_MAX_SURFACES * (SDIRT_NEWTON_MAXITER + 1) + 3 */
+int sdirt_ctl_to_lanes(const uint32_t* ctl /*dev*/, int32_t* lanes /*dev [SDIRT_CTL_LANES], out*/, void* stream);
+int sdirt_ctl_from_lanes(const int32_t* lanes /*dev*/, const sdirt_lens* lens /*or NULL: masks only*/,
+                         const int32_t* trips /*host [K]*/, const int32_t* trips_center /*host [K]*/,
+                         uint32_t* ctl /*dev, in/out*/, uint32_t* ctl_host /*host, page-locked, out, or NULL*/, void* stream);
 
 /* ---- host side: the reference's random stream ------------------------------ */
 

@@ -23,7 +23,11 @@ PSF_STRICT_IEEE = 4
 TRACE_NO_PREFETCH = 8
 PSF_ONE_ROUND = 16
 PSF_INTERLEAVED = 32
+PSF_ZERO_CTL = 64
+PSF_NO_VERIFY = 128
 CTL_STATUS, CTL_ANY_VALID, CTL_TRIPS2, CTL_MASKS, CTL_WORDS = 0, 1, 16, 64, 320
+CTL_LANES = 1411
+CTL_UNIFORM_SUM = 2
 
 KIND_PLANE, KIND_SPHERE, KIND_ASPHERE = 0, 1, 2
 
@@ -79,8 +83,7 @@ SIGNATURES = {
                                C.POINTER(DpParams), C.POINTER(_I32), _U32, _P, _P, _P, _P]),
     "sdirt_psf_lr_centered": (C.c_int, [_P, _P, _P, _I64, _P, _P, _I64, _P, _P, _I64, _D, _D, _D, _I32,
                                         C.POINTER(DpParams), C.POINTER(_I32), C.POINTER(_I32), _U32,
-                                        _P, _P, _P, _P, _P, _P, _P, _P]),
-    "sdirt_psf_tail_bytes": (_I64, [_I64, _I64, _I32, _I32, _I32]),
+                                        _P, _P, _P, _P, _P, _P, _P]),
     "sdirt_psf_rgb_centered": (C.c_int, [C.POINTER(_P), _I32, _P, _P, _I64, _P, _P, _I64, _P, _P, _I64, _D, _D, _D,
                                          _I32, C.POINTER(DpParams), C.POINTER(_I32), C.POINTER(_I32), _U32,
                                          _P, _P, _P, _P, _P, _P, _P]),
@@ -94,6 +97,8 @@ SIGNATURES = {
     "sdirt_psf_call_scratch_bytes": (_I64, [_I64, _I64, _I64]),
     "sdirt_psf_call": (C.c_int, [_P, _P, _P, _I64, _P, _I64, _I64, _D, _D, _D, _D, _D, _I32, C.POINTER(DpParams),
                                  C.POINTER(_I32), C.POINTER(_I32), _U32, _P, _P, _P, _P, _P, _P]),
+    "sdirt_ctl_to_lanes": (C.c_int, [_P, _P, _P]),
+    "sdirt_ctl_from_lanes": (C.c_int, [_P, _P, C.POINTER(_I32), C.POINTER(_I32), _P, _P, _P]),
     "sdirt_host_uniform_fill": (C.c_int, [_P, _I64, _I64, _P]),
     "sdirt_selftest_math": (C.c_int, [_I32, C.c_uint64, C.c_uint64, _I32, _P, _P]),
     "sdirt_local_psf_render": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P, _P]),

@@ -265,6 +265,29 @@ __global__ void __launch_bounds__(kBlock) k_psf_normalize(float* __restrict__ ps
 // fused kernels
 // ---------------------------------------------------------------------------
 
+// The END of a launch with one workgroup per point.  The SIMDs serve the OLDEST wave first, so of the four workgroups that
+// share a CU the oldest runs ahead and the youngest is left to finish alone, at 2 waves per SIMD (0.6-0.8 of the 8-wave
+// rate of these kernels) -- in the middle of a launch a younger workgroup takes the freed slot, at its end nobody does:
+// 0.13 ms per launch of k_psf_lr whatever its length (profiles/r05/launch_fixed_cost.txt).  Workgroups of the LAST
+// generation (the last 4 x CUs blocks: `prio_from`) therefore set their waves' issue priority -- s_setprio, which ranks
+// above age -- by the passes they still have to run, one level per kPrioStep passes: whoever is behind is served first
+// and the workgroups of a CU finish together.  A scheduling hint only: the results are the same bit for bit.
+// Measured (profiles/r06/prio_ab_levels*.txt, same box, warm): config 2 cut to 1024 / 2048 / 4096 / 16384 points
+// 0.670 / 1.233 / 2.348 / 9.02 ms -> 0.596 / 1.164 / 2.275 / 8.93; one level per 1 or 3 passes, per quarter of the work, a
+// constant priority for the older generations, two generations, every workgroup: all behind.  Cutting the last
+// generation into smaller work units on top of it (slices of spp whose partial tiles the last slice to arrive adds up:
+// commit acacd51, profiles/r06/tail_ab_*.txt) never added anything: what such a slice saves at the end of the launch it
+// pays at its own start and end.
+constexpr int kPrioStep = 2;
+__device__ __forceinline__ void prio_by_work_left(int passes_left)
+{
+    const int q = (passes_left - 1) / kPrioStep;        // 3+: seven or more passes to go ... 0: the last two
+    if (q >= 3) __builtin_amdgcn_s_setprio(3);
+    else if (q == 2) __builtin_amdgcn_s_setprio(2);
+    else if (q == 1) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
+}
+
 // psf_center: one workgroup per point, Sc rays, fp64 partial sums reduced in a
 // fixed order (deterministic).
 template <class HotMath>
@@ -273,19 +296,22 @@ k_chief_center(TripTable trips /* kernarg offset 0 */, const DevSurface* __restr
                const float* __restrict__ po, const float* __restrict__ xc,
                const float* __restrict__ yc, int Sc, float pz, float zs,
                float* __restrict__ center, int32_t* __restrict__ any_valid,
-               uint32_t* __restrict__ conv_mask)
+               uint32_t* __restrict__ conv_mask, int prio_from)
 {
     __shared__ uint32_t lds_mask[SDIRT_MAX_SURFACES];
     __shared__ double red[3][kFused];
     __shared__ int red_any;
     const int n = blockIdx.x;
+    const bool by_work_left = (int)blockIdx.x >= prio_from;
+    const int passes = (Sc + kFused - 1) / kFused;
     if (threadIdx.x < SDIRT_MAX_SURFACES) lds_mask[threadIdx.x] = 0;
     if (threadIdx.x == 0) red_any = 0;
     __syncthreads();
     const float px = po[3 * n], py = po[3 * n + 1], pzo = po[3 * n + 2];
     double sx = 0.0, sy = 0.0, sr = 0.0;
     int any = 0;
-    for (int s = threadIdx.x; s < Sc; s += blockDim.x) {
+    for (int s = threadIdx.x, pass = 0; s < Sc; s += blockDim.x, ++pass) {
+        if (by_work_left) prio_by_work_left(passes - pass);
         Ray r = make_ray<HotMath>(px, py, pzo, xc[s], yc[s], pz);
         trace_ray<true, HotMath>(lens, 0, K, kernarg_at(0), r, conv_mask ? lds_mask : nullptr);
         propagate_to<HotMath>(r, zs);
@@ -294,6 +320,7 @@ k_chief_center(TripTable trips /* kernarg offset 0 */, const DevSurface* __restr
         sr += (double)r.ra;
         any |= (r.ra == 1.0f);
     }
+    if (by_work_left) __builtin_amdgcn_s_setprio(0);
     red[0][threadIdx.x] = sx; red[1][threadIdx.x] = sy; red[2][threadIdx.x] = sr;
     if (any) red_any = 1;
     __syncthreads();
@@ -424,6 +451,76 @@ __device__ bool verify_trips(const TripTable& t, const uint32_t* __restrict__ ma
     return !failed;
 }
 
+// sdirt_psf_call's prologue as ONE launch: both pupil mappings of a psf call (u = [theta | r2 | theta_c | r2_c] ->
+// xy = [x2 | y2 | xc | yc], sdirt_pupil_samples twice) and, on request, the clearing of the control block.
+// `sum` != nullptr: the first workgroup also leaves the sum of the uniforms' bit patterns (30 bits) and its complement
+// in sum[0], sum[1] -- what the ranks of a sharded batch compare to be sure they all drew the same numbers.
+__global__ void __launch_bounds__(kBlock) k_pupil_pair(const float* __restrict__ u, int S, int Sc, float pr2, float pr2c,
+                                                       float* __restrict__ xy, uint32_t* __restrict__ zero, int nzero,
+                                                       uint32_t* __restrict__ sum)
+{
+    __shared__ uint32_t part[kBlock];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nzero) zero[i] = 0u;
+    if (i < S) pupil_point(u[i], u[S + i], pr2, xy[i], xy[S + i]);
+    else if (i < S + Sc) {
+        const int c = i - S;
+        pupil_point(u[2 * S + c], u[2 * S + Sc + c], pr2c, xy[2 * S + c], xy[2 * S + Sc + c]);
+    }
+    if (sum && blockIdx.x == 0) {
+        uint32_t acc = 0u;
+        for (int q = threadIdx.x; q < 2 * (S + Sc); q += blockDim.x) acc += __float_as_uint(u[q]);
+        part[threadIdx.x] = acc;
+        __syncthreads();                                           // (also orders the clearing above before the two stores)
+        for (int off = kBlock / 2; off > 0; off >>= 1) {
+            if ((int)threadIdx.x < off) part[threadIdx.x] += part[threadIdx.x + off];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) { sum[0] = part[0] & 0x3fffffffu; sum[1] = 0x3fffffffu - (part[0] & 0x3fffffffu); }
+    }
+}
+
+// The trip rule on the device for a call with one workgroup per point (sdirt_psf_call): round 1's masks stand in the
+// control block; status and the tables a correction would run go beside them.  One thread.
+__global__ void k_ctl_verify(uint32_t* __restrict__ ctl, const DevSurface* __restrict__ lens, int K, TripTable tp, TripTable tc)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const bool okp = verify_trips(tp, ctl + kCtlMask1P, lens, K, ctl + kCtlTrips2P);
+    const bool okc = verify_trips(tc, ctl + kCtlMask1C, lens, K, ctl + kCtlTrips2C);
+    ctl[kCtlStatus] = (okp && okc) ? 0u : (1u | (okp ? 0u : 2u) | (okc ? 0u : 4u));
+}
+
+// Round 1's masks and the any-valid flag of a control block as 0 / 1 lanes -- [primary | chief][surface][bit 0..10],
+// then the flag -- so that ranks can OR them with an all-reduce(MAX) (RCCL has no bitwise OR), and back.
+constexpr int kLaneBits = SDIRT_NEWTON_MAXITER + 1;
+constexpr int kMaskLanes = 2 * SDIRT_MAX_SURFACES * kLaneBits;       // then: any-valid, uniform sum, its complement
+static_assert(kMaskLanes + 3 == SDIRT_CTL_LANES, "lane layout");
+__global__ void __launch_bounds__(kBlock) k_ctl_to_lanes(const uint32_t* __restrict__ ctl, int32_t* __restrict__ lanes)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= SDIRT_CTL_LANES) return;
+    if (i == kMaskLanes) { lanes[i] = ctl[kCtlAnyValid] != 0u; return; }
+    if (i > kMaskLanes) { lanes[i] = (int32_t)ctl[SDIRT_CTL_UNIFORM_SUM + (i - kMaskLanes - 1)]; return; }
+    const int word = i / kLaneBits, bit = i - word * kLaneBits;      // word: 0..63 primary, 64..127 chief
+    lanes[i] = (int32_t)((ctl[kCtlMask1P + word] >> bit) & 1u);
+}
+__global__ void __launch_bounds__(2 * SDIRT_MAX_SURFACES) k_ctl_from_lanes(const int32_t* __restrict__ lanes, uint32_t* __restrict__ ctl,
+                                                                         const DevSurface* __restrict__ lens, int K, TripTable tp, TripTable tc)
+{
+    const int word = threadIdx.x;                                    // 128 threads, one mask word each
+    uint32_t m = 0u;
+    for (int b = 0; b < kLaneBits; ++b) m |= (lanes[word * kLaneBits + b] != 0 ? 1u : 0u) << b;
+    ctl[kCtlMask1P + word] = m;
+    if (word == 0) ctl[kCtlAnyValid] = lanes[kMaskLanes] != 0 ? 1u : 0u;
+    if (word == 1 || word == 2) ctl[SDIRT_CTL_UNIFORM_SUM + word - 1] = (uint32_t)lanes[kMaskLanes + word];
+    __syncthreads();
+    if (word == 0 && lens) {
+        const bool okp = verify_trips(tp, ctl + kCtlMask1P, lens, K, ctl + kCtlTrips2P);
+        const bool okc = verify_trips(tc, ctl + kCtlMask1C, lens, K, ctl + kCtlTrips2C);
+        ctl[kCtlStatus] = (okp && okc) ? 0u : (1u | (okp ? 0u : 2u) | (okc ? 0u : 4u));
+    }
+}
+
 // Last kernel of a round of the split path: max-normalise L (blockIdx.y 0) and R (1), and -- round 1
 // -- check both trip tables against the masks the round produced: status 0 = the reference's tables,
 // nothing more to do; else bit 0 set (bit 1: primary table wrong, bit 2: chief-ray table wrong) and
@@ -488,67 +585,6 @@ struct LensSet {
 struct TripSet {
     TripTable t[SDIRT_MAX_WAVELENGTHS];
 };
-// The end of a launch (CENTER instantiations, one wavelength): the last workgroups of a launch run out at falling
-// occupancy with nothing younger to fill in (0.2-0.35 of a workgroup's life per launch, profiles/r05/launch_fixed_cost.txt),
-// so the LAST n_tail points are rendered by smaller work units.  Block order of such a launch:
-//   [0, n_tail)                    chief-ray pass of tail point t alone: centre -> center_out
-//   [n_tail, n_tail + n_bulk)      points [0, n_bulk): chief-ray pass + primary pass + store, as ever
-//   [n_tail + n_bulk, ... + n_tail * K)  slice j of tail point t: `chunk` primary samples; the partial tiles go to
-//                                  part[t][j] (plain coalesced stores, in the tiles' own accumulator type); the LAST slice
-//                                  of a point to arrive adds the K partial tiles in slice order -- a fixed order, its own
-//                                  share straight from LDS --, normalises and stores the grids
-// (Adding the shares to the output with global float atomics -- how the few-point split path combines -- cost 1.1 ms per
-// 1024 tail points x 4 slices at ks 65: 31 G atomics/s across eight L2s; profiles/r06/tail_ab_first.txt.)
-// state[t] (zero before the launch, zero after it): 0 nobody has started the point's chief-ray pass, 1 somebody is at
-// it, 2 centre written, 2 + i: i slices have delivered.  A slice that finds 0 (its chief-ray block has not been
-// dispatched yet -- never observed, the hardware hands out blocks in order) takes the pass over itself, so a block only
-// ever waits for a block that is RUNNING: no assumption on the dispatch order.
-// Everything one workgroup hands to another -- the centre, the partial tiles, the state word -- moves through
-// AGENT-SCOPE ATOMIC accesses (tail_put / tail_get: write-through stores and cache-bypassing loads, coherent at the memory
-// side across the eight XCDs' L2s), ordered by program order: a producer waits for its data stores (s_waitcnt, inside
-// the workgroup-scope release) before it touches the state word, a consumer issues its data loads after the state word's
-// value has come back.  No agent-scope fence: each one writes an XCD's whole L2 back or invalidates it, and 4096 slices
-// doing that cost the launch more than the tail saves (profiles/r06/tail_ab_second.txt, tail_ab_third.txt).
-__device__ __forceinline__ void tail_put(float* p, float v)
-{
-    __hip_atomic_store(reinterpret_cast<uint32_t*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void tail_put(double* p, double v)
-{
-    __hip_atomic_store(reinterpret_cast<uint64_t*>(p), (uint64_t)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ float tail_get(const float* p)
-{
-    return __uint_as_float(__hip_atomic_load(reinterpret_cast<const uint32_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-}
-__device__ __forceinline__ double tail_get(const double* p)
-{
-    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const uint64_t*>(p), __ATOMIC_RELAXED,
-                                                             __HIP_MEMORY_SCOPE_AGENT));
-}
-struct TailArgs {
-    uint32_t* state;   // [n_tail], or nullptr: every point one workgroup
-    void* part;        // [n_tail][K][L | R tile] of ACC
-    int n_bulk, n_tail, K, chunk;
-    int prio_from;     // blocks from this index on (the last generation of the launch) issue by work left, see below
-};
-// The SIMDs serve the OLDEST wave first, so of the workgroups that share a CU the oldest runs ahead and the youngest is
-// left to finish alone, at 2 waves per SIMD (0.6-0.8 of the kernel's 8-wave rate) -- in the middle of a launch a younger
-// workgroup takes the freed slot, at its end nobody does.  Workgroups of the LAST generation therefore set their waves'
-// issue priority (s_setprio, which ranks above age) by the quarter of their work that is still to do: whoever is behind
-// is served first, the workgroups of a CU finish together.  A scheduling hint only: results are the same bit for bit.
-constexpr int kPrioLastGenerations = 1;      // 0: never; a large number: every workgroup
-constexpr int kPrioElse = 0;                 // issue priority of the workgroups before the last generation
-constexpr int kPrioOffset = 0;
-constexpr int kPrioStep = 2;                 // passes per priority level (0: quarters of a whole-point workgroup's passes)
-__device__ __forceinline__ void prio_by_work_left(int left, int total)
-{
-    const int q = kPrioStep > 0 ? (left - 1 + kPrioOffset) / kPrioStep + 1 : (4 * left + total - 1) / total;   // 4+: top ... 1: the last step
-    if (q >= 4) __builtin_amdgcn_s_setprio(3);
-    else if (q == 3) __builtin_amdgcn_s_setprio(2);
-    else if (q == 2) __builtin_amdgcn_s_setprio(1);
-    else __builtin_amdgcn_s_setprio(0);
-}
 // ACC = the accumulator type of the LDS tiles.  float: ds_add_f32, which gfx950 executes lane by lane (~193 cycles
 // of the CU's LDS per wave instruction whatever the addresses, profiles/r04/lds_atomic_bench.txt); double:
 // ds_add_f64 (17-33 cycles), the sum rounded to fp32 once on the way out like k_forward_integral_tiles -- chosen by
@@ -559,7 +595,7 @@ k_psf_lr(SplatBlock sb /* kernarg offset 0 */, TripSet trips /* 64 */, TripSet t
          LensSet lens_set, int K, const float* __restrict__ po, const float* __restrict__ x2,
          const float* __restrict__ y2, int S, int nsplit, int chunk, float pz, float zs, int ks, int pstride, float tr,
          float tl, const float* __restrict__ center, uint32_t flags, float* __restrict__ lout,
-         float* __restrict__ rout, uint32_t* __restrict__ conv_mask, CenterArgs ca, SplitArgs sa, TailArgs ta)
+         float* __restrict__ rout, uint32_t* __restrict__ conv_mask, CenterArgs ca, SplitArgs sa, int prio_from)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char tiles_raw[];
     ACC* __restrict__ tiles = reinterpret_cast<ACC*>(tiles_raw);    // [L | R] ks*ks each
@@ -570,32 +606,14 @@ k_psf_lr(SplatBlock sb /* kernarg offset 0 */, TripSet trips /* 64 */, TripSet t
     const int tile = ks * ks;
     ACC* tl_ = tiles;
     ACC* trr = tiles + tile;
-    const int chunk_arg = chunk;
-    int n = blockIdx.x / nsplit;
-    int j = blockIdx.x - n * nsplit;
+    const int n = blockIdx.x / nsplit;
+    const int j = blockIdx.x - n * nsplit;
     const int w = blockIdx.y;
-    int N = gridDim.x / nsplit;
-    // role of this workgroup in a launch with a finely cut tail (TailArgs): 0 = a whole point, 1 = the chief-ray pass of
-    // tail point `tpt`, 2 = slice j of its primary pass
-    int role = 0, tpt = 0;
-    if (CENTER && ta.state) {
-        const int b = blockIdx.x;
-        N = ta.n_bulk + ta.n_tail;
-        j = 0;
-        if (b < ta.n_tail) { role = 1; tpt = b; n = ta.n_bulk + b; }
-        else if (b < ta.n_tail + ta.n_bulk) { n = b - ta.n_tail; }
-        else {
-            const int q = b - ta.n_tail - ta.n_bulk;
-            role = 2; tpt = q / ta.K; j = q - tpt * ta.K; n = ta.n_bulk + tpt; chunk = ta.chunk;
-        }
-    }
-    // passes of this workgroup over its samples: chief-ray pass (when it runs here), primary pass
-    const bool by_work_left = (int)blockIdx.x >= ta.prio_from;
-    const int passes_p = role == 1 ? 0 : (min(S, (j + 1) * chunk) - j * chunk + kFused - 1) / kFused;
-    const int passes_c = (CENTER && role != 2) ? (ca.Sc + kFused - 1) / kFused : 0;
-    // the yardstick: the passes of a workgroup that renders a whole point (a slice of a tail point starts lower)
-    const int passes_wg = (CENTER ? (ca.Sc + kFused - 1) / kFused : 0) + (min(S, chunk_arg) + kFused - 1) / kFused;
-    if (kPrioElse > 0 && !by_work_left) __builtin_amdgcn_s_setprio(kPrioElse);
+    const int N = gridDim.x / nsplit;
+    // the last generation of the launch issues by the passes a workgroup still has to run (prio_by_work_left)
+    const bool by_work_left = (int)(blockIdx.y * gridDim.x + blockIdx.x) >= prio_from;
+    const int passes_p = (min(S, (j + 1) * chunk) - j * chunk + kFused - 1) / kFused;
+    const int passes_c = CENTER ? (ca.Sc + kFused - 1) / kFused : 0;
     const DevSurface* __restrict__ lens = lens_set.p[w];
     constexpr int kTripsAt = 64, kTripsCAt = 64 + 64 * SDIRT_MAX_WAVELENGTHS;
     x2 += (int64_t)w * S; y2 += (int64_t)w * S;
@@ -610,22 +628,7 @@ k_psf_lr(SplatBlock sb /* kernarg offset 0 */, TripSet trips /* 64 */, TripSet t
     }
     const float px = po[3 * n], py = po[3 * n + 1], pzo = po[3 * n + 2];
 
-    bool chief = CENTER;
-    if (CENTER && role != 0) {
-        // a tail point: whoever moves state 0 -> 1 runs the point's chief-ray pass (block `tpt`, unless a slice got here first)
-        if (threadIdx.x == 0) {
-            uint32_t expect = 0u;
-            __hip_atomic_compare_exchange_strong(&ta.state[tpt], &expect, 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                 __HIP_MEMORY_SCOPE_AGENT);
-            c_sh[0] = __uint_as_float(expect);
-        }
-        __syncthreads();
-        const uint32_t was = __float_as_uint(c_sh[0]);
-        __syncthreads();
-        if (role == 1 && was != 0u) return;
-        chief = was == 0u;
-    }
-    if (CENTER && chief) {
+    if (CENTER) {
         // ---- chief-ray centre of this point (same arithmetic and reduction order as
         // k_chief_center; the fp64 scratch aliases the not-yet-used tile memory)
         double* redd = reinterpret_cast<double*>(tiles_raw);         // [3][kFused]
@@ -635,7 +638,7 @@ k_psf_lr(SplatBlock sb /* kernarg offset 0 */, TripSet trips /* 64 */, TripSet t
         double sx = 0.0, sy = 0.0, sr = 0.0;
         int any = 0;
         for (int s = threadIdx.x, pass = 0; s < ca.Sc; s += blockDim.x, ++pass) {
-            if (by_work_left) prio_by_work_left(passes_c + passes_p - pass, passes_wg);
+            if (by_work_left) prio_by_work_left(passes_c + passes_p - pass);
             Ray r = make_ray<HotMath>(px, py, pzo, ca.xc[s], ca.yc[s], pz);
             trace_ray<true, HotMath>(ca.lens_c, 0, K, kernarg_at(kTripsCAt + 64 * w), r,
                                      ca.conv_mask_c ? lds_mask : nullptr);
@@ -663,27 +666,9 @@ k_psf_lr(SplatBlock sb /* kernarg offset 0 */, TripSet trips /* 64 */, TripSet t
         const float ccx = -((float)redd[0] / den), ccy = -((float)redd[kFused] / den);
         __syncthreads();                                             // everyone has read redd / c_sh
         if (threadIdx.x == 0) {
-            if (role == 0) {
-                ca.center_out[2 * n] = ccx; ca.center_out[2 * n + 1] = ccy;
-            } else {
-                // a tail point: publish the centre to its slices (see TailArgs on the ordering)
-                tail_put(ca.center_out + 2 * n, ccx); tail_put(ca.center_out + 2 * n + 1, ccy);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                __hip_atomic_store(&ta.state[tpt], 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            ca.center_out[2 * n] = ccx; ca.center_out[2 * n + 1] = ccy;
             c_sh[0] = ccx; c_sh[1] = ccy;
             if (ca.any_valid && any_f != 0.0f) atomicOr(ca.any_valid, 1);
-        }
-    }
-    if (CENTER && role != 0) {
-        if (chief) {
-            if (role == 1) return;
-        } else if (threadIdx.x == 0) {
-            // somebody else is at the point's chief-ray pass (or done): wait for the centre
-            while (__hip_atomic_load(&ta.state[tpt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 2u)
-                __builtin_amdgcn_s_sleep(8);
-            c_sh[0] = tail_get(ca.center_out + 2 * n);
-            c_sh[1] = tail_get(ca.center_out + 2 * n + 1);
         }
     }
 
@@ -739,7 +724,7 @@ k_psf_lr(SplatBlock sb /* kernarg offset 0 */, TripSet trips /* 64 */, TripSet t
         }
     };
     for (int s = j * chunk + threadIdx.x, pass = 0; s < s_end; s += blockDim.x, ++pass) {
-        if (by_work_left) prio_by_work_left(passes_p - pass, passes_wg);
+        if (by_work_left) prio_by_work_left(passes_p - pass);
         Ray r = make_ray<HotMath>(px, py, pzo, x2[s], y2[s], pz);
         trace_ray<true, HotMath>(lens, 0, K, primary_trips, r, conv_mask ? lds_mask : nullptr);
         propagate_to<HotMath>(r, zs);
@@ -753,7 +738,7 @@ k_psf_lr(SplatBlock sb /* kernarg offset 0 */, TripSet trips /* 64 */, TripSet t
     float* Rg = HAVE_R ? rout + (int64_t)n * pstride + w * tile : nullptr;
     // (double tiles: every sum is rounded to fp32 ONCE here; the maximum and the quotients are taken of the rounded
     // values, i.e. of exactly what k_psf_normalize would read back)
-    if (nsplit == 1 && role == 0) {
+    if (nsplit == 1) {
         if (flags & SDIRT_PSF_NORMALIZE) {
             float mx = -INFINITY;
             for (int i = threadIdx.x; i < tile; i += blockDim.x) mx = fmaxf(mx, (float)tl_[i]);
@@ -774,7 +759,7 @@ k_psf_lr(SplatBlock sb /* kernarg offset 0 */, TripSet trips /* 64 */, TripSet t
                 if (HAVE_R) Rg[i] = (float)trr[i];
             }
         }
-    } else if (role == 0) {
+    } else {
         for (int i = threadIdx.x; i < tile; i += blockDim.x) {
             const float a = (float)tl_[i];
             if (a != 0.0f) atomicAdd(&Lg[i], a);
@@ -786,44 +771,6 @@ k_psf_lr(SplatBlock sb /* kernarg offset 0 */, TripSet trips /* 64 */, TripSet t
     }
     if (conv_mask && (int)threadIdx.x < K && lds_mask[threadIdx.x])
         atomicOr(&conv_mask[threadIdx.x], lds_mask[threadIdx.x]);
-    if (CENTER && role == 2) {
-        // hand this slice's tiles over; the last slice of the point to get here finishes it
-        const int n_acc = (HAVE_R ? 2 : 1) * tile;
-        ACC* __restrict__ part = static_cast<ACC*>(ta.part) + (int64_t)tpt * ta.K * n_acc;
-        for (int i = threadIdx.x; i < n_acc; i += blockDim.x) tail_put(part + (int64_t)j * n_acc + i, tiles[i]);
-        __syncthreads();                       // workgroup-scope release: every wave has waited for its stores
-        if (threadIdx.x == 0)
-            c_sh[0] = __uint_as_float(__hip_atomic_fetch_add(&ta.state[tpt], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        __syncthreads();
-        if (__float_as_uint(c_sh[0]) != 2u + (uint32_t)ta.K - 1u) return;
-        for (int i = threadIdx.x; i < n_acc; i += blockDim.x) {
-            ACC acc = (ACC)0;
-            for (int q = 0; q < ta.K; ++q) acc += q == j ? tiles[i] : tail_get(part + (int64_t)q * n_acc + i);
-            tiles[i] = acc;
-        }
-        __syncthreads();
-        if (flags & SDIRT_PSF_NORMALIZE) {
-            float mx = -INFINITY;
-            for (int i = threadIdx.x; i < tile; i += blockDim.x) mx = fmaxf(mx, (float)tl_[i]);
-            const auto div_l = UDiv<HotMath>::make(block_max(mx, red) + 1e-6f);
-            auto div_r = div_l;
-            if (HAVE_R) {
-                mx = -INFINITY;
-                for (int i = threadIdx.x; i < tile; i += blockDim.x) mx = fmaxf(mx, (float)trr[i]);
-                div_r = UDiv<HotMath>::make(block_max(mx, red) + 1e-6f);
-            }
-            for (int i = threadIdx.x; i < tile; i += blockDim.x) {
-                Lg[i] = div_l((float)tl_[i]);
-                if (HAVE_R) Rg[i] = div_r((float)trr[i]);
-            }
-        } else {
-            for (int i = threadIdx.x; i < tile; i += blockDim.x) {
-                Lg[i] = (float)tl_[i];
-                if (HAVE_R) Rg[i] = (float)trr[i];
-            }
-        }
-        if (threadIdx.x == 0) __hip_atomic_store(&ta.state[tpt], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
 }
 
 static void launch_normalize(float* psf, int64_t N, int tile, hipStream_t st, int64_t stride = 0)
@@ -834,6 +781,12 @@ static void launch_normalize(float* psf, int64_t N, int tile, hipStream_t st, in
         k_psf_normalize<true><<<(unsigned)N, kBlock, lds, st>>>(psf, tile, stride);
     else
         k_psf_normalize<false><<<(unsigned)N, kBlock, 0, st>>>(psf, tile, stride);
+}
+
+// first block of the last generation of a launch of `blocks` workgroups at four per CU (prio_by_work_left)
+static int last_generation_from(int64_t blocks)
+{
+    return (int)std::max<int64_t>(0, blocks - 4ll * device_cus_or_default());
 }
 
 // ---------------------------------------------------------------------------
@@ -978,11 +931,11 @@ int sdirt_chief_center(const sdirt_lens* lens, const float* point_obj, int64_t N
     if (!(flags & SDIRT_PSF_STRICT_IEEE))
         k_chief_center<Lean><<<(int)N, kFused, 0, as_stream(stream)>>>(
             tt, lens->dev, lens->n_surfaces, point_obj, xc, yc, (int)Sc, (float)pupil_z,
-            (float)d_sensor, center, any_valid, conv_mask);
+            (float)d_sensor, center, any_valid, conv_mask, last_generation_from(N));
     else
         k_chief_center<Ieee><<<(int)N, kFused, 0, as_stream(stream)>>>(
             tt, lens->dev, lens->n_surfaces, point_obj, xc, yc, (int)Sc, (float)pupil_z,
-            (float)d_sensor, center, any_valid, conv_mask);
+            (float)d_sensor, center, any_valid, conv_mask, last_generation_from(N));
     LAUNCH_CHECK();
     return SDIRT_OK;
 }
@@ -1004,6 +957,7 @@ struct CenterRequest {
 
 constexpr size_t kWideTilesMax = 39 * 1024;
 
+
 static int spp_split(int64_t N, int64_t S, int* chunk_out, int n_cus = 0)
 {
     // Fill the chip: at least ~4 workgroups per CU; split the spp axis when the
@@ -1024,26 +978,6 @@ static int spp_split(int64_t N, int64_t S, int* chunk_out, int n_cus = 0)
     if (nsplit < 1) nsplit = 1;
     if (chunk_out) *chunk_out = chunk;
     return nsplit;
-}
-
-// The finely cut end of a launch (TailArgs): the last generation of workgroups -- as many points as the chip holds
-// workgroups, 4 per CU -- in kTailSlices slices each; launches that do not fill the chip once keep their own path
-// (spp_split cuts EVERY point then).
-constexpr int kTailSlices = 2;
-struct TailPlan { int n_tail, K, chunk; };
-constexpr size_t kTailStateAlign = 256;      // the partial tiles start on this boundary behind the state words
-static bool tail_plan(int64_t N, int64_t S, int n_cus, TailPlan& tp)
-{
-    const int64_t slots = 4ll * n_cus;
-    if (n_cus < 1 || N < slots) return false;
-    int K = (int)std::min<int64_t>(kTailSlices, S / (2 * kFused));     // a slice is at least two passes of a workgroup
-    if (K < 2) return false;
-    int chunk = (int)((S + K - 1) / K);
-    chunk = (chunk + 63) / 64 * 64;
-    K = (int)((S + chunk - 1) / chunk);
-    if (K < 2) return false;
-    tp.n_tail = (int)slots; tp.K = K; tp.chunk = chunk;
-    return true;
 }
 
 // Device scratch of a verified call: the control block, then the chief-ray partial sums.
@@ -1072,8 +1006,7 @@ static int launch_psf(const sdirt_lens* const* lens, int W, const float* point_o
                       const float* x2, const float* y2, int64_t S, double pupil_z, double d_sensor,
                       double ps, int32_t ks, const float* center, const CenterRequest* cen,
                       const sdirt_dp_params* dp, const TripSet& tt, uint32_t flags, float* l_psf,
-                      float* r_psf, uint32_t* conv_mask, void* stream, const VerifiedRequest* vr = nullptr,
-                      uint32_t* tail_ws = nullptr)
+                      float* r_psf, uint32_t* conv_mask, void* stream, const VerifiedRequest* vr = nullptr)
 {
     const bool have_r = r_psf != nullptr;
     const int tile = ks * ks;
@@ -1100,11 +1033,11 @@ static int launch_psf(const sdirt_lens* const* lens, int W, const float* point_o
         if (lean)
             k_chief_center<Lean><<<(int)N, kFused, 0, st>>>(
                 cen->trips_c.t[0], cen->lens_c->dev, K, point_obj, cen->xc, cen->yc, (int)cen->Sc,
-                (float)pupil_z, (float)d_sensor, cen->center_out, cen->any_valid, cen->conv_mask_c);
+                (float)pupil_z, (float)d_sensor, cen->center_out, cen->any_valid, cen->conv_mask_c, last_generation_from(N));
         else
             k_chief_center<Ieee><<<(int)N, kFused, 0, st>>>(
                 cen->trips_c.t[0], cen->lens_c->dev, K, point_obj, cen->xc, cen->yc, (int)cen->Sc,
-                (float)pupil_z, (float)d_sensor, cen->center_out, cen->any_valid, cen->conv_mask_c);
+                (float)pupil_z, (float)d_sensor, cen->center_out, cen->any_valid, cen->conv_mask_c, last_generation_from(N));
         LAUNCH_CHECK();
         center = cen->center_out;
     }
@@ -1115,20 +1048,8 @@ static int launch_psf(const sdirt_lens* const* lens, int W, const float* point_o
     const SplatGeom gm = make_geom(ps, ks);
     const DevDpParams dpp = make_dp(dp);
     const SplatBlock sblk = make_splat_block(gm, dpp);
-    dim3 grid((unsigned)(N * nsplit), (unsigned)W);
+    const dim3 grid((unsigned)(N * nsplit), (unsigned)W);
     const bool both = have_r && dpp.have_r;
-    TailArgs ta;
-    std::memset(&ta, 0, sizeof(ta));
-    int ncu = 0;
-    if (int rc = device_cus(&ncu)) return rc;
-    if (tail_ws && fuse_center && W == 1 && !vr) {
-        TailPlan tp;
-        if (tail_plan(N, S, ncu, tp)) {
-            ta.state = tail_ws; ta.n_tail = tp.n_tail; ta.n_bulk = (int)N - tp.n_tail; ta.K = tp.K; ta.chunk = tp.chunk;
-            ta.part = reinterpret_cast<char*>(tail_ws) + (sizeof(uint32_t) * tp.n_tail + kTailStateAlign - 1) / kTailStateAlign * kTailStateAlign;
-            grid.x = (unsigned)(N + (int64_t)tp.n_tail * tp.K);
-        }
-    }
     // double accumulators (ACC of k_psf_lr) whenever they leave room for four workgroups per CU, i.e. for the
     // kernel's 8 waves per SIMD: 4 x (39 KiB + 0.4 KiB of static LDS) <= 160 KiB -- L + R up to ks 49, L alone up to 70
     const size_t n_acc = (size_t)tile * (both ? 2 : 1);
@@ -1147,11 +1068,6 @@ static int launch_psf(const sdirt_lens* const* lens, int W, const float* point_o
         ca.conv_mask_c = cen->conv_mask_c;
         lds_bytes = std::max(lds_bytes, sizeof(double) * 3 * kFused);   // fp64 reduction scratch
     }
-    // the last generation of workgroups (as many as the chip holds) issues by work left
-    // (a launch with a finely cut tail: the last generation of whole-point workgroups and every slice behind it)
-    ta.prio_from = kPrioLastGenerations > 0
-        ? (int)std::max<int64_t>(0, (ta.state ? (int64_t)ta.n_tail + ta.n_bulk : (int64_t)grid.x) - (int64_t)kPrioLastGenerations * 4 * ncu)
-        : INT32_MAX;
     SplitArgs sa;
     std::memset(&sa, 0, sizeof(sa));
     // ---- verified call on the split path: round 1 with the speculated tables, the tables checked on
@@ -1192,7 +1108,7 @@ static int launch_psf(const sdirt_lens* const* lens, int W, const float* point_o
             sblk, tt, ttc, ls, K, point_obj, x2, y2, (int)S, nsplit, chunk, (float)pupil_z,       \
             (float)d_sensor, ks, (int)pstride, dpp.tr, dpp.tl, center, flags, l_psf,              \
             both ? r_psf : nullptr,                                                               \
-            conv_mask, ca, sa, ta);                                                               \
+            conv_mask, ca, sa, last_generation_from((int64_t)grid.x * grid.y));                   \
     } while (0)
 #define SDIRT_LAUNCH_PSF_C(HR, BG, MM, AC)                                                        \
     do {                                                                                          \
@@ -1278,26 +1194,17 @@ int sdirt_psf_rgb(const sdirt_lens* const* lens, int32_t W, const float* point_o
                       l_psf, r_psf, conv_mask, stream);
 }
 
-static int psf_centered(const sdirt_lens* const* lens, int32_t W, const sdirt_lens* lens_center,
-                        const float* point_obj, int64_t N, const float* x2, const float* y2,
-                        int64_t S, const float* xc, const float* yc, int64_t Sc, double pupil_z,
-                        double d_sensor, double ps, int32_t ks, const sdirt_dp_params* dp,
-                        const int32_t* trips, const int32_t* trips_center, uint32_t flags,
-                        float* center, int32_t* any_valid, float* l_psf, float* r_psf,
-                        uint32_t* conv_mask, uint32_t* conv_mask_center, uint32_t* tail_ws, void* stream);
-
 int sdirt_psf_lr_centered(const sdirt_lens* lens, const sdirt_lens* lens_center,
                           const float* point_obj, int64_t N, const float* x2, const float* y2,
                           int64_t S, const float* xc, const float* yc, int64_t Sc, double pupil_z,
                           double d_sensor, double ps, int32_t ks, const sdirt_dp_params* dp,
                           const int32_t* trips, const int32_t* trips_center, uint32_t flags,
                           float* center, int32_t* any_valid, float* l_psf, float* r_psf,
-                          uint32_t* conv_mask, uint32_t* conv_mask_center, void* tail_ws, void* stream)
+                          uint32_t* conv_mask, uint32_t* conv_mask_center, void* stream)
 {
-    if (((uintptr_t)tail_ws) & 7) return fail(SDIRT_ERR_INVALID_ARGUMENT, "tail_ws must be 8-byte aligned");
-    return psf_centered(&lens, 1, lens_center, point_obj, N, x2, y2, S, xc, yc, Sc, pupil_z, d_sensor, ps, ks, dp, trips,
-                        trips_center, flags, center, any_valid, l_psf, r_psf, conv_mask, conv_mask_center,
-                        static_cast<uint32_t*>(tail_ws), stream);
+    return sdirt_psf_rgb_centered(&lens, 1, lens_center, point_obj, N, x2, y2, S, xc, yc, Sc, pupil_z,
+                                  d_sensor, ps, ks, dp, trips, trips_center, flags, center, any_valid,
+                                  l_psf, r_psf, conv_mask, conv_mask_center, stream);
 }
 
 int sdirt_psf_rgb_centered(const sdirt_lens* const* lens, int32_t W, const sdirt_lens* lens_center,
@@ -1307,31 +1214,6 @@ int sdirt_psf_rgb_centered(const sdirt_lens* const* lens, int32_t W, const sdirt
                            const int32_t* trips, const int32_t* trips_center, uint32_t flags,
                            float* center, int32_t* any_valid, float* l_psf, float* r_psf,
                            uint32_t* conv_mask, uint32_t* conv_mask_center, void* stream)
-{
-    return psf_centered(lens, W, lens_center, point_obj, N, x2, y2, S, xc, yc, Sc, pupil_z, d_sensor, ps, ks, dp, trips,
-                        trips_center, flags, center, any_valid, l_psf, r_psf, conv_mask, conv_mask_center, nullptr, stream);
-}
-
-int64_t sdirt_psf_tail_bytes(int64_t N, int64_t S, int32_t ks, int32_t both, int32_t n_cus)
-{
-    TailPlan tp;
-    int ncu = n_cus > 0 ? n_cus : device_cus_or_default();
-    if (N < 1 || S < 1 || ks < 2 || ks > SDIRT_MAX_KS || !tail_plan(N, S, ncu, tp)) return 0;
-    // accumulators as launch_psf picks them: doubles while four workgroups per CU fit (the corner-clipped microlens
-    // branch always takes floats: never more than this)
-    const size_t n_acc = (size_t)ks * ks * (both ? 2 : 1);
-    const size_t acc = sizeof(double) * n_acc <= kWideTilesMax ? sizeof(double) : sizeof(float);
-    return (int64_t)((sizeof(uint32_t) * tp.n_tail + kTailStateAlign - 1) / kTailStateAlign * kTailStateAlign
-                     + acc * n_acc * tp.K * tp.n_tail);
-}
-
-static int psf_centered(const sdirt_lens* const* lens, int32_t W, const sdirt_lens* lens_center,
-                        const float* point_obj, int64_t N, const float* x2, const float* y2,
-                        int64_t S, const float* xc, const float* yc, int64_t Sc, double pupil_z,
-                        double d_sensor, double ps, int32_t ks, const sdirt_dp_params* dp,
-                        const int32_t* trips, const int32_t* trips_center, uint32_t flags,
-                        float* center, int32_t* any_valid, float* l_psf, float* r_psf,
-                        uint32_t* conv_mask, uint32_t* conv_mask_center, uint32_t* tail_ws, void* stream)
 {
     if (!lens || W < 1 || W > SDIRT_MAX_WAVELENGTHS || !lens_center || !point_obj || !x2 || !y2 || !xc ||
         !yc || !center || !l_psf || N < 0 || S < 0 || Sc < 0 || S > (1ll << 30) || Sc > (1ll << 30) ||
@@ -1357,7 +1239,7 @@ static int psf_centered(const sdirt_lens* const* lens, int32_t W, const sdirt_le
     cr.lens_c = lens_center; cr.xc = xc; cr.yc = yc; cr.Sc = Sc; cr.center_out = center;
     cr.any_valid = any_valid; cr.conv_mask_c = conv_mask_center;
     return launch_psf(lens, W, point_obj, N, x2, y2, S, pupil_z, d_sensor, ps, ks, nullptr, &cr, dp, tt,
-                      flags, l_psf, r_psf, conv_mask, stream, nullptr, tail_ws);
+                      flags, l_psf, r_psf, conv_mask, stream);
 }
 
 int32_t sdirt_psf_spp_slices(int64_t N, int64_t S, int32_t n_cus)
@@ -1423,25 +1305,81 @@ int sdirt_psf_call(const sdirt_lens* lens, const sdirt_lens* lens_center, const 
                    const int32_t* trips, const int32_t* trips_center, uint32_t flags, float* center,
                    float* l_psf, float* r_psf, void* scratch, uint32_t* ctl_host, void* stream)
 {
-    if (!u_host || !scratch || !ctl_host || N < 0 || S < 1 || Sc < 1 || S > (1ll << 30) || Sc > (1ll << 30))
+    if (!lens || !lens_center || !u_host || !scratch || N < 0 || S < 1 || Sc < 1 || S > (1ll << 30) || Sc > (1ll << 30))
         return fail(SDIRT_ERR_INVALID_ARGUMENT, "bad argument");
+    if ((flags & SDIRT_PSF_NO_VERIFY) && !(flags & SDIRT_PSF_ZERO_CTL))
+        return fail(SDIRT_ERR_INVALID_ARGUMENT, "SDIRT_PSF_NO_VERIFY goes with SDIRT_PSF_ZERO_CTL (the call writes the uniform sum into the block it clears)");
     if (((uintptr_t)scratch) & 7) return fail(SDIRT_ERR_INVALID_ARGUMENT, "scratch must be 8-byte aligned");
     hipStream_t st = as_stream(stream);
     const int64_t n = 2 * (S + Sc);
+    uint32_t* ctl = static_cast<uint32_t*>(scratch);
     float* u = reinterpret_cast<float*>(static_cast<char*>(scratch) +
                                         align64((size_t)sdirt_psf_verified_scratch_bytes(N, Sc)));
     float* xy = u + n;
     HIP_TRY(hipMemcpyAsync(u, u_host, sizeof(float) * (size_t)n, hipMemcpyHostToDevice, st));
     // the reference's draw order (optics.py:483-484, then again inside psf_center): theta, r^2 of the primary
-    // pass, theta, r^2 of the chief-ray pass
-    if (int rc = sdirt_pupil_samples(u, u + S, S, pupil_r, xy, xy + S, stream)) return rc;
-    if (int rc = sdirt_pupil_samples(u + 2 * S, u + 2 * S + Sc, Sc, pupil_r_center, xy + 2 * S, xy + 2 * S + Sc, stream))
-        return rc;
-    if (int rc = sdirt_psf_lr_verified(lens, lens_center, point_obj, N, xy, xy + S, S, xy + 2 * S, xy + 2 * S + Sc, Sc,
-                                       pupil_z, d_sensor, ps, ks, dp, trips, trips_center, flags, center, l_psf, r_psf,
-                                       scratch, stream))
-        return rc;
-    HIP_TRY(hipMemcpyAsync(ctl_host, scratch, sizeof(uint32_t) * SDIRT_CTL_WORDS, hipMemcpyDeviceToHost, st));
+    // pass, theta, r^2 of the chief-ray pass -- both mappings (and SDIRT_PSF_ZERO_CTL) in one launch
+    k_pupil_pair<<<grid_for(std::max<int64_t>(S + Sc, SDIRT_CTL_WORDS), kBlock, 1 << 30), kBlock, 0, st>>>(
+        u, (int)S, (int)Sc, (float)(pupil_r * pupil_r), (float)(pupil_r_center * pupil_r_center), xy, ctl,
+        (flags & SDIRT_PSF_ZERO_CTL) ? SDIRT_CTL_WORDS : 0, (flags & SDIRT_PSF_NO_VERIFY) ? ctl + SDIRT_CTL_UNIFORM_SUM : nullptr);
+    LAUNCH_CHECK();
+    const uint32_t kflags = flags & ~(SDIRT_PSF_ZERO_CTL | SDIRT_PSF_NO_VERIFY);
+    if (N == 0) {
+        // an empty shard of a sharded batch: nothing to render, its (cleared) control block still enters the reductions
+    } else if (spp_split(N, S, nullptr) > 1) {
+        if (flags & SDIRT_PSF_NO_VERIFY)
+            return fail(SDIRT_ERR_UNSUPPORTED, "SDIRT_PSF_NO_VERIFY: only for calls with one workgroup per point (sdirt_psf_spp_slices == 1)");
+        if (int rc = sdirt_psf_lr_verified(lens, lens_center, point_obj, N, xy, xy + S, S, xy + 2 * S, xy + 2 * S + Sc, Sc,
+                                           pupil_z, d_sensor, ps, ks, dp, trips, trips_center, kflags, center, l_psf, r_psf,
+                                           scratch, stream))
+            return rc;
+    } else {
+        // one workgroup per point: ONE fused launch with the speculated tables, its masks and the any-valid flag
+        // straight into the control block, the trip rule evaluated behind it by one thread (status, corrected tables);
+        // a correction is the caller's next call (SDIRT_PSF_ONE_ROUND is implied)
+        if (!trips || !trips_center) return fail(SDIRT_ERR_INVALID_ARGUMENT, "sdirt_psf_call needs both speculated tables");
+        if (int rc = sdirt_psf_lr_centered(lens, lens_center, point_obj, N, xy, xy + S, S, xy + 2 * S, xy + 2 * S + Sc, Sc,
+                                           pupil_z, d_sensor, ps, ks, dp, trips, trips_center, kflags, center,
+                                           reinterpret_cast<int32_t*>(ctl + kCtlAnyValid), l_psf, r_psf, ctl + kCtlMask1P,
+                                           ctl + kCtlMask1C, stream))
+            return rc;
+        if (!(flags & SDIRT_PSF_NO_VERIFY)) {
+            TripTable tp, tc;
+            if (int rc = make_trips(lens, trips, tp)) return rc;
+            if (int rc = make_trips(lens_center, trips_center, tc)) return rc;
+            k_ctl_verify<<<1, 64, 0, st>>>(ctl, lens->dev, lens->n_surfaces, tp, tc);
+            LAUNCH_CHECK();
+        }
+    }
+    if (ctl_host)
+        HIP_TRY(hipMemcpyAsync(ctl_host, scratch, sizeof(uint32_t) * SDIRT_CTL_WORDS, hipMemcpyDeviceToHost, st));
+    return SDIRT_OK;
+}
+
+int sdirt_ctl_to_lanes(const uint32_t* ctl, int32_t* lanes, void* stream)
+{
+    if (!ctl || !lanes) return fail(SDIRT_ERR_INVALID_ARGUMENT, "bad argument");
+    k_ctl_to_lanes<<<grid_for(SDIRT_CTL_LANES, kBlock), kBlock, 0, as_stream(stream)>>>(ctl, lanes);
+    LAUNCH_CHECK();
+    return SDIRT_OK;
+}
+
+int sdirt_ctl_from_lanes(const int32_t* lanes, const sdirt_lens* lens, const int32_t* trips, const int32_t* trips_center,
+                         uint32_t* ctl, uint32_t* ctl_host, void* stream)
+{
+    if (!lanes || !ctl || (lens && (!trips || !trips_center))) return fail(SDIRT_ERR_INVALID_ARGUMENT, "bad argument");
+    TripTable tp, tc;
+    std::memset(&tp, 0, sizeof(tp));
+    std::memset(&tc, 0, sizeof(tc));
+    if (lens) {
+        if (int rc = make_trips(lens, trips, tp)) return rc;
+        if (int rc = make_trips(lens, trips_center, tc)) return rc;
+    }
+    hipStream_t st = as_stream(stream);
+    k_ctl_from_lanes<<<1, 2 * SDIRT_MAX_SURFACES, 0, st>>>(lanes, ctl, lens ? lens->dev : nullptr, lens ? lens->n_surfaces : 0, tp, tc);
+    LAUNCH_CHECK();
+    if (ctl_host)
+        HIP_TRY(hipMemcpyAsync(ctl_host, ctl, sizeof(uint32_t) * SDIRT_CTL_WORDS, hipMemcpyDeviceToHost, st));
     return SDIRT_OK;
 }
 

@@ -74,14 +74,7 @@ __global__ void k_pupil_samples(const float* __restrict__ ut, const float* __res
 {
     const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= S) return;
-    const float theta = (ut[s] * 2.0f) * (float)3.141592653589793;   // optics.py:483
-    const float r = __builtin_sqrtf(ur[s] * pr2);                     // optics.py:484
-    // torch.cos/sin on CPU (MKL VML) are <1 ulp; the correctly rounded values,
-    // obtained here through fp64, agree with them far more often than a 1-2 ulp
-    // fp32 libm would, and that matters: d = o2 - o cancels against |o| ~ 1e4 mm
-    // (DESIGN.md §5).  O(spp) work, shared by all points -- cost is nil.
-    x2[s] = r * (float)__ocml_cos_f64((double)theta);
-    y2[s] = r * (float)__ocml_sin_f64((double)theta);
+    pupil_point(ut[s], ur[s], pr2, x2[s], y2[s]);
 }
 
 // sample_from_points (optics.py:486-494) into a point-major SoA bundle (ray (s, n) = element n S + s): a pure

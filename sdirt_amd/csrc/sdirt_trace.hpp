@@ -88,6 +88,18 @@ __device__ __forceinline__ Ray make_ray(float px, float py, float pz, float x2, 
     return r;
 }
 
+// One pupil sample: uniforms (theta / 2 pi, r^2 / R^2) -> a point of the pupil disc, optics.py:483-488.
+// torch.cos / sin on the CPU (MKL VML) are < 1 ulp; the correctly rounded values, obtained here through fp64, agree
+// with them far more often than a 1-2 ulp fp32 libm would, and that matters: d = o2 - o cancels against
+// |o| ~ 1e4 mm.  O(spp) work, shared by all points -- cost is nil.
+__device__ __forceinline__ void pupil_point(float u_theta, float u_r2, float pr2, float& x, float& y)
+{
+    const float theta = (u_theta * 2.0f) * (float)3.141592653589793;   // optics.py:483
+    const float r = __builtin_sqrtf(u_r2 * pr2);                       // optics.py:484
+    x = r * (float)__ocml_cos_f64((double)theta);
+    y = r * (float)__ocml_sin_f64((double)theta);
+}
+
 __device__ __forceinline__ float block_max(float v, float* red)
 {
     for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));

@@ -126,11 +126,6 @@ class Lensgroup:
         #: calc_magnification3): None = the lens's device, as the reference draws them; 'cpu' = the CPU generator
         #: (what a CPU run of the reference uses: seeds then reproduce its sample points)
         self.sample_rng_device = None
-        #: cut the END of a large fused launch into smaller work units (sdirt_psf_tail_words, include/sdirt_dp.h): the last
-        #: 4 x CUs points of a call with at least that many points are rendered as slices of spp whose partial grids are
-        #: added -- same rays, centres and trip masks; those points' grids are sums of <= 4 rounded partial sums.
-        #: False: one workgroup per point to the end (every grid ONE sum; 0.13 ms more per launch).
-        self.tail_split = True
         #: when a dict, kernel launches are bracketed with HIP events on the launch
         #: stream: {'psf_lr': [(start, end), ...], 'chief_center': [...]}  (bench.py)
         self.kernel_events = None
@@ -797,34 +792,6 @@ class Lensgroup:
             ncu = self.__dict__["_n_cus"] = int(torch.cuda.get_device_properties(self.device).multi_processor_count)
         return _lib.lib().sdirt_psf_spp_slices(N, spp, ncu)
 
-    def _tail_workspace(self, N, spp, ks, both):
-        """The device block sdirt_psf_lr_centered needs to cut the END of a launch into smaller work units
-        (sdirt_psf_tail_bytes; None when this shape has no tail).  Handed over zeroed; the kernel hands it back with its
-        state words zeroed again, and launches on one stream run in order: one block per stream serves every call on it."""
-        if not self.tail_split:
-            return None
-        ncu = self.__dict__.get("_n_cus")
-        if ncu is None:
-            ncu = self.__dict__["_n_cus"] = int(torch.cuda.get_device_properties(self.device).multi_processor_count)
-        sizes = self.__dict__.setdefault("_tail_bytes", {})
-        n = sizes.get((N, spp, ks, both))
-        if n is None:
-            if len(sizes) >= 64:
-                sizes.clear()
-            n = sizes[(N, spp, ks, both)] = int(_lib.lib().sdirt_psf_tail_bytes(N, spp, ks, int(both), ncu))
-        if n == 0:
-            return None
-        pool = self.__dict__.setdefault("_tail_ws", {})
-        st = torch.cuda.current_stream(self.device)
-        ws = pool.get(st.cuda_stream)
-        if ws is None or ws.numel() < n:
-            while len(pool) >= 8:
-                pool.pop(next(iter(pool)))
-            pool.pop(st.cuda_stream, None)
-            with torch.cuda.stream(st):
-                ws = pool[st.cuda_stream] = torch.zeros(n, dtype=torch.uint8, device=self.device)
-        return ws
-
     def _centre_buffer(self, center_out, N):
         """The [N, 2] centre tensor of a psf call: the caller's (checked) or a fresh one."""
         if center_out is None:
@@ -966,7 +933,6 @@ class Lensgroup:
             verified = (reference and self.mask_reduce is None and N > 0
                         and self._spp_slices(N, spp) > 1)
             ctl = None if verified else self._zeroed_control_block(2 * MS + 1)
-            tail_ws = None if verified else self._tail_workspace(N, spp, ks, dpp is not None and R is not None)
 
             def enqueue2(tp, tc):
                 if N == 0:
@@ -979,7 +945,7 @@ class Lensgroup:
                         dp_ref, (C.c_int32 * K)(*[int(t) for t in tp]),
                         (C.c_int32 * K)(*[int(t) for t in tc]), flags, dptr(cen), dptr(anyv),
                         dptr(L), dptr(R), dptr(masks[0]) if reference else None,
-                        dptr(masks[1]) if reference else None, dptr(tail_ws), stream_ptr(self.device)))
+                        dptr(masks[1]) if reference else None, stream_ptr(self.device)))
 
             def squeeze(L_, R_):
                 if R_ is None and want_r:
@@ -1243,7 +1209,7 @@ class Lensgroup:
                 handle, handle_c, dptr(po), N, dptr(x2), dptr(y2), spp, dptr(xc), dptr(yc), Sc, float(pupilz),
                 float(self.d_sensor), float(self.pixel_size), ks, dp_ref, (C.c_int32 * K)(*[int(t) for t in tabs[0]]),
                 (C.c_int32 * K)(*[int(t) for t in tabs[1]]), flags, dptr(cen), dptr(anyv), dptr(L), dptr(R),
-                dptr(masks[0]), dptr(masks[1]), None, stream_ptr(self.device)))
+                dptr(masks[0]), dptr(masks[1]), stream_ptr(self.device)))
             host = ctl.cpu().numpy()
             state["any"] = int(host[2 * MS])
             m = host[:2 * MS].reshape(2, MS)[:, :K].astype(np.int64) & 0xFFFFFFFF

@@ -1,10 +1,14 @@
 #!/usr/bin/env python3
-"""A/B of the finely cut END of a fused launch (sdirt_psf_lr_centered with / without `tail_ws`, include/sdirt_dp.h):
-kernel time by HIP events, and what the tail changes in the results -- centres and trip masks must be equal bit for
-bit, the grids of the tail points may differ in the last bits (sums of <= 4 rounded partial sums), the workspace must
-come back zeroed.
+"""Kernel time of sdirt_psf_lr_centered (chief-ray pass + primary pass of a point in one workgroup) over batch shapes, by HIP
+events, for A/Bs of how a launch ENDS (sdirt_psf.hip: prio_by_work_left; variants in tools/variants/prio_*.py) -- every
+shape warmed for 0.3 s first: a chip that has just been idle holds lower clocks for its first ~100 ms of work, so the first
+shape of a process and the first variant within a shape read 3-5 % high (what made round 6's first tail-split A/Bs look
+better than they were, profiles/r06/tail_ab_map.txt).  Prints a digest of the results: variants must agree bit for bit
+wherever the tiles are float64 (ks <= 49) and in centres and trip masks everywhere.
 
-  [SDIRT_AMD_LIB=build/libsdirt_dp_<variant>.so] python tools/tail_ab.py [--reps 20] [--shapes 2048:4096:65,16384:4096:65]
+  [SDIRT_AMD_LIB=build/libsdirt_dp_<variant>.so] python tools/end_ab.py [--reps 20] [--shapes 2048:4096:65,16384:4096:65]
+
+(The tail-split experiment itself -- tools/tail_ab.py with the tail_ws argument -- lives in commit acacd51.)
 """
 import argparse
 import ctypes as C
@@ -60,11 +64,8 @@ def main():
         xy = torch.empty((2, spp), device=dev); xyc = torch.empty((2, 2048), device=dev)
         _lib.check(h.sdirt_pupil_samples(dptr(u[0]), dptr(u[1]), spp, st["pupil_r"], dptr(xy[0]), dptr(xy[1]), sp))
         _lib.check(h.sdirt_pupil_samples(dptr(u[2]), dptr(u[3]), 2048, st["pupil_r"] * 0.25, dptr(xyc[0]), dptr(xyc[1]), sp))
-        nbytes = int(h.sdirt_psf_tail_bytes(N, spp, ks, 1, ncu))
-        words = min(N, 4 * ncu) if nbytes else 0
-        ws = torch.zeros(max(nbytes, 4), dtype=torch.uint8, device=dev)
         out = {}
-        for tail in (0, 1):
+        for tail in (0,):
             out[tail] = dict(cen=torch.empty((N, 2), device=dev), L=torch.empty((N, ks, ks), device=dev),
                              R=torch.empty((N, ks, ks), device=dev), mask=torch.zeros((2, 64), dtype=torch.int32, device=dev),
                              anyv=torch.zeros(1, dtype=torch.int32, device=dev))
@@ -74,7 +75,7 @@ def main():
             _lib.check(h.sdirt_psf_lr_centered(hl, hl, dptr(po), N, dptr(xy[0]), dptr(xy[1]), spp, dptr(xyc[0]), dptr(xyc[1]),
                                                2048, st["pupil_z"], st["d_sensor"], st["pixel_size"], ks, C.byref(dp), trips,
                                                tripc, 1, dptr(o["cen"]), dptr(o["anyv"]), dptr(o["L"]), dptr(o["R"]),
-                                               dptr(o["mask"][0]), dptr(o["mask"][1]), dptr(ws) if (tail and words) else None, sp))
+                                               dptr(o["mask"][0]), dptr(o["mask"][1]), sp))
 
         def timeit(tail):
             # ~0.3 s of launches first: a chip that has just been idle holds lower clocks for its first ~100 ms of work
@@ -90,27 +91,16 @@ def main():
                 e0.record(); run(tail); e1.record(); torch.cuda.synchronize()
                 ts.append(e0.elapsed_time(e1))
             return float(np.median(ts)), float(np.min(ts))
-        t = {0: [], 1: []}
-        for _ in range(args.rounds):
-            for tail in (0, 1):
-                t[tail].append(timeit(tail))
-        for tail in (0, 1):
-            out[tail]["mask"].zero_(); out[tail]["anyv"].zero_()
-            run(tail)
+        t = [timeit(0) for _ in range(args.rounds)]
+        out[0]["mask"].zero_(); out[0]["anyv"].zero_()
+        run(0)
         torch.cuda.synchronize()
-        a, b = out[0], out[1]
-        dL = (a["L"] - b["L"]).abs().amax(dim=(1, 2)); dR = (a["R"] - b["R"]).abs().amax(dim=(1, 2))
-        n_diff = int(((dL > 0) | (dR > 0)).sum())
-        first_diff = int(torch.nonzero((dL > 0) | (dR > 0))[0]) if n_diff else -1
-        med = lambda tail: float(np.median([x[0] for x in t[tail]]))
-        print(f"lib={os.path.basename(_lib.LIB_PATH)} N={N} spp={spp} ks={ks} tail_words={words} "
-              f"ms_plain={med(0):.4f} (min {min(x[1] for x in t[0]):.4f}) ms_tail={med(1):.4f} (min {min(x[1] for x in t[1]):.4f}) "
-              f"ratio={med(1) / med(0):.4f} | centres_equal={bool(torch.equal(a['cen'], b['cen']))} "
-              f"masks_equal={bool(torch.equal(a['mask'], b['mask']))} any_valid={int(a['anyv'])},{int(b['anyv'])} "
-              f"max_dL={float(dL.max()):.3e} max_dR={float(dR.max()):.3e} points_differing={n_diff} (first {first_diff}, "
-              f"n_bulk={N - words if words else N}) ws_zero_after={bool((ws[:4 * max(words, 1)] == 0).all())} "
-              f"finite={bool(torch.isfinite(b['L']).all() and torch.isfinite(b['R']).all())} "
-              f"L_max_is_1={float(b['L'].amax(dim=(1, 2)).min()):.6f}..{float(b['L'].amax(dim=(1, 2)).max()):.6f}", flush=True)
+        o = out[0]
+        import hashlib
+        sha = lambda x: hashlib.sha1(x.cpu().numpy().tobytes()).hexdigest()[:12]
+        print(f"lib={os.path.basename(_lib.LIB_PATH)} N={N} spp={spp} ks={ks} ms={float(np.median([x[0] for x in t])):.4f} "
+              f"(min {min(x[1] for x in t):.4f}) | cen_sha={sha(o['cen'])} mask_sha={sha(o['mask'])} any_valid={int(o['anyv'])} "
+              f"L_sha={sha(o['L'])} R_sha={sha(o['R'])} L_sum={o['L'].double().sum().item():.6f}", flush=True)
 
 
 if __name__ == "__main__":

@@ -1,4 +1,4 @@
-"""A/B of the issue priority by work left (sdirt_psf.hip): one level per 1 pass(es) left instead of per quarter."""
+"""A/B of the issue priority by work left (sdirt_psf.hip): one level per pass left instead of per two."""
 import sys
 from _edit import sub
 sub(sys.argv[1], "sdirt_psf.hip", "constexpr int kPrioStep = 2;", "constexpr int kPrioStep = 1;")
