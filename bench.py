@@ -2,28 +2,33 @@
 """bench.py -- rays/sec and PSFs/sec of the dual-pixel ray-traced PSF path.
 
 Workload (BASELINE.json configs[1]): rf50mm refocused to 1 m (F/4 stop),
-32x32x16 (x, y, z) PSF volume = 16384 point sources per GPU, 4096 primary rays
+32x32x16 (x, y, z) PSF volume = 16384 point sources, 4096 primary rays
 per point, 65x65 LEFT and RIGHT PSFs, lambda = 0.589 um.  One "step" = one
-Lensgroup.psf_lr call over the rank's 16384 points: draw the pupil uniforms
-(torch CPU generator, the reference's order), chief-ray centre pass (2048 rays
-per point) and the sample->trace->splat->normalise pass in ONE fused kernel launch,
-verification of the batch-global Newton trip counts (of step i while step i+1 runs).  For N > 1
-the ranks share the pupil sample set (48 KB broadcast) and the trip check (mask all-reduce), and
-the PSF shards are all-gathered to every rank over RCCL (north_star's reassembly step; on a side
-stream under the next step's kernels) -- `value` includes it, `value_no_gather` is the rate of the
-same loop without it; `gather` carries the bytes a rank receives per step, the all-gather's own time on its stream
-and `gather_bound` (does it take longer than the kernel it hides under?).  Weak scaling (default): every rank
-renders its own 16384-point slab of a 32x32x(16*N) volume; `--scaling strong`: the ONE 16384-point volume (c3:
-65536 points) cut into N contiguous shards.
+psf call over the rank's points (sdirt_amd.volume.VolumeStepper: ONE library call): draw the pupil uniforms
+(torch CPU generator, the reference's order), upload, pupil mapping, chief-ray centre pass (2048 rays
+per point) and the sample->trace->splat->normalise pass in ONE fused kernel launch, the reference's batch-global
+Newton trip rule evaluated on the device (checked by the host `depth` steps later).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--scaling weak|strong]   (N > 1: starts its own N ranks)
+N > 1 is STRONG scaling by default (north_star): the ONE volume of the workload cut into N contiguous
+shards -- config 2 on 8 GPUs: 2048 points per GPU --, every rank draws the same pupil samples, the trip masks are
+OR-reduced over the ranks (one small all-reduce per step), and the [N/world, 2, ks, ks] blocks the kernels wrote are
+all-gathered to every rank with ONE RCCL collective per step (485 MB received per rank and step at N = 8) on a side
+stream under the next step's kernel -- `value` includes it, `value_no_gather` is the same loop without it; `gather`
+carries the bytes a rank receives per step, the all-gather's own time on its stream and `gather_bound` (does it take
+longer than the kernel it hides under?).  `--scaling weak`: every rank renders its own 16384-point slab of a
+32x32x(16*N) volume.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--scaling strong|weak]   (N > 1: starts its own N ranks)
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-Rank 0 prints ONE JSON line (see the driver contract); `roofline` describes the
-dominant kernel (k_psf_lr), `cpu_baseline` times oracle/ (a C port of the
-reference's CPU path, OpenMP over the host cores, and a PyTorch-CPU restatement of
-the reference's whole-tensor execution model) on a bounded sample of the
-same workload.  oracle/ is only loaded for that baseline leg.
+Rank 0 prints ONE JSON line (see the driver contract) of less than 4 KB: the contract's keys, `roofline` (the
+dominant kernel, k_psf_lr; the figures that say something -- valu_flops_frac, valu_issue_frac -- as flat scalars),
+`cpu_baseline` (oracle/: a C port of the reference's CPU path, OpenMP over the host cores, and a PyTorch-CPU
+restatement of the reference's whole-tensor execution model, on a bounded sample of the same workload; oracle/ is only
+loaded for that leg), `also_summary` ([value, ms_per_step, roofline frac] of the staged SoA chain, f1, c4, c3, tcp, c5)
+and `sweep_summary` (the strong-scaling compute side on this one GPU).  The FULL record -- per-kernel tables, counter
+provenance, notes -- goes to the file named under `detail` (--detail-file, default bench_detail.json) and, with
+--verbose, to stderr.
 """
 import argparse
 import json
@@ -85,8 +90,114 @@ def claim_stdout():
         os.dup2(2, 1)
 
 
+def _r(x, digits=6):
+    """Floats of the one JSON line to six significant digits (the detail file keeps everything)."""
+    if isinstance(x, float):
+        return float(f"{x:.{digits}g}") if math.isfinite(x) else None
+    if isinstance(x, dict):
+        return {k: _r(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_r(v, digits) for v in x]
+    return x
+
+
+LINE_LIMIT = 4000      # bytes: the driver keeps the parsed line whole only when it is short (VERDICT r05: 16 KB was cut)
+_TOP = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+        "dtype", "data", "world_size", "backend", "psfs_per_sec", "render_streams", "kernel_ms", "value_no_gather",
+        "ms_per_step_no_gather", "value_two_streams", "ms_per_step_two_streams", "ms_per_step_sustained", "value_sustained",
+        "sustained_steps", "value_pcie_inclusive")
+_CFG = ("workload", "name", "points_per_gpu", "spp", "ks", "parallelism", "gather", "newton_trip_policy",
+        "relaunches_in_timed_region", "miopen_find_mode", "miopen_find_seconds", "backend")
+
+
+def compact(res):
+    """The ONE line the driver parses, under LINE_LIMIT bytes: the contract's keys, `roofline` and `cpu_baseline` with the
+    figures that say something as flat scalars, one [value, ms_per_step, roofline frac] triple per side workload
+    (`also_summary`), one [ms_per_step, kernel_ms, host_us_per_step, efficiency] row per shard size (`sweep_summary`).
+    Everything else -- per-kernel tables, counter provenance, notes -- is in the detail file named under `detail`."""
+    out = {k: res[k] for k in _TOP if k in res}
+    cfg = res.get("config") or {}
+    out["config"] = {k: cfg[k] for k in _CFG if k in cfg}
+    rf = res.get("roofline")
+    if rf:
+        o = {k: rf.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic") if k in rf}
+        for k in ("traffic_stale", "kernel", "algorithmic_bytes_per_launch"):
+            if rf.get(k) is not None:
+                o[k] = rf[k]
+        vf, vi, rk = rf.get("valu_flops") or {}, rf.get("valu_issue") or {}, rf.get("rocprof_kernel_trace") or {}
+        if vf:
+            o["valu_flops_frac"], o["valu_tflops"] = vf.get("frac"), vf.get("achieved")
+        if vi:
+            o["valu_issue_frac"] = vi.get("frac")
+            o["issue_bound_frac"] = (vi.get("issue_bound") or {}).get("frac")
+            o["counters_stale"] = vi.get("stale")
+        if rk:
+            o["rocprof_median_ms"], o["counters"] = rk.get("median_ms"), rk.get("file")
+        out["roofline"] = o
+    cb = res.get("cpu_baseline")
+    if cb:
+        o = {k: cb[k] for k in ("value", "unit", "cores", "kind", "sample", "cpu_model") if k in cb}
+        if "torch" in cb:
+            o["torch_value"], o["torch_threads"] = cb["torch"]["value"], cb["torch"]["threads"]
+        out["cpu_baseline"] = o
+    g = res.get("gather")
+    if g:
+        out["gather"] = {k: g[k] for k in ("algo", "backend", "world_size", "gb_received_per_rank_per_step",
+                                           "collectives_per_step", "ms", "GBps_received_per_rank", "compute_ms",
+                                           "gather_bound") if k in g}
+    also = res.get("also")
+    if also:
+        summ = {}
+        for name, r in also.items():
+            if name == "shard_sweep":
+                continue
+            if "error" in r:
+                summ[name] = r["error"][:60]
+            elif name == "staged":
+                for ks_name, c in (r.get("staged") or {}).items():
+                    # [rays/s of the chain, ms per step, the lowest HBM fraction among its three HBM-bound kernels]
+                    fr = [c["kernels"][k]["frac_of_hbm_peak"] for k in ("sample_rays", "propagate_to", "forward_integral")
+                          if "frac_of_hbm_peak" in c.get("kernels", {}).get(k, {})]
+                    summ[f"staged_{ks_name}"] = [c.get("rays_per_s"), c.get("ms_per_step"), min(fr) if fr else None]
+            else:
+                summ[name] = [r.get("value"), r.get("ms_per_step"), (r.get("roofline") or {}).get("frac")]
+        out["also_summary"] = summ
+    sweep = res.get("shard_sweep") or (also or {}).get("shard_sweep", {}).get("shard_sweep")
+    if sweep:
+        out["sweep_summary"] = {name: [r.get("ms_per_step"), r.get("kernel_ms"), r.get("host_us_per_step"), r.get("efficiency")]
+                                for name, r in sweep.items()}
+        out["sweep_columns"] = ["ms_per_step", "kernel_ms", "host_us_per_step", "efficiency"]
+    for k in ("kernels_ms",):
+        if k in res and len(json.dumps(res[k])) < 200:
+            out[k] = res[k]
+    if res.get("detail"):
+        out["detail"] = res["detail"]
+    out = _r(out)
+    # never longer than the limit: drop the optional blocks, largest first
+    for k in ("sweep_summary", "also_summary", "kernels_ms", "gather"):
+        if len(json.dumps(out)) <= LINE_LIMIT:
+            break
+        out.pop(k, None)
+        out.pop("sweep_columns", None) if k == "sweep_summary" else None
+    return out
+
+
+DETAIL_PATH = None     # --detail-file: where the full record of the run goes (default bench_detail.json beside bench.py)
+
+
 def emit_line(res):
-    line = (json.dumps(res) + "\n").encode()
+    """Rank 0's result: the FULL record into the detail file (and onto stderr under --verbose), its compact() form as the
+    ONE JSON line on stdout."""
+    path = DETAIL_PATH or os.path.join(ROOT, "bench_detail.json")
+    try:
+        with open(path, "w") as f:
+            json.dump(res, f, indent=1)
+        res = dict(res, detail=os.path.relpath(path, ROOT) if path.startswith(ROOT) else path)
+    except OSError as e:          # a read-only checkout must not cost the line
+        sys.stderr.write(f"bench.py: detail file not written: {e}\n")
+    if os.environ.get("SDIRT_BENCH_VERBOSE") == "1":
+        sys.stderr.write(json.dumps(res) + "\n")
+    line = (json.dumps(compact(res)) + "\n").encode()
     if _JSON_FD is None:
         sys.stdout.write(line.decode())
         sys.stdout.flush()
@@ -530,18 +641,22 @@ def bench_staged(args, emit=True, lens=None, ks_list=None):
 
 def bench_sweep(args, emit=True, lens=None):
     """--workload sweep: the COMPUTE side of strong scaling, on the one GPU a box of this pool has.  Config 2 cut to
-    16384 / 8192 / 4096 / 2048 points per step (what a rank renders at world 1 / 2 / 4 / 8 under `--scaling strong`),
-    each through the loop `--gpus N` runs (VolumeLoop with force=True): pupil broadcast, deferred trip check behind a
-    mask all-reduce, the shard rendered into its [n, 2, ks, ks] block and that block all-gathered on the comm stream --
-    every collective really issued, on a world-1 RCCL process group (sdirt_amd.dist.FORCE_COLLECTIVES).  What a 1-GPU box
-    cannot show is the xGMI side: a rank of an 8-GPU run RECEIVES 7 blocks where this stand-in copies its own.
+    16384 / 8192 / 4096 / 2048 points per step (what a rank renders at world 1 / 2 / 4 / 8 under strong scaling), each
+    through the loop `--gpus N` runs (sdirt_amd.volume.VolumeStepper with force_collectives): one library call per step,
+    the mask all-reduce in front of the device-side trip rule, the shard rendered into its [n, 2, ks, ks] block and that
+    block all-gathered on the comm stream -- every collective really issued, on a world-1 RCCL process group.  What a
+    1-GPU box cannot show is the xGMI side: a rank of an 8-GPU run RECEIVES 7 blocks where this stand-in copies its own.
     Every k-th point of the volume (all depth planes, all field positions), so that the batch-global Newton trip
-    tables are the whole volume's.  compute_efficiency = (ms of the plain 16384-point single-GPU step x n / 16384) /
-    ms_per_step: 1.0 = a rank of an N-GPU run would take exactly 1/N of the single-GPU step (marginal cost of a step,
-    from two region lengths; `fences_ms` is what the barrier + synchronisation pair around a timed region adds)."""
+    tables are the whole volume's.
+
+    Every figure is physical: ms_per_step = wall time between two fences (barrier + device synchronisation on both
+    sides, pipeline drain included) / steps, over >= 500 steps for shards of <= 4096 points; efficiency = (ms_per_step of
+    the plain 16384-point single-GPU loop x n / 16384) / ms_per_step <= ~1: a rank of an N-GPU run would take exactly 1/N
+    of the single-GPU step at 1.0.  kernel_ms = HIP events around the step's library call (48 KB upload + pupil mapping
+    + fused kernel); with two render streams consecutive launches overlap and a pair spans both."""
     import socket
     import torch.distributed as dist
-    from sdirt_amd import dist as sd
+    from sdirt_amd.volume import VolumeStepper
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback exists)"
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
@@ -552,79 +667,70 @@ def bench_sweep(args, emit=True, lens=None):
         port = sock.getsockname()[1]
         sock.close()
         dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
-    sd.FORCE_COLLECTIVES = True
     try:
         if lens is None:
             lens = build_lens(dev)
         pts_all = volume_points(1, "c2").to(dev)
         n_full = pts_all.shape[0]
-        steps = max(60, args.steps)
         ks, spp = WORKLOADS["c2"]["ks"], WORKLOADS["c2"]["spp"]
         rows = {}
+        import gc
 
         def run(points, force, label, streams=1):
-            loop = VolumeLoop(lens, points, points.shape[0], 1, dev, ks, spp, gather=force, force=force, streams=streams)
-            try:
-                loop.step()
-                loop.settle()                                    # trip-table discovery for this batch
-                for _ in range(10):
-                    loop.step()
-                loop.fence()
-                lens.kernel_events = {}
-                del loop.gather_events[:]
-                r0 = lens.trips.relaunches
-                # two region lengths: the slope is the cost of a step, the intercept what the two fences of a timed
-                # region cost (pipeline drain, the last steps' verification and gathers, barrier, device synchronisation)
-                dt_short = loop.timed(steps // 4)
-                loop.t_step = loop.t_wait = 0.0
-                dt = loop.timed(steps)
-                marginal = (dt - dt_short) / (steps - steps // 4) * 1e3
-                ev, lens.kernel_events = lens.kernel_events, None
-                k_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev["psf_lr_centered"]]))
-                row = {"points_per_step": points.shape[0], "steps": steps, "ms_per_step": dt / steps * 1e3,
-                       "ms_per_step_marginal": marginal, "fences_ms": dt * 1e3 - marginal * steps, "kernel_ms": k_ms,
-                       "gpu_idle_us_per_step": (marginal - k_ms) * 1e3,
-                       # wall time the host spends enqueueing a step (draw, upload, launches, collectives' host side,
-                       # verification arithmetic), without the time it sits blocked waiting for a result
-                       "host_us_per_step": (loop.t_step - loop.t_wait) / steps * 1e6,
-                       "rays_per_s": points.shape[0] * spp * steps / dt,
-                       "relaunches_in_timed_region": lens.trips.relaunches - r0,
-                       "trip_tables": {"psf": [int(v) for v in lens.trips.cache[("psf", 0.589, lens.precision)]],
-                                       "center": [int(v) for v in lens.trips.cache[("center", lens.precision)]]}}
-                if loop.gather_events:
-                    row["gather_ms"] = float(np.mean([a_.elapsed_time(b_) for a_, b_ in loop.gather_events]))
-                    row["gather_block_mb"] = points.shape[0] * 2 * ks * ks * 4 / 1e6
-                rows[label] = row
-                return row
-            finally:
-                loop.close()
-                del loop
-                torch.cuda.empty_cache()
-        import gc
+            n = points.shape[0]
+            steps = max(args.steps, 100 if n > 4096 else 500)
+            torch.manual_seed(0)
+            st = VolumeStepper(lens, points, n, ks, spp, DP, gather=force, streams=streams, time_steps=True,
+                               force_collectives=force)
+            for _ in range(20):
+                st.step()
+            st.fence()
+            gc.collect()
+            gc.freeze()
+            st.reset_counters()
+            r0 = st.relaunches
+            dt = st.timed(steps)
+            row = {"points_per_step": n, "steps": steps, "ms_per_step": dt / steps * 1e3, "kernel_ms": st.kernel_ms(),
+                   # wall time the host spends in step() and settle() per step, without the time it sits blocked waiting
+                   # for a control block: draw, ONE library call, the collectives' host side, event bookkeeping
+                   "host_us_per_step": st.t_step / steps * 1e6, "host_blocked_us_per_step": st.t_wait / steps * 1e6,
+                   "rays_per_s": n * spp * steps / dt, "relaunches_in_timed_region": st.relaunches - r0,
+                   "render_streams": streams, "steps_in_flight": st.depth,
+                   "trip_tables": [[int(v) for v in t_] for t_ in st.tables]}
+            g_ms = st.gather_ms()
+            if g_ms is not None:
+                row["gather_ms"], row["gather_block_mb"] = g_ms, n * 2 * ks * ks * 4 / 1e6
+            rows[label] = row
+            del st
+            torch.cuda.empty_cache()
+            return row
         base = run(pts_all, False, "single_gpu_loop_16384")       # the headline's own loop: no process group in the way
-        gc.collect()
-        gc.freeze()
+        base2 = run(pts_all, False, "single_gpu_loop_16384_two_streams", 2)
+
         def rate(row):
-            # marginal step against marginal step: what a long run converges to; `..._incl_fences`: this 100-step region
-            row["compute_efficiency"] = base["ms_per_step_marginal"] * (row["points_per_step"] / n_full) / row["ms_per_step_marginal"]
-            row["compute_efficiency_incl_fences"] = base["ms_per_step"] * (row["points_per_step"] / n_full) / row["ms_per_step"]
-            row["kernel_efficiency"] = base["kernel_ms"] * (row["points_per_step"] / n_full) / row["kernel_ms"]
+            # against the single-GPU loop with the SAME number of render streams: a rank with two streams is compared with
+            # a single GPU that also overlaps its launches
+            ref = base if row["render_streams"] == 1 else base2
+            row["efficiency"] = ref["ms_per_step"] * (row["points_per_step"] / n_full) / row["ms_per_step"]
+            if row["render_streams"] == 1:
+                row["kernel_efficiency"] = base["kernel_ms"] * (row["points_per_step"] / n_full) / row["kernel_ms"]
+                row["gpu_idle_us_per_step"] = max(0.0, (row["ms_per_step"] - row["kernel_ms"]) * 1e3)
             row["trip_tables_equal_full_batch"] = row.pop("trip_tables") == base["trip_tables"]
         for k in (1, 2, 4, 8):
             for streams in (1, 2):
-                # streams = 2: consecutive steps on alternating render streams -- the next step's workgroups fill the
-                # low-occupancy end of the previous launch (`kernel_ms` then spans two overlapping launches)
                 row = run(pts_all[::k].contiguous(), True, f"world{k}_shard_{n_full // k}" + ("" if streams == 1 else "_two_streams"), streams)
-                row["as_rank_of_world"], row["render_streams"] = k, streams
+                row["as_rank_of_world"] = k
                 rate(row)
-        rate(run(pts_all, False, "single_gpu_loop_16384_two_streams", 2))
+        base["efficiency"] = base2["efficiency"] = 1.0
+        base2["speedup_over_one_stream"] = base["ms_per_step"] / base2["ms_per_step"]
+        base.pop("trip_tables", None)
+        base2.pop("trip_tables", None)
     finally:
-        sd.FORCE_COLLECTIVES = False
         if own_group:
             dist.destroy_process_group()
     last = rows[f"world8_shard_{n_full // 8}"]
     res = {"metric": "rays/sec rf50mm 65x65 DP-PSF @4096spp, strong-scaling compute side on one GPU (2048-point step of a rank of 8)",
-           "value": last["rays_per_s"], "unit": "rays/s", "n_gpus": 1, "steps": steps, "warmup": 10,
+           "value": last["rays_per_s"], "unit": "rays/s", "n_gpus": 1, "steps": last["steps"], "warmup": 20,
            "ms_per_step": last["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
            "dtype": "f32", "data": "synthetic",
            "config": {"workload": "config 2 (rf50mm 32x32x16, 4096 spp, 65x65 L+R) cut to every k-th point, k = 1, 2, 4, 8: the step of "
@@ -642,12 +748,16 @@ def bench_c5(args, emit=True):
     512 x 768 RGB-D frame (NYUv2 is not in the reference's repository) -> PSFNet.render (psfnet.py:645-714: per-pixel
     L/R kernels from the PSF network, per-pixel convolution; ks 21, full-size MLP with seeded weights -- the
     reference's checkpoints are missing) -> DfDPNet forward under fp16 autocast (dfdp/dddnet/dddnet.py:122-152).
-    MIOpen's find mode (torch.backends.cudnn.benchmark) is OFF: the convolutions run with MIOpen's immediate-mode picks."""
+    The depth network's convolutions are stock MIOpen, run as a user of the network runs them: with
+    torch.backends.cudnn.benchmark = True, i.e. ONE find pass over the ~30 forward shapes during the first frame
+    (`miopen_find_seconds`; torch keeps the pick per shape for the life of the process, so the flag must be set before
+    the first call).  SDIRT_C5_FIND=0: MIOpen's immediate-mode picks instead -- the fallback solvers VERDICT r05 found in
+    the driver's stderr (GemmFwdRest without its workspace): 7.1 instead of ~3.5 ms for the forward pass.
+    `roofline`: the frame's largest kernel of this package, k_psfnet_mlp (MFMA-bound; its own HIP-event time)."""
     from sdirt_amd.dfdp import DfDPNet
     from sdirt_amd.psfnet import PSFNet
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback exists)"
     dev = torch.device("cuda", 0)
-    find_mode = bool(torch.backends.cudnn.benchmark)
     H, W, ks = 512, 768, 21
     torch.manual_seed(0)
     m = PSFNet(os.path.join(ROOT, "sdirt_amd", "data", "rf50mm.json"), sensor_res=(H, W), kernel_size=ks, device=dev)
@@ -661,80 +771,96 @@ def bench_c5(args, emit=True):
     torch.manual_seed(1)
     net = DfDPNet().to(dev).eval()
     stream = torch.cuda.current_stream(dev)
-    ev = {"render": [], "dfdp_forward": []}
 
-    def chain(record=False):
+    def chain(ev=None):
         with torch.no_grad():
-            e = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if record else None
-            if record:
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if ev is not None else None
+            if e:
                 e[0].record(stream)
             pair = m.render(img, depth, foc)
-            if record:
+            if e:
                 e[1].record(stream)
             left, right = pair[:, :3].contiguous(), pair[:, 3:].contiguous()
             with torch.autocast("cuda", dtype=torch.float16):
                 disp = net(left, right)
-            if record:
+            if e:
                 e[2].record(stream)
                 ev["render"].append((e[0], e[1]))
                 ev["dfdp_forward"].append((e[1], e[2]))
         return disp
-    t0 = time.perf_counter()
-    for _ in range(max(args.warmup, 3)):
-        disp = chain()
-    torch.cuda.synchronize(dev)
-    warm_s = time.perf_counter() - t0
-    steps = max(args.steps, 5)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        disp = chain(True)
-    torch.cuda.synchronize(dev)
-    wall = (time.perf_counter() - t0) / steps * 1e3
-    assert bool(torch.isfinite(disp).all())
-    ms = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in ev.items()}
+
+    def measure(warm):
+        t0 = time.perf_counter()
+        for _ in range(warm):
+            disp = chain()
+        torch.cuda.synchronize(dev)
+        warm_s = time.perf_counter() - t0
+        steps = max(args.steps, 5)
+        ev = {"render": [], "dfdp_forward": []}
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            disp = chain(ev)
+        torch.cuda.synchronize(dev)
+        wall = (time.perf_counter() - t0) / steps * 1e3
+        assert bool(torch.isfinite(disp).all())
+        return wall, {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in ev.items()}, warm_s, steps, disp
+    was = bool(torch.backends.cudnn.benchmark)
+    find = os.environ.get("SDIRT_C5_FIND", "1") == "1"
+    torch.backends.cudnn.benchmark = find
+    wall, ms, first_s, steps, disp = measure(max(args.warmup, 3))
+    torch.backends.cudnn.benchmark = was
+    # the PSF network alone (both passes of PSFNet.pred): 786432 rows x 4.78 MFLOP, the largest kernel of this package
+    # in the frame
+    x, y = torch.meshgrid(torch.linspace(-1, 1, W), torch.linspace(1, -1, H), indexing="xy")
+    o = torch.stack((x.to(dev)[None], y.to(dev)[None], m.depth2z(depth + m.d_sensor).squeeze(1)), -1).float()
+    with torch.no_grad():
+        _, mlp_ms = _hip_ms(lambda: m.psfnet.forward_fused(o, mirror=True), 10, 3, dev)
+    macs = 3 * 128 + 128 * 512 + 8 * 512 * 512 + 512 * ks * ks
+    flops = 2 * macs * 2 * H * W
+    tf = flops / (mlp_ms * 1e-3) / 1e12
+    MFMA_PEAK_F16 = 2500.0       # MI355X_MICROARCH.md: dense fp16 / bf16 matrix peak, TFLOP/s
     res = {"metric": "frames/sec config 5: RGB-D 512x768 -> PSFNet.render (DP pair) -> DfDP net forward, 1 GPU",
            "value": 1e3 / wall, "unit": "frames/s", "n_gpus": 1, "steps": steps, "warmup": max(args.warmup, 3),
            "ms_per_step": wall, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16",
            "data": "synthetic",
-           "config": {"workload": "synthetic RGB-D frame 1x3x512x768 (depth U[0.5, 5] m, focus 1 m) -> PSFNet.render, ks 21, full-size PSF "
-                                  "network (seeded weights) -> DfDPNet forward (fp16 autocast), rf50mm", "name": "c5",
-                      "miopen_find_mode": find_mode, "first_calls_s": warm_s},
-           "kernels_ms": ms}
+           "config": {"workload": "BASELINE config 5: synthetic RGB-D frame 1x3x512x768 (depth U[0.5, 5] m, focus 1 m) -> PSFNet.render, ks 21, "
+                                  "full-size PSF network (seeded weights) -> DfDPNet forward (fp16 autocast), rf50mm", "name": "c5",
+                      "miopen_find_mode": bool(find), "miopen_find_seconds": first_s if find else None, "first_calls_s": first_s},
+           "kernels_ms": dict(ms, psfnet_mlp=mlp_ms),
+           "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_PEAK_F16, "unit": "TFLOP/s", "frac": tf / MFMA_PEAK_F16,
+                        "traffic": None, "kernel": "k_psfnet_mlp (3 -> 128 -> 512 x 9 -> 441, both passes of PSFNet.pred: 786432 rows)",
+                        "algorithmic_flops_per_launch": flops,
+                        "note": "the frame's largest kernel of this package (2.9 of the render's 3.4 ms); the depth network's "
+                                "convolutions are stock MIOpen"}}
     if emit:
         emit_line(res)
     return res
 
 
 def quick_volume(workload, steps, device):
-    """K steps of another PSF-volume workload (WORKLOADS) with the stepping of the headline loop -- calls kept in
-    flight, Newton trip check of step i under step i + 1 -- for the `also` block of the default line."""
+    """K steps of another PSF-volume workload (WORKLOADS) through the headline's loop (VolumeStepper) -- for the `also`
+    block of the default line."""
+    from sdirt_amd.volume import VolumeStepper
     wl = WORKLOADS[workload]
     lens = build_lens(device, wl["lens"], wl["sensor_z"])
     gz = 8 if workload.startswith("c3") else wl["grid_z"]
     pts = volume_points(1, workload).to(device)
     n, ks, spp = pts.shape[0], wl["ks"], wl["spp"]
-    bufs = [tuple(torch.empty((n, ks, ks), dtype=torch.float32, device=device) for _ in range(2)) for _ in range(3)]
-    lens.psf_lr(pts, ks=ks, spp=spp, dp=DP, out=bufs[0])             # trip-table discovery
-    lens.psf_lr(pts, ks=ks, spp=spp, dp=DP, out=bufs[0])
-    torch.cuda.synchronize(device)
-    lens.kernel_events = {}
-    r0 = lens.trips.relaunches
-    pend = []
-    t0 = time.perf_counter()
-    for i in range(steps):
-        pend.append(lens.psf_lr(pts, ks=ks, spp=spp, dp=DP, out=bufs[i % 3], defer=True))
-        if len(pend) > 2:
-            pend.pop(0).wait()
-    for p_ in pend:
-        p_.wait()
-    torch.cuda.synchronize(device)
-    dt = time.perf_counter() - t0
-    ev, lens.kernel_events = lens.kernel_events, None
-    k_ms = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in ev.items()}
+    st = VolumeStepper(lens, pts, n, ks, spp, DP, time_steps=True)
+    for _ in range(3):
+        st.step()
+    st.fence()
+    r0 = st.relaunches
+    dt = st.timed(steps)
+    k_ms = st.kernel_ms()
+    alg_bytes = n * (12 + 8) + (spp + 2048) * 8 + 2 * n * ks * ks * 4
+    ach = alg_bytes / (k_ms * 1e-3) / 1e9
     return {"metric": f"rays/sec {wl['lens']} {ks}x{ks} DP-PSF @{spp}spp", "value": n * spp * steps / dt, "unit": "rays/s",
-            "steps": steps, "ms_per_step": dt / steps * 1e3, "kernels_ms": k_ms,
+            "steps": steps, "ms_per_step": dt / steps * 1e3, "kernels_ms": {"psf_call": k_ms},
+            "roofline": {"bound": "valu", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                         "traffic": None, "algorithmic_bytes_per_launch": alg_bytes},
             "config": {"workload": wl["desc"].format(gz=gz) + f", {n} points, {spp} spp, {ks}x{ks} L+R", "name": workload,
-                       "relaunches_in_timed_region": lens.trips.relaunches - r0}}
+                       "relaunches_in_timed_region": st.relaunches - r0}}
 
 
 def also_block(args, lens, device):
@@ -812,167 +938,6 @@ def bench_tcp(args, emit=True):
     return res
 
 
-class VolumeLoop:
-    """The stepping of one rank of a PSF-volume render: `step()` enqueues one psf_lr call over the rank's points with
-    the speculated Newton trip tables (defer=True) and keeps DEPTH calls in flight; `settle()` verifies them in order
-    and -- when the step asked for it -- sends the now final shard through the all-gather on the comm stream;
-    `timed(k)` = k steps between two fences (barrier + device synchronisation), MAX over ranks.
-
-    world > 1 (or force=True: the single-rank stand-in of `--workload sweep`, every collective issued on a world-1
-    process group): the ranks share the pupil sample set (48 KB broadcast per step) and the batch-global trip check
-    (mask all-reduce, sdirt_amd/dist.py) and the shard is gathered to every rank.
-
-    A rank renders into ONE [width, 2, ks, ks] block per step -- point n's left grid at [n, 0], its right grid at
-    [n, 1] (SDIRT_PSF_INTERLEAVED) -- which is also what the gather sends: one collective per step, no staging copy
-    (ShardedPSF.shard_buffer / gather: the library path and the benchmarked path are the same)."""
-    DEPTH = 8        # calls kept in flight (kernel enqueued, Newton trip check pending): ~80 ms of queued work
-
-    def __init__(self, lens, points_local, n_total, world, device, ks, spp, gather, force=False, streams=1):
-        import torch.distributed as dist
-        from sdirt_amd import dist as sd
-        self.lens, self.points, self.n_total, self.world, self.device = lens, points_local, n_total, world, device
-        self.ks, self.spp, self.gather, self.dist, self.sd = ks, spp, gather, dist, sd
-        self.n_local = points_local.shape[0]
-        self.multi = world > 1 or force
-        self.gather_group = self.comm_stream = self.sharded = None
-        if self.multi:
-            self.sharded = sd.ShardedPSF.from_lens(lens, ks, dp=DP)
-            # the all-gather of step i runs on its own stream underneath the kernels of step i+1
-            # (double-buffered: xGMI copy engines / RCCL channels vs. VALU-bound compute)
-            self.comm_stream = torch.cuda.Stream(device)
-            # its own communicator: PyTorch runs all collectives of one process group on one internal
-            # stream, so a gather issued on the default group would hold back the next step's small
-            # pupil broadcast (and with it the next kernel) until 4 GB have moved
-            self.gather_group = dist.new_group() if gather else None
-            # ... and the pupil broadcast of step i+1 on a third one, on a side stream: it depends on nothing that is
-            # queued, so it runs beside step i's kernel (on the default group it would queue behind step i's mask
-            # all-reduce, i.e. behind step i's kernel: 0.16-0.35 ms of idle GPU per step, `--workload sweep`)
-            self.pupil_group = dist.new_group()
-            self.pupil_stream = torch.cuda.Stream(device)
-        self.width = max(b_ - a_ for a_, b_ in sd.shard_bounds(n_total, world))
-        self.gather_buf = [torch.empty((world * self.width, 2, ks, ks), dtype=torch.float32, device=device)
-                           for _ in range(2)] if (gather and self.multi) else None
-        self.step_no = 0
-        # output blocks are owned by the caller and re-used (the previous steps' PSFs may still be
-        # feeding the all-gather / the consumer while the next step renders)
-        self.out_bufs = [torch.zeros((self.width, 2, ks, ks), dtype=torch.float32, device=device)
-                         for _ in range(self.DEPTH + 1)]
-        self.gather_done = [None] * (self.DEPTH + 1)   # per output block: event of the last gather reading it
-        self.gathers = 0
-        self.gather_events = []                        # (start, end) on the comm stream, one pair per step's all-gather
-        self.in_flight = []                            # (PendingPSF, out, slot, ready event | None)
-        self.t_step = self.t_wait = 0.0                # wall seconds inside step() / of them blocked in PendingPSF.wait()
-        self.in_step = False
-        # streams = 2: consecutive steps alternate between two render streams.  Steps are independent (their own
-        # output block, pupil set and control block), and on one in-order stream step i+1 cannot start before the LAST
-        # workgroup of step i has finished -- the end of a launch runs at falling occupancy (DESIGN.md §3: 0.13 ms of a
-        # 16384-point step, 10 % of a 2048-point one); on two streams the next step's workgroups fill it.
-        self.render_streams = [torch.cuda.Stream(device) for _ in range(streams)] if streams > 1 else None
-        torch.cuda.synchronize(device)                 # buffers above are ready whatever stream uses them first
-
-    def use_streams(self, n):
-        """Switch between one render stream (the caller's) and n alternating ones; between two fences only."""
-        self.fence()
-        self.render_streams = [torch.cuda.Stream(self.device) for _ in range(n)] if n > 1 else None
-
-    def close(self):
-        """Hand the lens back to single-rank use."""
-        if self.multi:
-            self.lens.mask_reduce = None
-
-    def settle(self, keep=0):
-        """Newton trip checks (lens.psf_lr(defer=True)) of all but the `keep` newest steps, each
-        followed -- when the step asked for it -- by the all-gather of its now final shard on
-        the comm stream.  The host stays `keep` kernels ahead of the GPU: the GPU renders step
-        i+1 while the host verifies step i and RCCL moves step i's PSFs, and a descheduled host
-        thread (the boxes are shared) does not leave the GPU idle."""
-        lens, device = self.lens, self.device
-        while len(self.in_flight) > keep:
-            pend, out, slot, ready = self.in_flight.pop(0)
-            r0 = lens.trips.relaunches
-            t_w = time.perf_counter()
-            pend.wait()
-            if self.in_step:
-                self.t_wait += time.perf_counter() - t_w
-            if ready is None:
-                continue
-            if lens.trips.relaunches != r0:          # re-rendered: the shard is ready later
-                ready = torch.cuda.Event()
-                ready.record(torch.cuda.current_stream(device))
-            buf = self.gather_buf[self.gathers % 2]
-            self.gathers += 1
-            with torch.cuda.stream(self.comm_stream):
-                self.comm_stream.wait_event(ready)
-                g0 = torch.cuda.Event(enable_timing=True)
-                g0.record(self.comm_stream)
-                self.sharded.gather(out, self.n_total, out=buf, group=self.gather_group)   # ONE collective
-                done = torch.cuda.Event(enable_timing=True)
-                done.record(self.comm_stream)
-                self.gather_events.append((g0, done))
-            self.gather_done[slot] = done
-
-    def step(self, gather=None):
-        t0 = time.perf_counter()
-        self.in_step = True
-        try:
-            return self._step(gather)
-        finally:
-            self.in_step = False
-            self.t_step += time.perf_counter() - t0
-
-    def _step(self, gather=None):
-        if self.render_streams is None:
-            return self._step_on_current_stream(gather)
-        with torch.cuda.stream(self.render_streams[self.step_no % len(self.render_streams)]):
-            return self._step_on_current_stream(gather)
-
-    def _step_on_current_stream(self, gather=None):
-        gather = self.gather if gather is None else gather
-        lens, device, n_local = self.lens, self.device, self.n_local
-        slot = self.step_no % (self.DEPTH + 1)
-        out = self.out_bufs[slot]
-        self.step_no += 1
-        if not self.multi:
-            self.in_flight.append((lens.psf_lr(self.points, ks=self.ks, spp=self.spp, dp=DP, out=out[:n_local], defer=True),
-                                   out, slot, None))
-            self.settle(keep=self.DEPTH)
-            return out
-        if self.gather_done[slot] is not None:
-            # an earlier gather may still read this block on the comm stream
-            torch.cuda.current_stream(device).wait_event(self.gather_done[slot])
-            self.gather_done[slot] = None
-        pupil = self.sd.broadcast_pupil_points(lens, self.spp, group=self.pupil_group, stream=self.pupil_stream)
-        pend = self.sharded.render(self.points, pupil, out[:n_local], defer=True)
-        ready = None
-        if gather:
-            ready = torch.cuda.Event()
-            ready.record(torch.cuda.current_stream(device))
-        self.in_flight.append((pend, out, slot, ready))
-        self.settle(keep=3 if gather else self.DEPTH)   # gathers trail by three steps: a host hiccup on one rank stalls nobody
-        return out
-
-    def fence(self):
-        self.settle()
-        torch.cuda.synchronize(self.device)          # all streams of the device, the gather one too
-        if self.multi:
-            self.dist.barrier()
-            torch.cuda.synchronize(self.device)
-
-    def timed(self, k, gather=None):
-        """k steps between two fences; wall time = MAX over ranks."""
-        self.fence()
-        t0 = time.perf_counter()
-        for _ in range(k):
-            self.step(gather)
-        self.fence()
-        dt = time.perf_counter() - t0
-        if self.multi:
-            tmax = torch.tensor([dt], dtype=torch.float64, device=self.device)
-            self.dist.all_reduce(tmax, op=self.dist.ReduceOp.MAX)
-            dt = float(tmax.item())
-        return dt
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -983,10 +948,15 @@ def main():
                          "ends each step with the whole PSF volume; `value_no_gather` is reported "
                          "beside `value` either way)")
     ap.add_argument("--gather", action="store_true", help="(default; kept for older scripts)")
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
-                    help="N > 1: weak (default) = every rank renders its own 16384-point slab of a volume N times as "
-                         "deep; strong = the ONE volume of the workload (c2 / c4: 16384 points, c3: 65536) cut into N "
-                         "contiguous shards")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="strong",
+                    help="N > 1: strong (default; SURVEY.md §8e, north_star) = the ONE volume of the workload (c2 / c4: 16384 "
+                         "points, c3: 65536) cut into N contiguous shards -- config 2 on 8 GPUs is 2048 points per GPU and "
+                         "485 MB received per rank and step; weak = every rank renders its own 16384-point slab of a volume "
+                         "N times as deep (a 131072-point volume at N = 8, 3.9 GB received per rank and step)")
+    ap.add_argument("--detail-file", default=None,
+                    help="where the full record of the run goes (default: bench_detail.json beside bench.py); the ONE "
+                         "line on stdout is its compact form (< 4 KB)")
+    ap.add_argument("--verbose", action="store_true", help="also print the full record on stderr")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true",
                     help="default c2 run at N = 1: skip the `also` block (staged SoA chain, f1, c4: a few steps each)")
@@ -1006,6 +976,10 @@ def main():
                     help="--workload staged: `calls` times the call-by-call chain only (the profiling recipe: one kernel "
                          "per name), `both` also the chain through sdirt_trace2sensor / SDIRT_PSF_NORMALIZE")
     args = ap.parse_args()
+    global DETAIL_PATH
+    DETAIL_PATH = args.detail_file
+    if args.verbose:
+        os.environ["SDIRT_BENCH_VERBOSE"] = "1"
     if not (args.gpus > 1 and "WORLD_SIZE" not in os.environ):      # (the self-launching parent relays its children's output)
         claim_stdout()
     if args.workload in EXTRA_WORKLOADS:
@@ -1041,31 +1015,26 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     from sdirt_amd import dist as sd
+    from sdirt_amd.volume import VolumeStepper
     lens = build_lens(device, wl["lens"], wl["sensor_z"])
     strong = args.scaling == "strong"
-    # weak: the volume grows with the ranks (16 -- c3: 8 -- depth planes per GPU); strong: the workload's own volume
-    # (c3 is stated for a node of 8: 64 planes) whatever the number of ranks
-    points_all = volume_points((8 if args.workload.startswith("c3") else 1) if strong else world, args.workload)
+    # strong (default): the workload's own volume (c3 is stated for a node of 8: 64 planes) whatever the number of ranks;
+    # weak: the volume grows with the ranks (16 -- c3: 8 -- depth planes per GPU).  One GPU: the same thing.
+    points_all = volume_points((8 if args.workload.startswith("c3") and world > 1 else 1) if strong else world, args.workload)
     n_total = points_all.shape[0]
     a, b = sd.shard_bounds(n_total, world)[rank]
     points_local = points_all[a:b].to(device)
     n_local = b - a
     gather_default = world > 1 and not args.no_gather
-    # N > 1: consecutive steps alternate between two render streams (the next step's workgroups fill the low-occupancy end
-    # of the previous launch: 3.5 % of a 16384-point step, 7 % of a 2048-point one with the collectives in the loop,
-    # `--workload sweep`).  N = 1 keeps ONE stream: the headline's kernel time is then the time of a launch that has
+    # N > 1: consecutive steps alternate between two render streams (the next step's workgroups fill what is left of
+    # the previous launch's end).  N = 1 keeps ONE stream: the headline's kernel time is then the time of a launch that has
     # the chip to itself, which is what `roofline` and the committed rocprofv3 summaries are about.
     n_streams = 2 if world > 1 else 1
-    loop = VolumeLoop(lens, points_local, n_total, world, device, KS, SPP, gather_default, streams=n_streams)
-    step, settle, timed = loop.step, loop.settle, loop.timed
-    gather_events, gather_group, width, out_bufs = loop.gather_events, loop.gather_group, loop.width, loop.out_bufs
-
-    # one-off initialisation, like loading the library: the first call on a lens discovers the
-    # Newton trip tables (a launch with 10 trips everywhere, then the verified table); they are
-    # lens state from then on.  Done before the W warm-up steps so that W = 0 still times K
-    # steady-state steps.
-    step(gather_default)
-    settle()
+    # every rank draws the same pupil uniforms from its own generator (VolumeStepper checks that they do)
+    torch.manual_seed(0)
+    # one-off initialisation, like loading the library: the stepper's first call on a lens discovers the Newton trip
+    # tables (a launch with 10 trips everywhere, then the verified table); they are lens state from then on
+    loop = VolumeStepper(lens, points_local, n_total, KS, SPP, DP, gather=gather_default, streams=n_streams, time_steps=True)
     # Everything the run needs is built: park the interpreter's heap in the permanent generation.  A full collection of
     # torch's heap takes 40-55 ms (measured: it strikes ~150 ms after the first launch, i.e. inside the timed window of
     # a --warmup 5 --steps 20 run, idles the GPU and costs it its clock: tools/clock_ramp.py); after the freeze the
@@ -1074,55 +1043,65 @@ def main():
     gc.collect()
     gc.freeze()
     for _ in range(args.warmup):
-        step(gather_default)
-    lens.kernel_events = {}
-    relaunch0 = lens.trips.relaunches
-    del gather_events[:]
-    dt = timed(args.steps, gather_default)
-    relaunches = lens.trips.relaunches - relaunch0
-    # the all-gathers of the timed steps as the comm stream saw them (start = the shards are final and the previous
-    # gather has left the stream, end = every rank's shards have arrived here); MAX over ranks like the wall time
-    gather_ms = None
-    if gather_default and gather_events:
-        gm = torch.tensor([float(np.mean([a_.elapsed_time(b_) for a_, b_ in gather_events]))], dtype=torch.float64, device=device)
+        loop.step()
+    loop.fence()
+    loop.reset_counters()
+    relaunch0 = loop.relaunches
+    dt = loop.timed(args.steps)
+    relaunches = loop.relaunches - relaunch0
+    k_event_ms = loop.kernel_ms()
+    host_us = loop.t_step / args.steps * 1e6
+    # the all-gathers of the timed steps as the comm stream saw them (start = the shard is final and the previous
+    # gather has left the stream, end = every rank's shard has arrived here); MAX over ranks like the wall time
+    gather_ms = loop.gather_ms() if gather_default else None
+    if gather_ms is not None:
+        gm = torch.tensor([gather_ms], dtype=torch.float64, device=device)
         dist.all_reduce(gm, op=dist.ReduceOp.MAX)
         gather_ms = float(gm.item())
 
-    ev = lens.kernel_events
-    lens.kernel_events = None
-    k_ms = {k: float(np.mean([e0.elapsed_time(e1) for e0, e1 in v])) for k, v in ev.items()}
-    n_launch = {k: len(v) for k, v in ev.items()}
-
     # the same K steps without the all-gather (N > 1), and a loop long enough for the clocks to
     # settle (the K-step region lasts a fraction of a second)
-    dt_ng = timed(args.steps, False) if gather_default else None
+    dt_ng = None
+    if gather_default:
+        loop.gather = False
+        dt_ng = loop.timed(args.steps)
+        loop.gather = True
     k_sus = dt_sus = None
     if args.sustain_seconds > 0:
         k_sus = max(args.steps, int(math.ceil(args.sustain_seconds / (dt / args.steps))))
-        dt_sus = timed(k_sus, gather_default)
+        dt_sus = loop.timed(k_sus)
+    pupil_last = None
+    if world == 1 and not args.no_cpu_baseline:
+        # the pupil points of the GPU leg's last step, as the device mapped them (they stand in the slot's scratch)
+        s_ = loop._slots[(loop.steps - 1) % len(loop._slots)]
+        xy = s_.scratch[loop.scratch_bytes - 4 * loop.n_u:].view(torch.float32).clone()
+        pupil_last = (xy[:SPP], xy[SPP:2 * SPP], xy[2 * SPP:2 * SPP + 2048], xy[2 * SPP + 2048:])
+    tables = [[int(v) for v in t_] for t_ in loop.tables]
 
     # N = 1: the same K steps once more with consecutive steps on two alternating streams (what a pipelined consumer of
-    # batch after batch gets: the next launch's workgroups fill the low-occupancy end of the previous one)
+    # batch after batch gets: the next launch's workgroups fill what is left of the previous launch's end)
     dt_two = None
     if world == 1:
-        loop.use_streams(2)
+        del loop
+        torch.cuda.empty_cache()
+        loop2 = VolumeStepper(lens, points_local, n_total, KS, SPP, DP, streams=2)
         for _ in range(max(args.warmup, 2)):
-            step(False)
-        dt_two = timed(args.steps, False)
-        loop.use_streams(1)
+            loop2.step()
+        dt_two = loop2.timed(args.steps)
+        del loop2
+        torch.cuda.empty_cache()
 
     if rank == 0:
         rays = n_total * SPP * args.steps
         # algorithmic HBM bytes of ONE k_psf_lr launch: read the points,
         # centres and pupil samples once, write the L and R tiles once.
         alg_bytes = n_local * (12 + 8) + (SPP + 2048) * 8 + 2 * n_local * KS * KS * 4
-        dom = "psf_lr_centered" if "psf_lr_centered" in k_ms else "psf_lr"
-        k_events = k_ms[dom]
+        dom = "psf_call"
+        k_ms = {dom: k_event_ms}
         if n_streams > 1:
             # two launches overlap on the chip: an event pair spans both.  What a launch costs the step is the step itself
             # (without the gather): that is the duration the roofline figures and `gather_bound` are computed with.
-            k_ms = dict(k_ms)
-            k_ms[dom] = min(k_events, (dt_ng if dt_ng is not None else dt) / args.steps * 1e3)
+            k_ms[dom] = min(k_event_ms, (dt_ng if dt_ng is not None else dt) / args.steps * 1e3)
         ach = alg_bytes / (k_ms[dom] * 1e-3) / 1e9
         traffic = valu = None
         counters = pmc_counters(args.workload)
@@ -1168,31 +1147,38 @@ def main():
                                    "file": counters["file"], "collected": counters.get("collected"),
                                    "commit": counters.get("commit"),
                                    "source_hash": counters.get("source_hash"), "source_hash_now": source_hash()}}
+        cfg_name = {"c2": "BASELINE config 2", "c3": "BASELINE config 3", "c3k65": "BASELINE config 3 on 65x65 grids",
+                    "c4": "BASELINE config 4"}[args.workload]
+        gz_total = (64 if args.workload.startswith("c3") and world > 1 else GRID_Z) if strong else GRID_Z * world
         res = {
             "metric": f"rays/sec {wl['lens']} {KS}x{KS} DP-PSF @{SPP}spp", "value": rays / dt,
             "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak",
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "world_size": dist.get_world_size() if world > 1 else 1,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "psfs_per_sec": n_total * args.steps / dt,
             "backend": backend,
-            "config": {"workload": wl["desc"].format(gz=(64 if args.workload.startswith("c3") else GRID_Z) if strong else GRID_Z * world)
-                                   + (f" cut into {world} shards" if strong and world > 1 else "")
+            "config": {"workload": f"{cfg_name}: " + wl["desc"].format(gz=gz_total)
+                                   + (f" = {n_total} points, ONE volume cut into {world} contiguous shards" if strong and world > 1 else
+                                      (f" = {n_total} points (weak scaling: a slab of {n_local} per GPU)" if world > 1 else f" = {n_total} points"))
                                    + f", {n_local} points/GPU, {SPP} spp (+2048 chief-ray "
                                    f"rays/point), {KS}x{KS} L+R PSFs, lambda 0.589um, focus 1 m F/4",
                        "name": args.workload,
-                       "points_per_gpu": n_local, "spp": SPP, "ks": KS,
+                       "points_per_gpu": n_local, "points_total": n_total, "spp": SPP, "ks": KS,
                        "parallelism": f"points sharded over {world} GPU(s)"
                                       + ("" if world == 1 else
-                                         ", shared pupil samples (48 KB broadcast) and batch-global "
+                                         ", every rank draws the same pupil samples, batch-global "
                                          "Newton trip check (mask all-reduce) per step")
-                                      + (" + RCCL all-gather of the PSF volume to every rank"
+                                      + (" + ONE RCCL all-gather of the [N/world, 2, ks, ks] blocks to every rank"
                                          if gather_default else ""),
                        "gather": bool(gather_default),
                        "newton_trip_policy": lens.trip_policy,
+                       "trip_tables": tables,
                        "relaunches_in_timed_region": relaunches},
-            "kernels_ms": k_ms, "kernel_launches": n_launch, "render_streams": n_streams,
-            "kernel_event_ms": k_events,
+            "kernels_ms": k_ms, "render_streams": n_streams, "kernel_ms": k_ms[dom],
+            "kernel_event_ms": k_event_ms, "host_us_per_step": host_us,
+            "kernel_ms_what": "HIP events on the render stream around the step's ONE library call (sdirt_psf_call: 48 KB upload, "
+                              "one pupil-mapping launch, k_psf_lr); the committed rocprofv3 kernel trace is k_psf_lr alone",
             # what bounds the kernel is its vector ALU time (profiles/r03/k_psf_lr_sites.txt):
             # `valu_flops` is the fraction that says something; achieved / peak / frac / traffic are the
             # mandated HBM figures (0.7 % by construction: 8 algorithmic bytes against 3.4 kflop per ray)
@@ -1200,8 +1186,7 @@ def main():
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_stale": bool(counters["stale"]) if counters else None,
                          "valu_flops": valu_flops,
-                         "kernel": "k_psf_lr<R,small-r,Lean,CENTER> (chief-ray pass + primary pass "
-                                   "of a point in one workgroup)",
+                         "kernel": "k_psf_lr<R,small-r,Lean,CENTER> (chief-ray + primary pass of a point in one workgroup)",
                          "algorithmic_bytes_per_launch": alg_bytes, "valu_issue": valu,
                          # the committed rocprofv3 --kernel-trace --stats of this command (carried, like the
                          # counters): its median and its average without the two table-discovery launches a
@@ -1215,15 +1200,16 @@ def main():
                                  "issue by construction (%s VALU instr per traced ray vs %.2f "
                                  "algorithmic bytes), DESIGN.md §3"
                                  % ("%.0f" % (valu["wave_instructions_per_launch"] * 64 / (n_local * (SPP + 2048)))
-                                    if valu else "~5 k", alg_bytes / (n_local * (SPP + 2048)))},
+                                    if valu else "~5 k", alg_bytes / max(1, n_local * (SPP + 2048)))},
         }
         if dt_ng is not None:
             res["value_no_gather"] = rays / dt_ng
             res["ms_per_step_no_gather"] = dt_ng / args.steps * 1e3
             gb = 2 * (n_total - n_local) * KS * KS * 4 / 1e9      # received per rank and step
             compute_ms = k_ms[dom]
+            width = max(b_ - a_ for a_, b_ in sd.shard_bounds(n_total, world))
             res["gather"] = {"algo": os.environ.get("SDIRT_GATHER_ALGO", "allgather"),
-                             "backend": dist.get_backend(gather_group), "world_size": dist.get_world_size(gather_group),
+                             "backend": dist.get_backend(), "world_size": dist.get_world_size(),
                              "gb_received_per_rank_per_step": gb, "collectives_per_step": 1,
                              "block": f"[{width}, 2, {KS}, {KS}] fp32 per rank, rendered in place (SDIRT_PSF_INTERLEAVED)",
                              "ms": gather_ms, "GBps_received_per_rank": gb / (gather_ms * 1e-3) if gather_ms else None,
@@ -1240,9 +1226,7 @@ def main():
             res["ms_per_step_sustained"] = dt_sus / k_sus * 1e3
             res["value_sustained"] = n_total * SPP * k_sus / dt_sus
             res["sustained_steps"] = k_sus
-        pupil_last = lens.last_pupil_points
         if world == 1 and args.workload == "c2" and not args.no_also:
-            del out_bufs[1:]                    # 4.4 GB of PSF buffers the side lines do not need
             res["also"] = also_block(args, lens, device)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(lens, points_all, pupil_last)

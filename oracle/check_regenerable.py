@@ -43,7 +43,13 @@ def regenerate(out_dir, jobs=8):
     while todo or running:
         while todo and len(running) < max(1, jobs):
             running.append(start(todo.pop(0)))
-        finish(*running.pop(0))
+        done = [r for r in running if r[2].poll() is not None]
+        if not done:
+            time.sleep(0.2)
+            continue
+        for r in done:
+            running.remove(r)
+            finish(*r)
     return took
 
 

@@ -23,10 +23,13 @@ GEO_SPP = 2048                           # basics.py:29
 EPSILON = 1e-9                           # basics.py:35
 MAXT = 1e5                               # basics.py:33
 
-#: True = every Ray carries `obliq` from its construction on, as the reference's does (basics.py:240).  Default:
-#: the array is created by the first read or write of `ray.obliq` (before the bundle is traced) -- a bundle that
-#: nobody asked for its obliquity factor moves 28 instead of 32 bytes per ray through every staged kernel.
-TRACK_OBLIQ = False
+#: True (default) = every Ray a CALLER makes -- Ray(...), Ray.from_normalized, Lensgroup.sample_from_points and the other
+#: public samplers -- carries `obliq` from its construction on, as the reference's does (basics.py:240), and `ray.obliq`
+#: can be read after any trace.  The bundles the package makes for ITSELF (the staged PSF chain for grids above 141
+#: pixels: Ray.empty(obliq=False)) never carry it: nothing on the PSF path reads it, and a bundle without it moves 28
+#: instead of 32 bytes per ray through every staged kernel.  False = callers' rays are lean as well: the array is
+#: created by the first read or write of `ray.obliq`, which must then come BEFORE the trace.
+TRACK_OBLIQ = True
 
 _AIRLIKE = ("vacuum", "air", "occluder")
 
@@ -163,7 +166,7 @@ class Ray:
         return self
 
     # -- construction helpers -------------------------------------------------
-    def _init_empty(self, shape, wvln, device):
+    def _init_empty(self, shape, wvln, device, track=None):
         require_gpu(device)
         self.shape = tuple(int(s) for s in shape)
         self.numel = int(np.prod(self.shape)) if len(self.shape) else 1
@@ -175,15 +178,16 @@ class Ray:
         # been traced without it (the products of surfaces.py:674 were not kept)
         self._ob = None
         self._ob_lost = False
-        if TRACK_OBLIQ:
+        if TRACK_OBLIQ if track is None else track:
             self._ob = torch.ones(max(self.numel, 1), dtype=torch.float32, device=self.device)
 
     @classmethod
     def empty(cls, shape, wvln=DEFAULT_WAVE, device=None, obliq=False):
-        """An uninitialised bundle; obliq=True: with an (uninitialised) obliquity array as well."""
+        """An uninitialised bundle WITHOUT an obliquity array (whatever TRACK_OBLIQ says: this is the constructor of the
+        package's own bundles); obliq=True: with an (uninitialised) one."""
         self = cls.__new__(cls)
-        self._init_empty(shape, wvln, device if device is not None else default_device())
-        if obliq and self._ob is None:
+        self._init_empty(shape, wvln, device if device is not None else default_device(), track=False)
+        if obliq:
             self._ob = torch.empty(max(self.numel, 1), dtype=torch.float32, device=self.device)
         return self
 

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 
@@ -58,16 +59,22 @@ inline int device_cus(int* out)
     return SDIRT_OK;
 }
 // Opt a kernel in to more dynamic LDS than the default 48 KiB allowance (up to the CU's 160 KiB): once per kernel
-// instantiation and device, not once per launch.
+// instantiation, device and size -- the largest size asked for so far is remembered per device, a later launch that
+// needs more sets the attribute again.  (Concurrent host threads: the attribute call is idempotent, the remembered
+// size only ever grows.)
 template <auto Kernel>
 inline int allow_large_lds(int bytes = 160 * 1024 - 1024)
 {
-    static bool done[kMaxDevices] = {};
+    static std::atomic<int> allowed[kMaxDevices] = {};
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
-    if (dev >= 0 && dev < kMaxDevices && done[dev]) return SDIRT_OK;
+    const bool known = dev >= 0 && dev < kMaxDevices;
+    if (known && allowed[dev].load(std::memory_order_acquire) >= bytes) return SDIRT_OK;
     HIP_TRY(hipFuncSetAttribute((const void*)Kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    if (dev >= 0 && dev < kMaxDevices) done[dev] = true;
+    if (known) {
+        int seen = allowed[dev].load(std::memory_order_relaxed);
+        while (seen < bytes && !allowed[dev].compare_exchange_weak(seen, bytes, std::memory_order_release)) {}
+    }
     return SDIRT_OK;
 }
 

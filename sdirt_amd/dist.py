@@ -222,11 +222,15 @@ class ShardedPSF:
             u = broadcast_pupil_points(self.lens, spp, group=self.group)
         else:
             u = broadcast_uniforms(spp, self.device, group=self.group)
-        if self.ks is None or not gather or self.world == 1:
+        from . import _lib
+        # grids above SDIRT_MAX_KS go through the staged chain, which renders two tensors (Lensgroup.psf_lr refuses
+        # out=block for them -- and a rank that raises before the collective would leave its peers hanging in it)
+        two_tensors = self.ks is None or (self.lens is not None and self.ks > _lib.MAX_KS)
+        if two_tensors or not gather or self.world == 1:
             L, R = self.render(points[a:b], u)
             if not gather or self.world == 1:
                 return L, R
-            block = torch.stack((L, R), dim=1)              # (a CPU stand-in renders two tensors)
+            block = torch.stack((L, R), dim=1)              # (a CPU stand-in, or the staged chain, renders two tensors)
         else:
             # the kernel writes the shard straight into the block the collective sends: no torch.stack
             block = self.shard_buffer(n_total)

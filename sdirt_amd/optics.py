@@ -20,7 +20,7 @@ import weakref
 import numpy as np
 import torch
 
-from . import _hostrng, _lib
+from . import _hostrng, _lib, basics
 from .basics import DEFAULT_WAVE, DEPTH, GEO_SPP, WAVE_RGB, Ray, dptr, stream_ptr
 from .newton import NEWTON_MAXITER, TripPlanner
 from .surfaces import Aspheric
@@ -410,6 +410,8 @@ class Lensgroup:
         _lib.check(_lib.lib().sdirt_sample_rays(dptr(po), po.shape[0], dptr(x2), dptr(y2), spp,
                                                 float(pupilz), ray.c_rays(),
                                                 stream_ptr(self.device)))
+        if basics.TRACK_OBLIQ:                               # a caller's bundle: readable obliq, as the reference's (basics.py:240)
+            ray.obliq = torch.ones((), device=self.device)
         return ray
 
     def _staging(self, spp, depth=8, rows=2):

@@ -35,7 +35,7 @@ from .basics import DEFAULT_WAVE, GEO_SPP
 
 class _Slot:
     __slots__ = ("out", "u_host", "scratch", "ctl_host", "lanes", "ev_kernel", "ev_read", "ev_gather", "args", "lane_args",
-                 "stream", "k0", "k1")
+                 "stream", "k0", "k1", "used")
 
 
 class VolumeStepper:
@@ -87,10 +87,11 @@ class VolumeStepper:
         self._main = torch.cuda.current_stream(dev)
         self.render_streams = [torch.cuda.Stream(dev) for _ in range(streams)] if streams > 1 else [self._main]
         self.rb_stream = torch.cuda.Stream(dev)
-        self.comm_stream = torch.cuda.Stream(dev) if self.gather else None
+        # (`gather` may be switched between two fences: the stream and the communicator exist whenever the batch is sharded)
+        self.comm_stream = torch.cuda.Stream(dev) if self.multi else None
         # communicators of their own: the collectives of one process group share one internal stream
         self.mask_group = dist.new_group() if self.multi else None
-        self.gather_group = dist.new_group() if self.gather else None
+        self.gather_group = dist.new_group() if self.multi else None
         with torch.cuda.device(dev):
             self.po = lens._points_to_object_now(self.points) if self.n_local else torch.empty((0, 3), device=dev)
         self.centers = torch.empty((max(self.n_local, 1), 2), dtype=torch.float32, device=dev)
@@ -152,6 +153,7 @@ class VolumeStepper:
             s.k0 = torch.cuda.Event(enable_timing=True) if self.time_steps else None
             s.k1 = torch.cuda.Event(enable_timing=True) if self.time_steps else None
             s.stream = self.render_streams[len(self._slots) % len(self.render_streams)]
+            s.used = False
             self._bind(s)
             self._slots.append(s)
 
@@ -180,6 +182,7 @@ class VolumeStepper:
             r.wait_event(s.ev_gather)
             s.ev_gather = None
         _hostrng.rand_into(s.u_host)
+        s.used = True
         if s.k0 is not None:
             s.k0.record(r)
         _lib.check(self.h.sdirt_psf_call(*s.args))
@@ -309,7 +312,17 @@ class VolumeStepper:
         return self._volume
 
     def kernel_ms(self):
-        """Mean HIP-event time of the settled steps' library call (upload of 48 KB + pupil mapping + fused kernel) on
-        its render stream, since the last call of this method (time_steps=True)."""
-        ev = [(s.k0, s.k1) for s in self._slots if s.k0 is not None and s.k1.query()]
+        """Mean HIP-event time of the slots' most recent library call (upload of 48 KB + pupil mapping + fused kernel)
+        on its render stream (time_steps=True; after fence()).  With two render streams consecutive launches overlap on
+        the chip and a pair spans both."""
+        ev = [(s.k0, s.k1) for s in self._slots if s.k0 is not None and s.used and s.k1.query()]
         return float(np.mean([a.elapsed_time(b) for a, b in ev])) if ev else None
+
+    def gather_ms(self):
+        """Mean HIP-event time of the all-gathers since the last call (time_steps=True, after fence()), or None."""
+        ev, self.gather_events = self.gather_events, []
+        return float(np.mean([a.elapsed_time(b) for a, b in ev])) if ev else None
+
+    def reset_counters(self):
+        self.t_step = self.t_wait = 0.0
+        self.gather_events = []

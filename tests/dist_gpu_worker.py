@@ -79,6 +79,38 @@ def main():
             l2.psf_lr(points[a:b], ks=ks, spp=spp, dp=dp)
             own.append({str(k): v.tolist() for k, v in l2.trips.cache.items()})
         out["own_tables_differ"] = any(o != own[0] for o in own[1:])
+    # ---- the render loop of a sharded volume (sdirt_amd.volume.VolumeStepper): ONE library call per step, every rank
+    # draws the same uniforms, masks OR-ed over the ranks in front of the device-side trip rule, one all-gather per step
+    from sdirt_amd.volume import VolumeStepper
+    a, b = sd.shard_bounds(n_pts, world)[rank]
+    torch.manual_seed(99)                                   # the same seed on every rank
+    lens_s = make_lens("rf50mm", "cuda:0")
+    st = VolumeStepper(lens_s, points[a:b], n_pts, ks, spp, dp, gather=True, depth=2)
+    vols = []
+    for _ in range(3):
+        st.step()
+        st.fence()
+        vols.append(st.volume().clone())
+    out["stepper_relaunches"] = st.relaunches
+    if rank == 0:
+        solo = make_lens("rf50mm", "cuda:0")
+        torch.manual_seed(99)
+        worst = 0.0
+        for v in vols:
+            Ls, Rs = solo.psf_lr(points, ks=ks, spp=spp, dp=dp)
+            assert tuple(v.shape) == (n_pts, 2, ks, ks)
+            worst = max(worst, float((v[:, 0] - Ls).abs().max()), float((v[:, 1] - Rs).abs().max()))
+        out["stepper_max_abs_diff"] = worst
+        assert worst == 0.0, worst            # float64 tiles at ks 33: the sharded loop equals the solo calls bit for bit
+    # ranks whose generators have diverged are told so instead of rendering different batches
+    torch.manual_seed(5 + rank)
+    try:
+        st.step()
+        st.fence()
+        out["divergence_detected"] = False
+    except RuntimeError as e:
+        out["divergence_detected"] = "different pupil uniforms" in str(e)
+    assert out["divergence_detected"]
     print(json.dumps(out), flush=True)
     dist.barrier()
     dist.destroy_process_group()

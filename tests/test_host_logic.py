@@ -528,14 +528,51 @@ def test_bench_keeps_stdout_for_its_one_json_line(tmp_path):
     the descriptor stdout had at start-up."""
     import subprocess
     import sys
-    code = ("import os, sys, json; sys.path.insert(0, %r); import bench; bench.claim_stdout(); "
-            "os.write(1, b'RCCL version : banner\\n'); print('a stray print'); bench.emit_line({'metric': 'm', 'value': 1.5}); "
-            "os.write(1, b'more noise\\n')" % ROOT)
+    detail = str(tmp_path / "detail.json")
+    code = ("import os, sys, json; sys.path.insert(0, %r); import bench; bench.DETAIL_PATH = %r; bench.claim_stdout(); "
+            "os.write(1, b'RCCL version : banner\\n'); print('a stray print'); "
+            "bench.emit_line({'metric': 'm', 'value': 1.5, 'kernels': {'a long table': list(range(3000))}}); "
+            "os.write(1, b'more noise\\n')" % (ROOT, detail))
     p = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
-    assert len(lines) == 1 and __import__("json").loads(lines[0]) == {"metric": "m", "value": 1.5}, p.stdout
+    import json
+    assert len(lines) == 1 and json.loads(lines[0]) == {"metric": "m", "value": 1.5, "config": {}, "detail": detail}, p.stdout
     assert "RCCL version : banner" in p.stderr and "a stray print" in p.stderr and "more noise" in p.stderr
+    # the full record went to the detail file
+    assert json.load(open(detail))["kernels"]["a long table"][-1] == 2999
+
+
+def test_the_one_json_line_stays_under_4_kb_and_keeps_the_evidence():
+    """a 16 KB line lost its `also` values and the VALU fractions in the driver's `parsed`.  bench.compact()
+    on the newest committed full record of the default run (profiles/rNN/bench_c2_detail.json): under 4000 bytes, the
+    contract's keys whole, the roofline fractions that say something as flat scalars, one triple per side workload,
+    one row per shard size."""
+    import glob
+    import json
+    import bench
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "bench_c2_detail.json")))
+    assert files, "no committed full record of the default bench run"
+    full = json.load(open(files[-1]))
+    assert len(json.dumps(full)) > 8000                   # (the record really is the long form)
+    line = bench.compact(full)
+    text = json.dumps(line)
+    assert len(text) < bench.LINE_LIMIT <= 4000, len(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert line["config"]["workload"].startswith("BASELINE config 2") and "model" not in line["config"]
+    rf = line["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "valu_flops_frac", "valu_issue_frac"):
+        assert k in rf and not isinstance(rf[k], dict), k
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-6 and 0.1 < rf["valu_flops_frac"] < 0.5
+    cb = line["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
+    assert {"f1", "c4", "c3", "tcp", "c5", "staged_ks65"} <= set(line["also_summary"])
+    assert all(len(v) == 3 for v in line["also_summary"].values() if isinstance(v, list))
+    assert {"single_gpu_loop_16384", "world8_shard_2048", "world8_shard_2048_two_streams"} <= set(line["sweep_summary"])
+    eff = line["sweep_columns"].index("efficiency")
+    assert all(0.0 < row[eff] <= 1.03 for row in line["sweep_summary"].values())      # physical figures only
 
 
 def test_spp_slices_is_host_arithmetic_with_an_explicit_cu_count():

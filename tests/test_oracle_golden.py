@@ -330,17 +330,19 @@ def test_draw_psf_radial_fields(oracle):
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="needs the reference checkout (build container only)")
 def test_the_fixtures_regenerate_byte_for_byte(tmp_path):
-    """oracle/gen_golden.py, run afresh against the reference, reproduces every file it owns under tests/golden/ byte for
-    byte -- lens_state_*.json included: the reference's paraxial pupil estimate (an fp32 lstsq that lands on different
-    values run to run, oracle/ref_pupil_variation.py) is frozen at the committed value, and the fresh estimate is checked
-    to lie within that spread (the generator asserts it).  Build container only; a few seconds."""
-    import filecmp
-    import subprocess
+    """ALL ten generators under oracle/, run afresh against the reference into an EMPTY directory (gen_golden.py first, the
+    other nine side by side: oracle/check_regenerable.py), reproduce every one of the 37 files under tests/golden/ byte
+    for byte.  The reference's run-to-run-unstable scalars -- the paraxial pupils (an fp32 lstsq that lands on different
+    values run to run, oracle/ref_pupil_variation.py) and hfov / foclen / fnum, which it computes from fresh estimates --
+    are frozen at oracle/frozen_lens_scalars.json (kept OUTSIDE tests/golden/: the fixtures are reproduced from those
+    numbers, not from themselves), and every generator asserts that this run's fresh values lie within the reference's
+    own spread of them.  Build container only; ~2.5 minutes, nearly all of it the reference's analysis_rms (F26)."""
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    subprocess.check_call([sys.executable, os.path.join(root, "oracle", "gen_golden.py"), "--out", str(tmp_path)],
-                          stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
-    names = sorted(os.listdir(tmp_path))
-    assert len(names) >= 14 and "lens_state_rf50mm.json" in names
-    different = [n for n in names if not filecmp.cmp(tmp_path / n, os.path.join(root, "tests", "golden", n), shallow=False)]
-    assert not different, different
+    sys.path.insert(0, os.path.join(root, "oracle"))
+    import check_regenerable as cr
+    took = cr.regenerate(str(tmp_path), jobs=min(8, os.cpu_count() or 1))
+    assert len(took) == 10
+    names, same, missing = cr.compare(str(tmp_path))
+    assert len(names) == 37 and "lens_state_rf50mm_variant.json" in names and "f11_rf50_variant_pts4.npz" in names
+    assert sorted(set(names) - set(same)) == [] and missing == [], (sorted(set(names) - set(same)), missing)

@@ -1,12 +1,12 @@
 #!/bin/bash
 # Profiling recipe for the bench workloads (run on the GPU box through gpurun):
-#   tools/profile_bench.sh <workload: c2|c3|c4> <commit> [round-dir, default r05]
+#   tools/profile_bench.sh <workload: c2|c3|c4> <commit> [round-dir, default r06]
 # Pass 1: kernel trace + stats of `python3 bench.py` (the same command the driver runs, minus the
 # CPU baseline).  Passes 2-4: PMC counters, each group in its own run (never trace domains
 # together with --pmc on this pool).  Output: gpurun_out/prof_<round>_<workload>/ and the condensed
 # gpurun_out/prof_<round>_<workload>/pmc_<workload>.json that bench.py reads from profiles/<round>/.
 set -u
-WL=${1:-c2}; COMMIT=${2:-unknown}; RND=${3:-r05}
+WL=${1:-c2}; COMMIT=${2:-unknown}; RND=${3:-r06}
 OUT=gpurun_out/prof_${RND}_${WL}
 mkdir -p "$OUT"
 export TMPDIR=/tmp

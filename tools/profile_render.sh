@@ -2,7 +2,7 @@
 # Kernel trace + HBM counters of the f1 workload (per-pixel DP-PSF convolution, bench.py --workload f1):
 #   tools/profile_render.sh <commit> [round-dir, default r03]   -> gpurun_out/prof_<round>_f1/summary_render.json
 set -u
-COMMIT=${1:-unknown}; RND=${2:-r03}
+COMMIT=${1:-unknown}; RND=${2:-r06}
 OUT=gpurun_out/prof_${RND}_f1
 mkdir -p "$OUT"
 export TMPDIR=/tmp
@@ -11,6 +11,11 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $CMD > "
 CMD="python3 bench.py --workload f1 --steps 5 --warmup 2 --sustain-seconds 0"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- $CMD > "$OUT/pmc_fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- $CMD > "$OUT/pmc_write.log" 2>&1
+# what the kernel does with its time beside the loads (round 6: why 0.70 of 8 TB/s when its read pattern alone reaches 0.87)
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES \
+    --output-format csv -d "$OUT/pmc_a" -- $CMD > "$OUT/pmc_a.log" 2>&1
+rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS \
+    --output-format csv -d "$OUT/pmc_b" -- $CMD > "$OUT/pmc_b.log" 2>&1
 python3 tools/summarize_prof.py "$OUT" k_local_psf_render > "$OUT/summary.json"
 python3 - "$OUT" "$COMMIT" <<'PY'
 import json, sys, time
@@ -26,7 +31,8 @@ d = {"workload": "f1", "commit": commit, "source_hash": bench.source_hash(),
      "collected": time.strftime("%Y-%m-%d %H:%M UTC", time.gmtime()), "kernel": name,
      "kernel_trace_avg_us": t["avg_us"], "kernel_trace_median_us": t["median_us"], "calls": t["calls"],
      "algorithmic_bytes": alg, "hbm_bytes_counted": hbm, "traffic_over_algorithmic": hbm / alg,
-     "achieved_GBs_avg": alg / (t["avg_us"] * 1e-6) / 1e9, "frac_of_8TBs": alg / (t["avg_us"] * 1e-6) / 8e12}
+     "achieved_GBs_avg": alg / (t["avg_us"] * 1e-6) / 1e9, "frac_of_8TBs": alg / (t["avg_us"] * 1e-6) / 8e12,
+     "counters_last_dispatch": {k: v["last"] for k, v in p.items() if k not in ("FETCH_SIZE", "WRITE_SIZE")}}
 json.dump(d, open(f"{out}/summary_render.json", "w"), indent=1)
 print(json.dumps(d))
 PY
