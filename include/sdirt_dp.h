@@ -134,6 +134,15 @@ typedef struct sdirt_dp_params {
 /* sdirt_psf_call only (one workgroup per point): leave the trip rule unevaluated -- the masks of a rank of a sharded
  * batch say nothing before they are OR-ed with the other ranks' (sdirt_ctl_to_lanes, all-reduce, sdirt_ctl_from_lanes). */
 #define SDIRT_PSF_NO_VERIFY 128u /* (needs SDIRT_PSF_ZERO_CTL) */
+/* sdirt_psf_lr / _centered / sdirt_psf_call (one workgroup per point): run-to-run IDENTICAL grids also on 50 to 70 pixels
+ * (L + R; L alone: up to 99) -- BASELINE config 2's 65 x 65.  A point's grids are summed in LDS: in float64 (rounded to
+ * fp32 once: the arrival order of the atomics cannot matter) wherever four workgroups per CU have room for such tiles,
+ * ks <= 49; above, the default is fp32 tiles, whose sums differ in the last bits from run to run.  With this flag the
+ * tiles stay float64 and the workgroups get 1024 threads, two per CU: +0.5 % time (profiles/r05/ab_tiles.txt).  The
+ * chief-ray centroid is then reduced over 1024 instead of 512 partial sums (float64; the fp32 centre it rounds to may
+ * differ from the default path's in the last bit).  SDIRT_ERR_UNSUPPORTED beyond ks 70 / 99, for r > 0.5 and when the
+ * spp axis is cut (sdirt_psf_spp_slices > 1: partial grids meet in global float atomics). */
+#define SDIRT_PSF_DETERMINISTIC 256u
 
 /* ---- library ------------------------------------------------------------ */
 int sdirt_abi_version(void);

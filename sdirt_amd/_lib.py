@@ -25,6 +25,7 @@ PSF_ONE_ROUND = 16
 PSF_INTERLEAVED = 32
 PSF_ZERO_CTL = 64
 PSF_NO_VERIFY = 128
+PSF_DETERMINISTIC = 256
 CTL_STATUS, CTL_ANY_VALID, CTL_TRIPS2, CTL_MASKS, CTL_WORDS = 0, 1, 16, 64, 320
 CTL_LANES = 1411
 CTL_UNIFORM_SUM = 2

@@ -589,8 +589,10 @@ struct TripSet {
 // of the CU's LDS per wave instruction whatever the addresses, profiles/r04/lds_atomic_bench.txt); double:
 // ds_add_f64 (17-33 cycles), the sum rounded to fp32 once on the way out like k_forward_integral_tiles -- chosen by
 // launch_psf whenever the double tiles still leave room for four workgroups per CU (L + R: ks <= 49).
-template <bool HAVE_R, bool BIG, class HotMath, bool CENTER, class ACC>
-__global__ void __launch_bounds__(kFused, BIG ? 4 : 8)
+// THREADS = 1024 (SDIRT_PSF_DETERMINISTIC on grids of 50 to 70 pixels): double tiles in workgroups of 16 waves, two per
+// CU -- the same 8 waves per SIMD; a workgroup waits at its barriers for the slowest of 16 waves: +0.5 % (profiles/r05/ab_tiles.txt).
+template <bool HAVE_R, bool BIG, class HotMath, bool CENTER, class ACC, int THREADS = kFused>
+__global__ void __launch_bounds__(THREADS, BIG ? 4 : 8)
 k_psf_lr(SplatBlock sb /* kernarg offset 0 */, TripSet trips /* 64 */, TripSet trips_c /* 64 + 64 W */,
          LensSet lens_set, int K, const float* __restrict__ po, const float* __restrict__ x2,
          const float* __restrict__ y2, int S, int nsplit, int chunk, float pz, float zs, int ks, int pstride, float tr,
@@ -601,7 +603,7 @@ k_psf_lr(SplatBlock sb /* kernarg offset 0 */, TripSet trips /* 64 */, TripSet t
     ACC* __restrict__ tiles = reinterpret_cast<ACC*>(tiles_raw);    // [L | R] ks*ks each
     if (!CENTER && sa.gate && sa.gate[kCtlStatus] == 0u) return;    // round 2 of a verified call, nothing to redo
     __shared__ uint32_t lds_mask[SDIRT_MAX_SURFACES];
-    __shared__ float red[kFused / 64];
+    __shared__ float red[THREADS / 64];
     __shared__ float c_sh[2];
     const int tile = ks * ks;
     ACC* tl_ = tiles;
@@ -612,8 +614,8 @@ k_psf_lr(SplatBlock sb /* kernarg offset 0 */, TripSet trips /* 64 */, TripSet t
     const int N = gridDim.x / nsplit;
     // the last generation of the launch issues by the passes a workgroup still has to run (prio_by_work_left)
     const bool by_work_left = (int)(blockIdx.y * gridDim.x + blockIdx.x) >= prio_from;
-    const int passes_p = (min(S, (j + 1) * chunk) - j * chunk + kFused - 1) / kFused;
-    const int passes_c = CENTER ? (ca.Sc + kFused - 1) / kFused : 0;
+    const int passes_p = (min(S, (j + 1) * chunk) - j * chunk + THREADS - 1) / THREADS;
+    const int passes_c = CENTER ? (ca.Sc + THREADS - 1) / THREADS : 0;
     const DevSurface* __restrict__ lens = lens_set.p[w];
     constexpr int kTripsAt = 64, kTripsCAt = 64 + 64 * SDIRT_MAX_WAVELENGTHS;
     x2 += (int64_t)w * S; y2 += (int64_t)w * S;
@@ -631,7 +633,7 @@ k_psf_lr(SplatBlock sb /* kernarg offset 0 */, TripSet trips /* 64 */, TripSet t
     if (CENTER) {
         // ---- chief-ray centre of this point (same arithmetic and reduction order as
         // k_chief_center; the fp64 scratch aliases the not-yet-used tile memory)
-        double* redd = reinterpret_cast<double*>(tiles_raw);         // [3][kFused]
+        double* redd = reinterpret_cast<double*>(tiles_raw);         // [3][THREADS]
         if (threadIdx.x < SDIRT_MAX_SURFACES) lds_mask[threadIdx.x] = 0;
         if (threadIdx.x == 0) c_sh[0] = 0.0f;
         __syncthreads();
@@ -648,22 +650,22 @@ k_psf_lr(SplatBlock sb /* kernarg offset 0 */, TripSet trips /* 64 */, TripSet t
             sr += (double)r.ra;
             any |= (r.ra == 1.0f);
         }
-        redd[threadIdx.x] = sx; redd[kFused + threadIdx.x] = sy; redd[2 * kFused + threadIdx.x] = sr;
+        redd[threadIdx.x] = sx; redd[THREADS + threadIdx.x] = sy; redd[2 * THREADS + threadIdx.x] = sr;
         if (any) c_sh[0] = 1.0f;                                     // benign race: all write 1
         __syncthreads();
-        for (int off = kFused / 2; off > 0; off >>= 1) {
+        for (int off = THREADS / 2; off > 0; off >>= 1) {
             if ((int)threadIdx.x < off) {
                 redd[threadIdx.x] += redd[threadIdx.x + off];
-                redd[kFused + threadIdx.x] += redd[kFused + threadIdx.x + off];
-                redd[2 * kFused + threadIdx.x] += redd[2 * kFused + threadIdx.x + off];
+                redd[THREADS + threadIdx.x] += redd[THREADS + threadIdx.x + off];
+                redd[2 * THREADS + threadIdx.x] += redd[2 * THREADS + threadIdx.x + off];
             }
             __syncthreads();
         }
         if (ca.conv_mask_c && (int)threadIdx.x < K && lds_mask[threadIdx.x])
             atomicOr(&ca.conv_mask_c[threadIdx.x], lds_mask[threadIdx.x]);
         const float any_f = c_sh[0];
-        const float den = (float)redd[2 * kFused] + (float)1e-9;
-        const float ccx = -((float)redd[0] / den), ccy = -((float)redd[kFused] / den);
+        const float den = (float)redd[2 * THREADS] + (float)1e-9;
+        const float ccx = -((float)redd[0] / den), ccy = -((float)redd[THREADS] / den);
         __syncthreads();                                             // everyone has read redd / c_sh
         if (threadIdx.x == 0) {
             ca.center_out[2 * n] = ccx; ca.center_out[2 * n + 1] = ccy;
@@ -1053,7 +1055,21 @@ static int launch_psf(const sdirt_lens* const* lens, int W, const float* point_o
     // double accumulators (ACC of k_psf_lr) whenever they leave room for four workgroups per CU, i.e. for the
     // kernel's 8 waves per SIMD: 4 x (39 KiB + 0.4 KiB of static LDS) <= 160 KiB -- L + R up to ks 49, L alone up to 70
     const size_t n_acc = (size_t)tile * (both ? 2 : 1);
-    const bool wide = !dpp.big && sizeof(double) * n_acc <= kWideTilesMax;
+    bool wide = !dpp.big && sizeof(double) * n_acc <= kWideTilesMax;
+    // SDIRT_PSF_DETERMINISTIC: double tiles also where only TWO workgroups per CU have room for them (L + R up to ks 70)
+    // -- those then have 1024 threads; beyond that (or with the spp axis cut: partial grids meet in global float
+    // atomics) there is no order-independent sum to offer
+    bool wide1024 = false;
+    if ((flags & SDIRT_PSF_DETERMINISTIC) && !wide) {
+        if (dpp.big || nsplit > 1 || sizeof(double) * n_acc > 2 * kWideTilesMax)
+            return fail(SDIRT_ERR_UNSUPPORTED, "SDIRT_PSF_DETERMINISTIC: float64 tiles need ks <= 70 (L + R; L alone: 99), r <= 0.5 and "
+                                               "one workgroup per point (sdirt_psf_spp_slices == 1)");
+        wide = wide1024 = true;
+    }
+    if ((flags & SDIRT_PSF_DETERMINISTIC) && nsplit > 1)
+        return fail(SDIRT_ERR_UNSUPPORTED, "SDIRT_PSF_DETERMINISTIC: the spp axis is cut for this batch (sdirt_psf_spp_slices > 1): "
+                                           "partial grids are added with global float atomics");
+    const int threads = wide1024 ? 2 * kFused : kFused;
     size_t lds_bytes = (wide ? sizeof(double) : sizeof(float)) * n_acc;
     CenterArgs ca;
     TripSet ttc;
@@ -1066,7 +1082,7 @@ static int launch_psf(const sdirt_lens* const* lens, int W, const float* point_o
         ca.lens_c = cen->lens_c->dev; ttc = cen->trips_c; ca.xc = cen->xc; ca.yc = cen->yc;
         ca.Sc = (int)cen->Sc; ca.center_out = cen->center_out; ca.any_valid = cen->any_valid;
         ca.conv_mask_c = cen->conv_mask_c;
-        lds_bytes = std::max(lds_bytes, sizeof(double) * 3 * kFused);   // fp64 reduction scratch
+        lds_bytes = std::max(lds_bytes, sizeof(double) * 3 * threads);  // fp64 reduction scratch
     }
     SplitArgs sa;
     std::memset(&sa, 0, sizeof(sa));
@@ -1100,15 +1116,21 @@ static int launch_psf(const sdirt_lens* const* lens, int W, const float* point_o
         ca.center_out = cen->center_out;
         center = nullptr;
     }
-#define SDIRT_LAUNCH_PSF(HR, BG, MM, CT, AC)                                                      \
+#define SDIRT_LAUNCH_PSF_T(HR, BG, MM, CT, AC, TH)                                                \
     do {                                                                                          \
         if (lds_bytes > 48 * 1024) /* large tiles: opt in to the full 160 KiB of LDS */           \
-            if (int rc_ = allow_large_lds<&k_psf_lr<HR, BG, MM, CT, AC>>()) return rc_;           \
-        k_psf_lr<HR, BG, MM, CT, AC><<<grid, kFused, lds_bytes, st>>>(                            \
+            if (int rc_ = allow_large_lds<&k_psf_lr<HR, BG, MM, CT, AC, TH>>()) return rc_;       \
+        k_psf_lr<HR, BG, MM, CT, AC, TH><<<grid, TH, lds_bytes, st>>>(                            \
             sblk, tt, ttc, ls, K, point_obj, x2, y2, (int)S, nsplit, chunk, (float)pupil_z,       \
             (float)d_sensor, ks, (int)pstride, dpp.tr, dpp.tl, center, flags, l_psf,              \
             both ? r_psf : nullptr,                                                               \
             conv_mask, ca, sa, last_generation_from((int64_t)grid.x * grid.y));                   \
+    } while (0)
+#define SDIRT_LAUNCH_PSF(HR, BG, MM, CT, AC) SDIRT_LAUNCH_PSF_T(HR, BG, MM, CT, AC, kFused)
+#define SDIRT_LAUNCH_PSF_W(HR, MM)                                                                \
+    do {                                                                                          \
+        if (fuse_center) SDIRT_LAUNCH_PSF_T(HR, false, MM, true, double, 2 * kFused);             \
+        else SDIRT_LAUNCH_PSF_T(HR, false, MM, false, double, 2 * kFused);                        \
     } while (0)
 #define SDIRT_LAUNCH_PSF_C(HR, BG, MM, AC)                                                        \
     do {                                                                                          \
@@ -1119,7 +1141,10 @@ static int launch_psf(const sdirt_lens* const* lens, int W, const float* point_o
         if (lean) SDIRT_LAUNCH_PSF_C(HR, BG, Lean, AC); else SDIRT_LAUNCH_PSF_C(HR, BG, Ieee, AC); \
     } while (0)
     // the corner-clipped microlens branch runs at 4 waves per SIMD whatever the tiles: float tiles only
-    if (both) {
+    if (wide1024) {
+        if (both) { if (lean) SDIRT_LAUNCH_PSF_W(true, Lean); else SDIRT_LAUNCH_PSF_W(true, Ieee); }
+        else { if (lean) SDIRT_LAUNCH_PSF_W(false, Lean); else SDIRT_LAUNCH_PSF_W(false, Ieee); }
+    } else if (both) {
         if (dpp.big) SDIRT_LAUNCH_PSF_M(true, true, float);
         else if (wide) SDIRT_LAUNCH_PSF_M(true, false, double);
         else SDIRT_LAUNCH_PSF_M(true, false, float);
@@ -1142,7 +1167,9 @@ static int launch_psf(const sdirt_lens* const* lens, int W, const float* point_o
     }   // rounds
 #undef SDIRT_LAUNCH_PSF_M
 #undef SDIRT_LAUNCH_PSF_C
+#undef SDIRT_LAUNCH_PSF_W
 #undef SDIRT_LAUNCH_PSF
+#undef SDIRT_LAUNCH_PSF_T
     // param_list=None leaves the R grid all-zero (monte_carlo.py:230-235)
     if (!both && have_r) HIP_TRY(hipMemsetAsync(r_psf, 0, sizeof(float) * (size_t)N * W * tile, st));
     if (!vr && nsplit > 1 && (flags & SDIRT_PSF_NORMALIZE)) {

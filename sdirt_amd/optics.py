@@ -126,6 +126,11 @@ class Lensgroup:
         #: calc_magnification3): None = the lens's device, as the reference draws them; 'cpu' = the CPU generator
         #: (what a CPU run of the reference uses: seeds then reproduce its sample points)
         self.sample_rng_device = None
+        #: True: psf calls ask for run-to-run IDENTICAL grids also where the default sums them in fp32 LDS tiles (grids of 50
+        #: to 70 pixels -- config 2's 65 x 65; L alone: to 99): SDIRT_PSF_DETERMINISTIC, float64 tiles in 1024-thread
+        #: workgroups, +0.5 % time.  Grids up to 49 pixels are summed in float64 anyway.  Beyond the range, with r > 0.5 or
+        #: few points with many samples (the spp axis cut) the library says SDIRT_ERR_UNSUPPORTED.
+        self.deterministic = False
         #: when a dict, kernel launches are bracketed with HIP events on the launch
         #: stream: {'psf_lr': [(start, end), ...], 'chief_center': [...]}  (bench.py)
         self.kernel_events = None
@@ -341,6 +346,7 @@ class Lensgroup:
 
     def _table_digest(self):
         return hash(tuple((s.kind, float(s.r), float(s.d), float(s.c), float(s.k),
+
                            tuple(float(a) for a in (s.ai if s.ai is not None else ()))) for s in self.surfaces))
 
     def _fixed_trips_for(self, policy):
@@ -351,6 +357,10 @@ class Lensgroup:
         if self.precision not in ("ieee", "lean"):
             raise ValueError("precision must be 'lean' or 'ieee'")
         return _lib.PSF_STRICT_IEEE if self.precision == "ieee" else 0
+
+    def _psf_flags(self):
+        """Math policy and, on request, the order-independent sums of a fused psf call (self.deterministic)."""
+        return self._math_flags() | (_lib.PSF_DETERMINISTIC if self.deterministic else 0)
 
     def _timed(self, name):
         return _EventBracket(self.kernel_events, name, self.device)
@@ -920,7 +930,7 @@ class Lensgroup:
         dpp = None if (dp is None or _default_r_zero) else _lib.DpParams(*[float(v) for v in dp])
         dp_ref = C.byref(dpp) if dpp is not None else None
         handle = self.dev_lens(wvln)
-        flags = (_lib.PSF_NORMALIZE if normalize else 0) | self._math_flags() \
+        flags = (_lib.PSF_NORMALIZE if normalize else 0) | self._psf_flags() \
             | (_lib.PSF_INTERLEAVED if torch.is_tensor(out) else 0)
         wkey = round(float(wvln if wvln < 10 else wvln * 1e-3), 6)
         K = len(self.surfaces)
@@ -1159,7 +1169,7 @@ class Lensgroup:
         dpp = None if (dp is None or default_r_zero) else _lib.DpParams(*[float(v) for v in dp])
         dp_ref = C.byref(dpp) if dpp is not None else None
         handle, handle_c = self.dev_lens(wvln), self.dev_lens(DEFAULT_WAVE)
-        flags = (_lib.PSF_NORMALIZE if normalize else 0) | self._math_flags() \
+        flags = (_lib.PSF_NORMALIZE if normalize else 0) | self._psf_flags() \
             | (_lib.PSF_INTERLEAVED if torch.is_tensor(out) else 0)
         wkey = round(float(wvln if wvln < 10 else wvln * 1e-3), 6)
         keys = [("psf", wkey, self.precision), ("center", self.precision)]
@@ -1292,7 +1302,7 @@ class Lensgroup:
         cen = torch.empty((W, N, 2), dtype=torch.float32, device=self.device)
         L = torch.empty((N, W, ks, ks), dtype=torch.float32, device=self.device)
         R = torch.empty_like(L) if want_r else None
-        flags = _lib.PSF_NORMALIZE | self._math_flags()
+        flags = _lib.PSF_NORMALIZE | self._psf_flags()
         # one control block: [primary masks W x MS | chief-ray masks W x MS | any-valid W]
         ctl = torch.zeros(2 * W * MS + W, dtype=torch.int32, device=self.device)
         masks = ctl[:2 * W * MS].view(2, W, MS)
@@ -1357,7 +1367,7 @@ class Lensgroup:
         handles = (C.c_void_p * W)(*[self.dev_lens(w).value for w in WAVE_RGB])
         L = torch.empty((N, W, ks, ks), dtype=torch.float32, device=self.device)
         R = torch.empty_like(L) if want_r else None
-        flags = _lib.PSF_NORMALIZE | self._math_flags()
+        flags = _lib.PSF_NORMALIZE | self._psf_flags()
         masks = torch.zeros((W, MS), dtype=torch.int32, device=self.device)
         reference = self.trip_policy == "reference"
 

@@ -100,7 +100,7 @@ class VolumeStepper:
         self.keys = [("psf", self.wkey, lens.precision), ("center", lens.precision)]
         # the rule is evaluated (and the control block copied out) on the read-back stream, behind the mask reduction of
         # a sharded batch: the render stream carries nothing but uploads and kernels
-        self.flags = _lib.PSF_NORMALIZE | lens._math_flags() | _lib.PSF_INTERLEAVED | _lib.PSF_ZERO_CTL | _lib.PSF_NO_VERIFY
+        self.flags = _lib.PSF_NORMALIZE | lens._psf_flags() | _lib.PSF_INTERLEAVED | _lib.PSF_ZERO_CTL | _lib.PSF_NO_VERIFY
         self.dpp = _lib.DpParams(*[float(v) for v in self.dp])
         self.handle, self.handle_c = lens.dev_lens(wvln), lens.dev_lens(DEFAULT_WAVE)
         self.tables = None

@@ -161,3 +161,40 @@ def test_lanes_round_trip_keeps_the_control_block():
     assert torch.equal(b[_lib.CTL_MASKS:_lib.CTL_MASKS + 128], ctl[_lib.CTL_MASKS:_lib.CTL_MASKS + 128])
     assert int(b[_lib.CTL_ANY_VALID]) == 1 and int(b[2]) == 12345 and int(b[3]) == 0x3FFFFFFF - 12345
     assert torch.equal(host, b) and int(b[_lib.CTL_STATUS]) != 0      # random masks: the rule rejects [3] * K
+
+
+def test_deterministic_flag_makes_65x65_grids_repeat_from_run_to_run():
+    """SDIRT_PSF_DETERMINISTIC (Lensgroup.deterministic = True): BASELINE config 2's 65 x 65 grids summed in float64 tiles
+    by 1024-thread workgroups -- three renders of the same batch with the same pupil points are IDENTICAL (the default's
+    fp32 tiles differ in the last bits with the LDS-atomic arrival order), within the splat bar of the default path, the
+    chief-ray centres within one ulp of its; beyond ks 70 the library says so."""
+    from sdirt_amd import _lib
+    lens = make_lens("rf50mm", DEV)
+    pts = grid(1500, seed=4).to(DEV)
+    ks, spp = 65, 4096
+    g = torch.Generator().manual_seed(8)
+    st = load_state("rf50mm")
+    ang, r2 = torch.rand(spp, generator=g) * 2 * np.pi, torch.rand(spp, generator=g)
+    xy = (torch.sqrt(r2) * st["pupil_r"] * torch.cos(ang), torch.sqrt(r2) * st["pupil_r"] * torch.sin(ang))
+    angc, r2c = torch.rand(2048, generator=g) * 2 * np.pi, torch.rand(2048, generator=g)
+    xyc = (torch.sqrt(r2c) * st["pupil_r"] * 0.25 * torch.cos(angc), torch.sqrt(r2c) * st["pupil_r"] * 0.25 * torch.sin(angc))
+
+    def render():
+        cen = torch.empty((1500, 2), device=DEV)
+        L, R = lens.psf_lr(pts, ks=ks, spp=spp, dp=DP, pupil_xy=xy, center_pupil_xy=xyc, center_out=cen)
+        return L.clone(), R.clone(), cen
+    plain = [render() for _ in range(2)]
+    lens.deterministic = True
+    det = [render() for _ in range(3)]
+    for L, R, cen in det[1:]:
+        assert torch.equal(L, det[0][0]) and torch.equal(R, det[0][1]) and torch.equal(cen, det[0][2])
+    dl = (det[0][0] - plain[0][0]).abs().max().item()
+    dr = (det[0][1] - plain[0][1]).abs().max().item()
+    assert dl < 2e-6 and dr < 2e-6, (dl, dr)
+    from conftest import ulp_diff
+    assert ulp_diff(det[0][2].cpu().numpy(), plain[0][2].cpu().numpy()).max() <= 1
+    repeat = torch.equal(plain[0][0], plain[1][0]) and torch.equal(plain[0][1], plain[1][1])
+    print(f"deterministic vs default: {dl:.2e} / {dr:.2e}; the default repeated itself bit for bit this time: {repeat}")
+    with pytest.raises(_lib.SdirtError, match="SDIRT_PSF_DETERMINISTIC"):
+        lens.psf_lr(pts[:1100], ks=75, spp=1024, dp=DP)
+    lens.psf_lr(pts[:1100], ks=45, spp=1024, dp=DP)               # float64 tiles anyway: nothing to refuse
