@@ -958,6 +958,9 @@ def main():
                          "line on stdout is its compact form (< 4 KB)")
     ap.add_argument("--verbose", action="store_true", help="also print the full record on stderr")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-two-streams", action="store_true",
+                    help="N = 1: skip the second leg (the same K steps on two alternating render streams) -- the profiling "
+                         "recipes: overlapping launches would stand in the kernel trace with twice their duration")
     ap.add_argument("--no-also", action="store_true",
                     help="default c2 run at N = 1: skip the `also` block (staged SoA chain, f1, c4: a few steps each)")
     ap.add_argument("--sustain-seconds", type=float, default=20.0,
@@ -1081,7 +1084,7 @@ def main():
     # N = 1: the same K steps once more with consecutive steps on two alternating streams (what a pipelined consumer of
     # batch after batch gets: the next launch's workgroups fill what is left of the previous launch's end)
     dt_two = None
-    if world == 1:
+    if world == 1 and not args.no_two_streams:
         del loop
         torch.cuda.empty_cache()
         loop2 = VolumeStepper(lens, points_local, n_total, KS, SPP, DP, streams=2)

@@ -468,8 +468,18 @@ __global__ void __launch_bounds__(kBlock) k_pupil_pair(const float* __restrict__
         pupil_point(u[2 * S + c], u[2 * S + Sc + c], pr2c, xy[2 * S + c], xy[2 * S + Sc + c]);
     }
     if (sum && blockIdx.x == 0) {
-        uint32_t acc = 0u;
-        for (int q = threadIdx.x; q < 2 * (S + Sc); q += blockDim.x) acc += __float_as_uint(u[q]);
+        // (the first version walked the 12288 uniforms with one dependent load per thread and pass: 14 us in front of
+        // every fused kernel, profiles/r06/kernel_stats_bench_c2.csv -- four independent loads in flight per thread now)
+        const int n = 2 * (S + Sc);
+        uint32_t a0 = 0u, a1 = 0u, a2 = 0u, a3 = 0u;
+        int q = threadIdx.x;
+        for (; q + 3 * kBlock < n; q += 4 * kBlock) {
+            const uint32_t v0 = __float_as_uint(u[q]), v1 = __float_as_uint(u[q + kBlock]),
+                           v2 = __float_as_uint(u[q + 2 * kBlock]), v3 = __float_as_uint(u[q + 3 * kBlock]);
+            a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+        }
+        for (; q < n; q += kBlock) a0 += __float_as_uint(u[q]);
+        const uint32_t acc = (a0 + a1) + (a2 + a3);
         part[threadIdx.x] = acc;
         __syncthreads();                                           // (also orders the clearing above before the two stores)
         for (int off = kBlock / 2; off > 0; off >>= 1) {

@@ -10,9 +10,9 @@ WL=${1:-c2}; COMMIT=${2:-unknown}; RND=${3:-r06}
 OUT=gpurun_out/prof_${RND}_${WL}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-CMD="python3 bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-also --sustain-seconds 0 --workload $WL"
+CMD="python3 bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-also --no-two-streams --sustain-seconds 0 --workload $WL"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $CMD > "$OUT/trace.log" 2>&1
-CMD="python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-also --sustain-seconds 0 --workload $WL"
+CMD="python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-also --no-two-streams --sustain-seconds 0 --workload $WL"
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES \
     --output-format csv -d "$OUT/pmc_a" -- $CMD > "$OUT/pmc_a.log" 2>&1
 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU_TRANS_F32 SQ_ACTIVE_INST_SCA SQ_INSTS_BRANCH SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_IDX_ACTIVE \

@@ -16,6 +16,34 @@ rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ
     --output-format csv -d "$OUT/pmc_a" -- $CMD > "$OUT/pmc_a.log" 2>&1
 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS \
     --output-format csv -d "$OUT/pmc_b" -- $CMD > "$OUT/pmc_b.log" 2>&1
+# the kernel's READ PATTERN alone (tools/bw_pixel.hip: one wave per pixel, 14 dword loads per lane one pixel ahead, no
+# arithmetic, no LDS) under the same counters: what separates the product from it
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/bw_pixel.hip -o /tmp/bw_pixel > "$OUT/bw_pixel_build.log" 2>&1
+/tmp/bw_pixel > "$OUT/bw_pixel.txt" 2>&1
+rocprofv3 --kernel-trace --output-format csv -d "$OUT/probe_trace" -- /tmp/bw_pixel > "$OUT/probe_trace.log" 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES \
+    --output-format csv -d "$OUT/probe_pmc_a" -- /tmp/bw_pixel > "$OUT/probe_pmc_a.log" 2>&1
+rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS \
+    --output-format csv -d "$OUT/probe_pmc_b" -- /tmp/bw_pixel > "$OUT/probe_pmc_b.log" 2>&1
+python3 - "$OUT" <<'PY'
+import csv, glob, json, sys, collections
+out = sys.argv[1]
+res = {}
+for f in glob.glob(out + "/probe_pmc_*/**/*_counter_collection.csv", recursive=True):
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(f)):
+        acc[r["Kernel_Name"][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, cs in acc.items():
+        for c, v in cs.items():
+            res.setdefault(k, {})[c] = v[-1]
+dur = collections.defaultdict(list)
+for f in glob.glob(out + "/probe_trace/**/*_kernel_trace.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        dur[r["Kernel_Name"][:60]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+for k, v in dur.items():
+    res.setdefault(k, {})["min_us"] = min(v)
+json.dump(res, open(out + "/probe_counters.json", "w"), indent=1)
+PY
 python3 tools/summarize_prof.py "$OUT" k_local_psf_render > "$OUT/summary.json"
 python3 - "$OUT" "$COMMIT" <<'PY'
 import json, sys, time
