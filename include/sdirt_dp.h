@@ -524,6 +524,13 @@ int sdirt_dp_cost_volume_backward(const void* grad_cost /*dev*/, int32_t batch, 
                                   int32_t d_max, int32_t height, int32_t width, int32_t half_precision,
                                   void* grad_x /*dev, out*/, void* grad_y /*dev, out*/, void* stream);
 
+/* nn.AvgPool2d((k, k), stride=(k, k)) of the depth network's two context branches (dfdp/dddnet/dddnet.py:376-385: windows
+ * of 32 and of 8 pixels on [B, 128, H/4, W/4] maps): x [planes, height, width] -> out [planes, height / k, width / k],
+ * fp32 accumulation and one division by k * k as torch's kernel; k must divide height and width.  half_precision != 0:
+ * fp16 tensors (the network runs under autocast), else fp32. */
+int sdirt_avg_pool_windows(const void* x /*dev*/, int64_t planes, int32_t height, int32_t width, int32_t k,
+                           int32_t half_precision, void* out /*dev*/, void* stream);
+
 /* PSFNet tone curves (deeplens/psfnet.py:589-620), elementwise over n floats, in place allowed:
  * mode 0 = degamma(img) (code value in [0,1] -> linear luminance, psfnet.py:600-603),
  * mode 1 = clip(gamma(l), 0, 1) (psfnet.py:617-620 followed by the clip of render, :712). */

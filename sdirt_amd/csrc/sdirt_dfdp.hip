@@ -118,6 +118,62 @@ extern "C" int sdirt_dp_cost_volume(const void* x, const void* y, int32_t batch,
 }
 
 // ---------------------------------------------------------------------------
+// The context branches of the depth network's feature extractor (dfdp/dddnet/dddnet.py:376-385): nn.AvgPool2d with a
+// window of 32 x 32 / 8 x 8 and the same stride on [B, 128, H/4, W/4] maps.  torch's kernel gives one THREAD the
+// whole window (1024 strided reads): 240 us per call at 512 x 768, four calls per frame = 13 % of config 5's frame
+// (profiles/r06/top_kernels_c5.txt).  Here one workgroup owns one output row of one plane: thread t sums column t
+// of the k input rows (coalesced reads), the k column sums of a window are added from LDS.  fp32 accumulation and
+// ONE division by k * k, as torch (accscalar_t = float); the order of the additions differs.
+// ---------------------------------------------------------------------------
+template <class T>
+__global__ void __launch_bounds__(256) k_avg_pool_windows(const T* __restrict__ x, int H, int W, int k, T* __restrict__ out)
+{
+    extern __shared__ float colsum[];                           // [W]
+    const int OH = H / k, OW = W / k;
+    const int plane = blockIdx.x / OH, oy = blockIdx.x - plane * OH;
+    const T* __restrict__ src = x + ((int64_t)plane * H + (int64_t)oy * k) * W;
+    for (int c = threadIdx.x; c < W; c += blockDim.x) {
+        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+        int r = 0;
+        for (; r + 3 < k; r += 4) {
+            a0 += (float)src[(int64_t)r * W + c];
+            a1 += (float)src[(int64_t)(r + 1) * W + c];
+            a2 += (float)src[(int64_t)(r + 2) * W + c];
+            a3 += (float)src[(int64_t)(r + 3) * W + c];
+        }
+        for (; r < k; ++r) a0 += (float)src[(int64_t)r * W + c];
+        colsum[c] = (a0 + a1) + (a2 + a3);
+    }
+    __syncthreads();
+    const float inv = 1.0f / (float)(k * k);
+    for (int ox = threadIdx.x; ox < OW; ox += blockDim.x) {
+        float s = 0.0f;
+        for (int j = 0; j < k; ++j) s += colsum[ox * k + j];
+        out[((int64_t)plane * OH + oy) * OW + ox] = (T)(s * inv);
+    }
+}
+
+extern "C" int sdirt_avg_pool_windows(const void* x, int64_t planes, int32_t height, int32_t width, int32_t k,
+                                      int32_t half_precision, void* out, void* stream)
+{
+    if (!x || !out || planes < 0 || height < 1 || width < 1 || k < 1 || height % k || width % k)
+        return fail(SDIRT_ERR_INVALID_ARGUMENT, "bad argument (the window must divide height and width)");
+    if (width > 12288) return fail(SDIRT_ERR_UNSUPPORTED, "width > 12288");
+    const int64_t blocks = planes * (height / k);
+    if (blocks == 0) return SDIRT_OK;
+    if (blocks > (1ll << 31) - 1) return fail(SDIRT_ERR_INVALID_ARGUMENT, "too many planes");
+    const size_t lds = sizeof(float) * (size_t)width;
+    if (half_precision)
+        k_avg_pool_windows<_Float16><<<(unsigned)blocks, 256, lds, as_stream(stream)>>>(
+            static_cast<const _Float16*>(x), height, width, k, static_cast<_Float16*>(out));
+    else
+        k_avg_pool_windows<float><<<(unsigned)blocks, 256, lds, as_stream(stream)>>>(
+            static_cast<const float*>(x), height, width, k, static_cast<float*>(out));
+    LAUNCH_CHECK();
+    return SDIRT_OK;
+}
+
+// ---------------------------------------------------------------------------
 // PSFNet tone curves (deeplens/psfnet.py:589-620), one pass each instead of ~25 elementwise launches.
 // The arithmetic follows torch's fp32 op sequence on the GPU term by term (scalar / tensor is
 // reciprocal * scalar, tensor / scalar is tensor * (1 / scalar), no contraction), so the results

@@ -75,6 +75,40 @@ def dp_cost_volume(x, y, d_max=20):
     return _cost_volume_reference(x, y, d_max)
 
 
+class _WindowAverage(torch.autograd.Function):
+    """sdirt_avg_pool_windows; the adjoint spreads grad / k^2 over each window."""
+
+    @staticmethod
+    def forward(ctx, x, k):
+        B, C, H, W = x.shape
+        x = x.contiguous()
+        out = torch.empty((B, C, H // k, W // k), dtype=x.dtype, device=x.device)
+        _lib.check(_lib.lib().sdirt_avg_pool_windows(dptr(x), B * C, H, W, k, 1 if x.dtype == torch.float16 else 0,
+                                                     dptr(out), stream_ptr(x.device)))
+        ctx.k = k
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        k = ctx.k
+        return (grad / (k * k)).repeat_interleave(k, dim=-2).repeat_interleave(k, dim=-1), None
+
+
+class WindowAverage(nn.AvgPool2d):
+    """nn.AvgPool2d((k, k), stride=(k, k)) (dddnet.py:376-385: the context branches pool over 32 x 32 and 8 x 8 windows).
+    CUDA fp16 / fp32 maps whose sides the window divides take sdirt_avg_pool_windows (torch's kernel gives one thread a
+    whole window: 240 us per call at 512 x 768 against ~10); anything else is nn.AvgPool2d itself.  No parameters: the
+    reference's checkpoints load unchanged."""
+
+    def forward(self, x):
+        k = self.kernel_size if isinstance(self.kernel_size, int) else self.kernel_size[0]
+        square = (self.kernel_size, self.stride) in ((k, k), ((k, k), (k, k)), ((k, k), k), (k, (k, k)))
+        if (x.is_cuda and x.dim() == 4 and x.dtype in (torch.float16, torch.float32) and square and self.padding in (0, (0, 0))
+                and x.shape[-2] % k == 0 and x.shape[-1] % k == 0 and x.shape[-1] <= 12288):
+            return _WindowAverage.apply(x, k)
+        return super().forward(x)
+
+
 class BasicConv(nn.Module):
     """conv (2-D / 3-D, optionally transposed, no bias) [+ batch norm] [+ ReLU]; dddnet.py:513-541."""
 
@@ -107,9 +141,9 @@ class Feature(nn.Module):
         self.layer1 = nn.Sequential(BasicConv(64, 128, kernel_size=3, stride=1, padding=4, dilation=4),
                                     BasicConv(128, 128, kernel_size=3, stride=1, padding=8, dilation=8),
                                     BasicConv(128, 128, kernel_size=3, stride=2, padding=1))
-        self.branch1 = nn.Sequential(nn.AvgPool2d((32, 32), stride=(32, 32)), _convbn(128, 32),
+        self.branch1 = nn.Sequential(WindowAverage((32, 32), stride=(32, 32)), _convbn(128, 32),
                                      nn.ReLU(inplace=True))
-        self.branch3 = nn.Sequential(nn.AvgPool2d((8, 8), stride=(8, 8)), _convbn(128, 32),
+        self.branch3 = nn.Sequential(WindowAverage((8, 8), stride=(8, 8)), _convbn(128, 32),
                                      nn.ReLU(inplace=True))
         self.end = nn.Sequential(BasicConv(192, 96, kernel_size=3, stride=1, padding=1),
                                  BasicConv(96, 32, kernel_size=1, bn=False, relu=False, padding=0))

@@ -149,3 +149,28 @@ def test_cost_volume_other_cuda_dtypes_take_the_reference_formulation():
         assert torch.allclose(got.float(), want, atol=2e-2)
     xd = x.double().requires_grad_(True)
     assert torch.autograd.gradcheck(lambda a: dp_cost_volume(a, y.double(), 8), (xd,), nondet_tol=0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+@pytest.mark.parametrize("k,shape", [(32, (1, 128, 128, 192)), (8, (2, 128, 128, 192)), (4, (1, 3, 12, 20)), (1, (1, 2, 5, 7))])
+def test_window_average_equals_avg_pool2d(dtype, k, shape):
+    """WindowAverage (sdirt_avg_pool_windows) against nn.AvgPool2d((k, k), stride=(k, k)) -- the two context branches of the
+    feature extractor (dddnet.py:376-385) -- forward within one rounding of the result type (fp32 accumulation in another
+    order), the adjoint exactly; shapes the kernel does not take (a side the window does not divide) go to torch."""
+    from sdirt_amd.dfdp import WindowAverage
+    g = torch.Generator(device="cuda").manual_seed(k)
+    x = torch.randn(shape, device="cuda", generator=g).to(dtype)
+    ours, ref = WindowAverage((k, k), stride=(k, k)), torch.nn.AvgPool2d((k, k), stride=(k, k))
+    a, b = ours(x), ref(x)
+    assert a.shape == b.shape and a.dtype == b.dtype
+    tol = 2e-3 if dtype == torch.float16 else 2e-6
+    assert (a.float() - b.float()).abs().max().item() <= tol * max(1.0, b.float().abs().max().item())
+    x1 = x.float().clone().requires_grad_(True)
+    x2 = x.float().clone().requires_grad_(True)
+    w = torch.randn(b.shape, device="cuda", generator=g)
+    (ours(x1) * w).sum().backward()
+    (ref(x2) * w).sum().backward()
+    assert torch.allclose(x1.grad, x2.grad, rtol=0, atol=1e-7)
+    odd = torch.randn(1, 2, 10, 13, device="cuda").to(dtype)
+    assert torch.equal(WindowAverage((4, 4), stride=(4, 4))(odd), torch.nn.AvgPool2d((4, 4), stride=(4, 4))(odd))
