@@ -133,7 +133,7 @@ typedef struct sdirt_dp_params {
 #define SDIRT_PSF_ZERO_CTL 64u
 /* sdirt_psf_call only (one workgroup per point): leave the trip rule unevaluated -- the masks of a rank of a sharded
  * batch say nothing before they are OR-ed with the other ranks' (sdirt_ctl_to_lanes, all-reduce, sdirt_ctl_from_lanes). */
-#define SDIRT_PSF_NO_VERIFY 128u /* (needs SDIRT_PSF_ZERO_CTL) */
+#define SDIRT_PSF_NO_VERIFY 128u
 /* sdirt_psf_lr / _centered / sdirt_psf_call (one workgroup per point): run-to-run IDENTICAL grids also on 50 to 70 pixels
  * (L + R; L alone: up to 99) -- BASELINE config 2's 65 x 65.  A point's grids are summed in LDS: in float64 (rounded to
  * fp32 once: the arrival order of the atomics cannot matter) wherever four workgroups per CU have room for such tiles,
@@ -364,9 +364,9 @@ int32_t sdirt_psf_spp_slices(int64_t n_points, int64_t spp, int32_t n_cus);
 #define SDIRT_CTL_STATUS 0     /* 0: the speculated tables were the reference's (round 2 did nothing);       */
                                /* else bit 0 | bit 1 (primary table corrected) | bit 2 (chief-ray table corrected) */
 #define SDIRT_CTL_ANY_VALID 1  /* 1 if any chief ray reached the sensor (optics.py:902)                      */
-#define SDIRT_CTL_UNIFORM_SUM 2 /* sdirt_psf_call with SDIRT_PSF_NO_VERIFY: sum of the uniforms' bit patterns (30 bits), */
-                               /* word 3 its complement to 0x3fffffff: ranks that all drew the same numbers read, after */
-                               /* the MAX-reduction of sdirt_ctl_to_lanes / _from_lanes, two words that still add up      */
+#define SDIRT_CTL_TAG 2        /* sdirt_ctl_from_lanes: the caller's 30-bit tag of sdirt_ctl_to_lanes (e.g. a checksum of the   */
+                               /* step's uniforms) and, in word 3, its complement to 0x3fffffff, as the MAX over ranks left     */
+                               /* them: the two still add up to 0x3fffffff iff every rank handed in the same tag               */
 #define SDIRT_CTL_TRIPS2 16    /* 16 + 16 words: the tables round 2 ran, one signed byte per surface         */
 #define SDIRT_CTL_MASKS 64     /* 4 x 64 words: convergence masks of round 1 (primary, chief), round 2 (same) */
 #define SDIRT_CTL_WORDS 320
@@ -407,6 +407,9 @@ int sdirt_psf_lr_verified(const sdirt_lens* lens, const sdirt_lens* lens_center,
  *     SDIRT_CTL_TRIPS2 (one signed byte per surface: primary at word 16, chief-ray at word 32) until the status is 0 --
  *     a table speculated from above (10 trips on curved surfaces, what NULL-free first calls should pass) is corrected
  *     exactly in one round.  No host-side rule is needed: tests/c_client/psf_client.c renders fixture F1 this way.
+ * u_host is read by the call's first kernel WHERE IT IS (page-locked memory is mapped into the device's address space: no copy
+ * command on the stream, whose two engine hand-overs cost a 2048-point step 25 us): it must stay unchanged until that kernel has
+ * run -- one buffer per call in flight.  (Memory that is not mapped is copied instead.)
  * scratch: dev, 8-byte aligned, sdirt_psf_call_scratch_bytes(n_points, spp, spp_center) bytes: [control block | chief-ray
  * partial sums | uniforms | pupil points x2, y2, xc, yc]; its first SDIRT_CTL_WORDS words zeroed by the caller, or by
  * the call itself under SDIRT_PSF_ZERO_CTL. */
@@ -422,12 +425,13 @@ int sdirt_psf_call(const sdirt_lens* lens, const sdirt_lens* lens_center, const 
 /* A batch sharded over ranks: the reference's trip rule is batch-wide, so the ranks' masks are OR-ed
  * before it is evaluated.  RCCL has no bitwise OR: sdirt_ctl_to_lanes spreads round 1's masks and the any-valid flag of
  * a control block (sdirt_psf_call with SDIRT_PSF_NO_VERIFY) into SDIRT_CTL_LANES int32 lanes -- 0 / 1 lanes [primary |
- * chief-ray][SDIRT_MAX_SURFACES][bit 0..10], the flag, then the two SDIRT_CTL_UNIFORM_SUM words as they are --, the caller all-reduces them with MAX, and
+ * chief-ray][SDIRT_MAX_SURFACES][bit 0..10], the flag, then `tag` (30 bits: whatever the ranks must agree on, e.g. a checksum of the
+ * uniforms they drew) and its complement --, the caller all-reduces them with MAX, and
  * sdirt_ctl_from_lanes folds them back into the control block, evaluates the rule there (lens != NULL: status word and
  * corrected tables as sdirt_psf_call leaves them; trips / trips_center = the tables that ran) and copies the block to
  * ctl_host (page-locked, or NULL).  Every rank then reads the same status.  Device pointers + stream, no allocation. */
 #define SDIRT_CTL_LANES 1411   /* 2 * SDIRT_MAX_SURFACES * (SDIRT_NEWTON_MAXITER + 1) + 3 */
-int sdirt_ctl_to_lanes(const uint32_t* ctl /*dev*/, int32_t* lanes /*dev [SDIRT_CTL_LANES], out*/, void* stream);
+int sdirt_ctl_to_lanes(const uint32_t* ctl /*dev*/, uint32_t tag, int32_t* lanes /*dev [SDIRT_CTL_LANES], out*/, void* stream);
 int sdirt_ctl_from_lanes(const int32_t* lanes /*dev*/, const sdirt_lens* lens /*or NULL: masks only*/,
                          const int32_t* trips /*host [K]*/, const int32_t* trips_center /*host [K]*/,
                          uint32_t* ctl /*dev, in/out*/, uint32_t* ctl_host /*host, page-locked, out, or NULL*/, void* stream);

@@ -28,7 +28,7 @@ PSF_NO_VERIFY = 128
 PSF_DETERMINISTIC = 256
 CTL_STATUS, CTL_ANY_VALID, CTL_TRIPS2, CTL_MASKS, CTL_WORDS = 0, 1, 16, 64, 320
 CTL_LANES = 1411
-CTL_UNIFORM_SUM = 2
+CTL_TAG = 2
 
 KIND_PLANE, KIND_SPHERE, KIND_ASPHERE = 0, 1, 2
 
@@ -98,7 +98,7 @@ SIGNATURES = {
     "sdirt_psf_call_scratch_bytes": (_I64, [_I64, _I64, _I64]),
     "sdirt_psf_call": (C.c_int, [_P, _P, _P, _I64, _P, _I64, _I64, _D, _D, _D, _D, _D, _I32, C.POINTER(DpParams),
                                  C.POINTER(_I32), C.POINTER(_I32), _U32, _P, _P, _P, _P, _P, _P]),
-    "sdirt_ctl_to_lanes": (C.c_int, [_P, _P, _P]),
+    "sdirt_ctl_to_lanes": (C.c_int, [_P, _U32, _P, _P]),
     "sdirt_ctl_from_lanes": (C.c_int, [_P, _P, C.POINTER(_I32), C.POINTER(_I32), _P, _P, _P]),
     "sdirt_host_uniform_fill": (C.c_int, [_P, _I64, _I64, _P]),
     "sdirt_selftest_math": (C.c_int, [_I32, C.c_uint64, C.c_uint64, _I32, _P, _P]),

@@ -453,40 +453,15 @@ __device__ bool verify_trips(const TripTable& t, const uint32_t* __restrict__ ma
 
 // sdirt_psf_call's prologue as ONE launch: both pupil mappings of a psf call (u = [theta | r2 | theta_c | r2_c] ->
 // xy = [x2 | y2 | xc | yc], sdirt_pupil_samples twice) and, on request, the clearing of the control block.
-// `sum` != nullptr: the first workgroup also leaves the sum of the uniforms' bit patterns (30 bits) and its complement
-// in sum[0], sum[1] -- what the ranks of a sharded batch compare to be sure they all drew the same numbers.
 __global__ void __launch_bounds__(kBlock) k_pupil_pair(const float* __restrict__ u, int S, int Sc, float pr2, float pr2c,
-                                                       float* __restrict__ xy, uint32_t* __restrict__ zero, int nzero,
-                                                       uint32_t* __restrict__ sum)
+                                                       float* __restrict__ xy, uint32_t* __restrict__ zero, int nzero)
 {
-    __shared__ uint32_t part[kBlock];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < nzero) zero[i] = 0u;
     if (i < S) pupil_point(u[i], u[S + i], pr2, xy[i], xy[S + i]);
     else if (i < S + Sc) {
         const int c = i - S;
         pupil_point(u[2 * S + c], u[2 * S + Sc + c], pr2c, xy[2 * S + c], xy[2 * S + Sc + c]);
-    }
-    if (sum && blockIdx.x == 0) {
-        // (the first version walked the 12288 uniforms with one dependent load per thread and pass: 14 us in front of
-        // every fused kernel, profiles/r06/kernel_stats_bench_c2.csv -- four independent loads in flight per thread now)
-        const int n = 2 * (S + Sc);
-        uint32_t a0 = 0u, a1 = 0u, a2 = 0u, a3 = 0u;
-        int q = threadIdx.x;
-        for (; q + 3 * kBlock < n; q += 4 * kBlock) {
-            const uint32_t v0 = __float_as_uint(u[q]), v1 = __float_as_uint(u[q + kBlock]),
-                           v2 = __float_as_uint(u[q + 2 * kBlock]), v3 = __float_as_uint(u[q + 3 * kBlock]);
-            a0 += v0; a1 += v1; a2 += v2; a3 += v3;
-        }
-        for (; q < n; q += kBlock) a0 += __float_as_uint(u[q]);
-        const uint32_t acc = (a0 + a1) + (a2 + a3);
-        part[threadIdx.x] = acc;
-        __syncthreads();                                           // (also orders the clearing above before the two stores)
-        for (int off = kBlock / 2; off > 0; off >>= 1) {
-            if ((int)threadIdx.x < off) part[threadIdx.x] += part[threadIdx.x + off];
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) { sum[0] = part[0] & 0x3fffffffu; sum[1] = 0x3fffffffu - (part[0] & 0x3fffffffu); }
     }
 }
 
@@ -505,12 +480,13 @@ __global__ void k_ctl_verify(uint32_t* __restrict__ ctl, const DevSurface* __res
 constexpr int kLaneBits = SDIRT_NEWTON_MAXITER + 1;
 constexpr int kMaskLanes = 2 * SDIRT_MAX_SURFACES * kLaneBits;       // then: any-valid, uniform sum, its complement
 static_assert(kMaskLanes + 3 == SDIRT_CTL_LANES, "lane layout");
-__global__ void __launch_bounds__(kBlock) k_ctl_to_lanes(const uint32_t* __restrict__ ctl, int32_t* __restrict__ lanes)
+__global__ void __launch_bounds__(kBlock) k_ctl_to_lanes(const uint32_t* __restrict__ ctl, uint32_t tag, int32_t* __restrict__ lanes)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= SDIRT_CTL_LANES) return;
     if (i == kMaskLanes) { lanes[i] = ctl[kCtlAnyValid] != 0u; return; }
-    if (i > kMaskLanes) { lanes[i] = (int32_t)ctl[SDIRT_CTL_UNIFORM_SUM + (i - kMaskLanes - 1)]; return; }
+    // the caller's tag and its complement: after a MAX over ranks the two still add up to 0x3fffffff iff all ranks agreed
+    if (i > kMaskLanes) { lanes[i] = (int32_t)(i == kMaskLanes + 1 ? (tag & 0x3fffffffu) : 0x3fffffffu - (tag & 0x3fffffffu)); return; }
     const int word = i / kLaneBits, bit = i - word * kLaneBits;      // word: 0..63 primary, 64..127 chief
     lanes[i] = (int32_t)((ctl[kCtlMask1P + word] >> bit) & 1u);
 }
@@ -522,7 +498,7 @@ __global__ void __launch_bounds__(2 * SDIRT_MAX_SURFACES) k_ctl_from_lanes(const
     for (int b = 0; b < kLaneBits; ++b) m |= (lanes[word * kLaneBits + b] != 0 ? 1u : 0u) << b;
     ctl[kCtlMask1P + word] = m;
     if (word == 0) ctl[kCtlAnyValid] = lanes[kMaskLanes] != 0 ? 1u : 0u;
-    if (word == 1 || word == 2) ctl[SDIRT_CTL_UNIFORM_SUM + word - 1] = (uint32_t)lanes[kMaskLanes + word];
+    if (word == 1 || word == 2) ctl[SDIRT_CTL_TAG + word - 1] = (uint32_t)lanes[kMaskLanes + word];
     __syncthreads();
     if (word == 0 && lens) {
         const bool okp = verify_trips(tp, ctl + kCtlMask1P, lens, K, ctl + kCtlTrips2P);
@@ -1344,8 +1320,6 @@ int sdirt_psf_call(const sdirt_lens* lens, const sdirt_lens* lens_center, const 
 {
     if (!lens || !lens_center || !u_host || !scratch || N < 0 || S < 1 || Sc < 1 || S > (1ll << 30) || Sc > (1ll << 30))
         return fail(SDIRT_ERR_INVALID_ARGUMENT, "bad argument");
-    if ((flags & SDIRT_PSF_NO_VERIFY) && !(flags & SDIRT_PSF_ZERO_CTL))
-        return fail(SDIRT_ERR_INVALID_ARGUMENT, "SDIRT_PSF_NO_VERIFY goes with SDIRT_PSF_ZERO_CTL (the call writes the uniform sum into the block it clears)");
     if (((uintptr_t)scratch) & 7) return fail(SDIRT_ERR_INVALID_ARGUMENT, "scratch must be 8-byte aligned");
     hipStream_t st = as_stream(stream);
     const int64_t n = 2 * (S + Sc);
@@ -1353,12 +1327,28 @@ int sdirt_psf_call(const sdirt_lens* lens, const sdirt_lens* lens_center, const 
     float* u = reinterpret_cast<float*>(static_cast<char*>(scratch) +
                                         align64((size_t)sdirt_psf_verified_scratch_bytes(N, Sc)));
     float* xy = u + n;
-    HIP_TRY(hipMemcpyAsync(u, u_host, sizeof(float) * (size_t)n, hipMemcpyHostToDevice, st));
+    // The uniforms: page-locked host memory is mapped into the device's address space -- the mapping kernel reads them
+    // where they are (48 KB over PCIe, a few microseconds) instead of behind a copy on the stream.  A copy command between
+    // two kernels of one stream costs two engine hand-overs, compute queue -> SDMA engine -> compute queue: 12 us each, 25
+    // of the 38 us a 2048-point step idled between its fused kernels (profiles/r06/step_timeline_plain.txt).  Memory that
+    // is not mapped (pageable memory handed in against the contract) still goes through the copy.
+    const float* u_src = nullptr;
+    {
+        void* mapped = nullptr;
+        if (hipHostGetDevicePointer(&mapped, const_cast<float*>(u_host), 0) == hipSuccess && mapped)
+            u_src = static_cast<const float*>(mapped);
+        else
+            (void)hipGetLastError();
+    }
+    if (!u_src) {
+        HIP_TRY(hipMemcpyAsync(u, u_host, sizeof(float) * (size_t)n, hipMemcpyHostToDevice, st));
+        u_src = u;
+    }
     // the reference's draw order (optics.py:483-484, then again inside psf_center): theta, r^2 of the primary
     // pass, theta, r^2 of the chief-ray pass -- both mappings (and SDIRT_PSF_ZERO_CTL) in one launch
     k_pupil_pair<<<grid_for(std::max<int64_t>(S + Sc, SDIRT_CTL_WORDS), kBlock, 1 << 30), kBlock, 0, st>>>(
-        u, (int)S, (int)Sc, (float)(pupil_r * pupil_r), (float)(pupil_r_center * pupil_r_center), xy, ctl,
-        (flags & SDIRT_PSF_ZERO_CTL) ? SDIRT_CTL_WORDS : 0, (flags & SDIRT_PSF_NO_VERIFY) ? ctl + SDIRT_CTL_UNIFORM_SUM : nullptr);
+        u_src, (int)S, (int)Sc, (float)(pupil_r * pupil_r), (float)(pupil_r_center * pupil_r_center), xy, ctl,
+        (flags & SDIRT_PSF_ZERO_CTL) ? SDIRT_CTL_WORDS : 0);
     LAUNCH_CHECK();
     const uint32_t kflags = flags & ~(SDIRT_PSF_ZERO_CTL | SDIRT_PSF_NO_VERIFY);
     if (N == 0) {
@@ -1393,10 +1383,10 @@ int sdirt_psf_call(const sdirt_lens* lens, const sdirt_lens* lens_center, const 
     return SDIRT_OK;
 }
 
-int sdirt_ctl_to_lanes(const uint32_t* ctl, int32_t* lanes, void* stream)
+int sdirt_ctl_to_lanes(const uint32_t* ctl, uint32_t tag, int32_t* lanes, void* stream)
 {
     if (!ctl || !lanes) return fail(SDIRT_ERR_INVALID_ARGUMENT, "bad argument");
-    k_ctl_to_lanes<<<grid_for(SDIRT_CTL_LANES, kBlock), kBlock, 0, as_stream(stream)>>>(ctl, lanes);
+    k_ctl_to_lanes<<<grid_for(SDIRT_CTL_LANES, kBlock), kBlock, 0, as_stream(stream)>>>(ctl, tag, lanes);
     LAUNCH_CHECK();
     return SDIRT_OK;
 }

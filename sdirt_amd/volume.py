@@ -19,8 +19,7 @@ that is not 0 (the speculated trip tables were not the reference's for this batc
 grid) sends that step through the corrected tables again -- on every rank alike, they all read the same reduced status.
 
 Sharded batches: every rank draws the SAME uniforms from its own generator (seed them alike -- `torch.manual_seed`
-before the loop, as every rank of a job does anyway); the sum of each step's uniforms (formed on the device by the call's
-first kernel) rides along in the all-reduced block, and ranks whose streams have diverged raise instead of accepting the step.  That replaces the pupil
+before the loop, as every rank of a job does anyway); the sum of each step's uniforms rides along in the all-reduced block, and ranks whose streams have diverged raise instead of accepting the step.  That replaces the pupil
 broadcast of ShardedPSF.psf_volume (one collective per step less); SURVEY.md §8e allows either.
 """
 import ctypes as C
@@ -34,7 +33,7 @@ from .basics import DEFAULT_WAVE, GEO_SPP
 
 
 class _Slot:
-    __slots__ = ("out", "u_host", "scratch", "ctl_host", "lanes", "ev_kernel", "ev_read", "ev_gather", "args", "lane_args",
+    __slots__ = ("out", "u_host", "u_bits", "scratch", "ctl_host", "lanes", "ev_kernel", "ev_read", "ev_gather", "args", "lane_args",
                  "stream", "k0", "k1", "used")
 
 
@@ -146,6 +145,7 @@ class VolumeStepper:
             s = _Slot()
             s.out = torch.zeros((self.width, 2, self.ks, self.ks), dtype=torch.float32, device=dev)
             s.u_host = torch.empty(self.n_u, dtype=torch.float32, pin_memory=True)
+            s.u_bits = s.u_host.numpy().view(np.uint32)
             s.scratch = torch.zeros(self.scratch_bytes, dtype=torch.uint8, device=dev)
             s.ctl_host = torch.zeros(_lib.CTL_WORDS, dtype=torch.int32, pin_memory=True)
             s.lanes = torch.zeros(_lib.CTL_LANES, dtype=torch.int32, device=dev)
@@ -169,7 +169,7 @@ class VolumeStepper:
                   P(L.data_ptr() + 4 * self.ks * self.ks), P(s.scratch.data_ptr()), None,
                   _lib.StreamArg(s.stream.cuda_stream, self.device.index))
         rb = _lib.StreamArg(self.rb_stream.cuda_stream, self.device.index)
-        s.lane_args = ((P(s.scratch.data_ptr()), P(s.lanes.data_ptr()), rb),
+        s.lane_args = ([P(s.scratch.data_ptr()), 0, P(s.lanes.data_ptr()), rb],
                        (P(s.lanes.data_ptr()), self.handle, self._tp, self._tc, P(s.scratch.data_ptr()), P(s.ctl_host.data_ptr()), rb))
 
     # ------------------------------------------------------------------ the loop
@@ -193,6 +193,8 @@ class VolumeStepper:
         # read-back stream: the render stream goes straight on to the next step's upload and kernel
         rb = self.rb_stream
         rb.wait_event(s.ev_kernel)
+        # (sharded: the sum of the step's uniforms rides along -- ranks whose generators have diverged are told so)
+        s.lane_args[0][1] = int(s.u_bits.sum(dtype=np.uint64)) & 0x3FFFFFFF if self.multi else 0
         _lib.check(self.h.sdirt_ctl_to_lanes(*s.lane_args[0]))
         if self.multi:
             with torch.cuda.stream(rb):
@@ -213,7 +215,7 @@ class VolumeStepper:
             self.t_wait += time.perf_counter() - t0
             t0 = time.perf_counter()
             w = s.ctl_host.numpy()
-            if int(w[_lib.CTL_UNIFORM_SUM]) + int(w[_lib.CTL_UNIFORM_SUM + 1]) != 0x3FFFFFFF:
+            if int(w[_lib.CTL_TAG]) + int(w[_lib.CTL_TAG + 1]) != 0x3FFFFFFF:
                 raise RuntimeError("the ranks of this batch drew different pupil uniforms: seed their CPU generators alike "
                                    "(torch.manual_seed) and draw nothing else from them between steps")
             if int(w[_lib.CTL_STATUS]) != 0:
@@ -272,7 +274,7 @@ class VolumeStepper:
                         self.ks, C.byref(self.dpp), ctp, ctc, self.flags & ~(_lib.PSF_ZERO_CTL | _lib.PSF_NO_VERIFY),
                         P(self.centers.data_ptr()), P(base + 4 * _lib.CTL_ANY_VALID), P(L.data_ptr()),
                         P(L.data_ptr() + 4 * self.ks * self.ks), P(base + 4 * _lib.CTL_MASKS), P(base + 4 * (_lib.CTL_MASKS + 64)), st))
-                _lib.check(h.sdirt_ctl_to_lanes(P(base), P(s.lanes.data_ptr()), st))
+                _lib.check(h.sdirt_ctl_to_lanes(P(base), 0, P(s.lanes.data_ptr()), st))
                 if self.multi:
                     self.dist.all_reduce(s.lanes, op=self.dist.ReduceOp.MAX, group=self.mask_group)
                 _lib.check(h.sdirt_ctl_from_lanes(P(s.lanes.data_ptr()), self.handle, ctp, ctc, P(base), P(s.ctl_host.data_ptr()), st))

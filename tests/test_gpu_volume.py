@@ -145,11 +145,10 @@ def test_lanes_round_trip_keeps_the_control_block():
     ctl = torch.zeros(_lib.CTL_WORDS, dtype=torch.int32)
     ctl[_lib.CTL_MASKS:_lib.CTL_MASKS + 128] = torch.randint(0, 2048, (128,), generator=g, dtype=torch.int32)
     ctl[_lib.CTL_ANY_VALID] = 1
-    ctl[_lib.CTL_UNIFORM_SUM], ctl[_lib.CTL_UNIFORM_SUM + 1] = 12345, 0x3FFFFFFF - 12345
     d = ctl.to(DEV)
     lanes = torch.full((_lib.CTL_LANES,), -7, dtype=torch.int32, device=DEV)
     h, sp = _lib.lib(), stream_ptr(torch.device(DEV))
-    _lib.check(h.sdirt_ctl_to_lanes(dptr(d), dptr(lanes), sp))
+    _lib.check(h.sdirt_ctl_to_lanes(dptr(d), 12345, dptr(lanes), sp))
     lv = lanes.cpu().numpy()
     assert set(np.unique(lv[:2 * 64 * 11 + 1])) <= {0, 1}
     back = torch.zeros_like(d)
