@@ -769,8 +769,7 @@ def bench_c5(args, emit=True):
     depth = -(500 + 4500 * torch.rand(1, 1, H, W, device=dev, generator=g))       # 0.5 ... 5 m
     foc = torch.tensor([-1000.0], device=dev)
     torch.manual_seed(1)
-    # inference: eval mode, batch norms folded into their convolutions (the same function, DfDPNet.folded_for_inference)
-    net = DfDPNet().to(dev).eval().folded_for_inference()
+    net = DfDPNet().to(dev).eval()
     stream = torch.cuda.current_stream(dev)
 
     def chain(ev=None):

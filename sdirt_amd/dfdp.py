@@ -222,29 +222,6 @@ class DfDPNet(nn.Module):
         cost = dp_cost_volume(self.feature(xl), self.feature(yr), self.maxdisp)
         return self.disp(self.matching(cost))
 
-    def folded_for_inference(self):
-        """A copy of this network in eval mode with every batch norm folded into the convolution in front of it
-        (torch.nn.utils.fusion.fuse_conv_bn_eval: W' = W * gamma / sqrt(var + eps), b' = beta - mean * gamma / sqrt(var + eps)
-        -- the same function of the input, one kernel per layer instead of two: 26 of the 52 batch-norm launches of a
-        forward pass are 0.2 ms of config 5's frame, profiles/r06/top_kernels_c5.txt).  The copy shares nothing with `self`
-        and has no batch-norm parameters left: it is for inference, checkpoints are loaded into the original."""
-        import copy
-        from torch.nn.utils.fusion import fuse_conv_bn_eval
-        net = copy.deepcopy(self).eval()
-        for m in net.modules():
-            if isinstance(m, BasicConv) and m.use_bn:
-                m.conv = fuse_conv_bn_eval(m.conv, m.bn, transpose=isinstance(m.conv, (nn.ConvTranspose2d, nn.ConvTranspose3d)))
-                m.bn, m.use_bn = nn.Identity(), False
-            elif isinstance(m, BasicConv):
-                m.bn = nn.Identity()                 # constructed for the checkpoint's keys, never applied (bn=False)
-            elif isinstance(m, nn.Sequential):
-                mods = list(m._modules.items())
-                for (ka, a), (kb, b) in zip(mods, mods[1:]):
-                    if isinstance(a, nn.Conv2d) and isinstance(b, nn.BatchNorm2d):       # _convbn of the context branches
-                        m._modules[ka] = fuse_conv_bn_eval(a, b)
-                        m._modules[kb] = nn.Identity()
-        return net
-
 
 class Basenet(nn.Module):
     """dfdp/basenet.py:9-105, depth-estimation mode: the DP pair rendered by PSFNet.render

@@ -174,22 +174,3 @@ def test_window_average_equals_avg_pool2d(dtype, k, shape):
     assert torch.allclose(x1.grad, x2.grad, rtol=0, atol=1e-7)
     odd = torch.randn(1, 2, 10, 13, device="cuda").to(dtype)
     assert torch.equal(WindowAverage((4, 4), stride=(4, 4))(odd), torch.nn.AvgPool2d((4, 4), stride=(4, 4))(odd))
-
-
-def test_batch_norm_folding_keeps_the_function():
-    """DfDPNet.folded_for_inference(): no batch norm left, the same disparity map (fp32, CPU) to rounding."""
-    from sdirt_amd.dfdp import DfDPNet
-    torch.manual_seed(3)
-    net = DfDPNet().eval()
-    with torch.no_grad():
-        for m in net.modules():                     # statistics and affine parameters a trained network would have
-            if isinstance(m, (torch.nn.BatchNorm2d, torch.nn.BatchNorm3d)):
-                m.running_mean.normal_(0, 0.1); m.running_var.uniform_(0.5, 1.5); m.weight.uniform_(0.5, 1.5); m.bias.normal_(0, 0.1)
-    folded = net.folded_for_inference()
-    assert not any(isinstance(m, (torch.nn.BatchNorm2d, torch.nn.BatchNorm3d)) for m in folded.modules())
-    assert any(isinstance(m, (torch.nn.BatchNorm2d, torch.nn.BatchNorm3d)) for m in net.modules())      # the original is untouched
-    g = torch.Generator().manual_seed(1)
-    left, right = torch.rand(1, 3, 128, 128, generator=g), torch.rand(1, 3, 128, 128, generator=g)
-    with torch.no_grad():
-        a, b = net(left, right), folded(left, right)
-    assert a.shape == b.shape and float((a - b).abs().max()) < 2e-3 * max(1.0, float(a.abs().max()))

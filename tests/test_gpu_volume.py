@@ -197,3 +197,32 @@ def test_deterministic_flag_makes_65x65_grids_repeat_from_run_to_run():
     with pytest.raises(_lib.SdirtError, match="SDIRT_PSF_DETERMINISTIC"):
         lens.psf_lr(pts[:1100], ks=75, spp=1024, dp=DP)
     lens.psf_lr(pts[:1100], ks=45, spp=1024, dp=DP)               # float64 tiles anyway: nothing to refuse
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("SDIRT_FUZZ_SEEDS", 4))))
+def test_stepper_fuzz_equals_psf_lr_bit_for_bit(seed):
+    """Random batch shapes with one workgroup per point (many points, or few samples), random grid sizes with float64
+    tiles (ks <= 49), random dual-pixel geometry, either lens: three steps of the loop == three psf_lr calls from the same
+    seed, bit for bit, whatever the trip tables do from step to step."""
+    from sdirt_amd.volume import VolumeStepper
+    rng = np.random.default_rng(1000 + seed)
+    name = "rf35mm" if rng.random() < 0.3 else "rf50mm"
+    if rng.random() < 0.5:
+        n, spp = int(rng.integers(1024, 2600)), int(rng.choice([256, 1000, 2048, 4096]))
+    else:
+        n, spp = int(rng.integers(1, 900)), int(rng.choice([64, 256, 777, 1024]))
+    ks = int(rng.integers(3, 50))
+    dp = (float(rng.uniform(0.6, 0.9)), float(rng.uniform(1.2, 1.6)), float(rng.uniform(0.2, 0.4)), float(rng.uniform(0.3, 0.5)))
+    pts = grid(n, seed=seed).to(DEV)
+    lens = make_lens(name, DEV)
+    if lens._spp_slices(n, spp) != 1:
+        pytest.skip("the spp axis is cut for this shape")
+    torch.manual_seed(seed)
+    want = [tuple(t.clone() for t in lens.psf_lr(pts, ks=ks, spp=spp, dp=dp)) for _ in range(3)]
+    lens2 = make_lens(name, DEV)
+    torch.manual_seed(seed)
+    st = VolumeStepper(lens2, pts, ks=ks, spp=spp, dp=dp, depth=2, streams=int(rng.integers(1, 3)))
+    outs = [st.step() for _ in range(3)]
+    st.fence()
+    for i, (blk, (L, R)) in enumerate(zip(outs, want)):
+        assert torch.equal(blk[:, 0], L) and torch.equal(blk[:, 1], R), (name, n, spp, ks, i)
