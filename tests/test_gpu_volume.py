@@ -132,6 +132,13 @@ def test_psf_call_status_word_and_corrected_tables_for_one_workgroup_per_point()
     assert newton.verify(tp, w[_lib.CTL_MASKS:_lib.CTL_MASKS + K], order, curved)[0]
     assert newton.verify(tc, w[_lib.CTL_MASKS + 64:_lib.CTL_MASKS + 64 + K], order, curved)[0]
     assert torch.equal(out[:, 0], L0) and torch.equal(out[:, 1], R0)
+    # uniforms in PAGEABLE memory (against the contract: not mapped into the device's address space) go through the copy
+    keep, u = u, u.clone()
+    assert not u.is_pinned()
+    out.zero_()
+    status, anyv, _, _, _ = call(tp, tc)
+    assert status == 0 and torch.equal(out[:, 0], L0) and torch.equal(out[:, 1], R0)
+    u = keep
 
 
 def test_lanes_round_trip_keeps_the_control_block():
