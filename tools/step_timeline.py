@@ -30,12 +30,17 @@ def run(args):
     pts = bench.volume_points(1, "c2")[:: 16384 // args.n].contiguous().to(dev)
     torch.manual_seed(0)
     st = VolumeStepper(lens, pts, pts.shape[0], 65, 4096, bench.DP, gather=args.collectives, force_collectives=args.collectives,
-                       streams=args.streams)
+                       streams=args.streams, time_steps=True)
     for _ in range(20):
         st.step()
     st.fence()
+    if args.freeze:
+        import gc
+        gc.collect()
+        gc.freeze()          # a full collection of torch's heap takes 40-55 ms: longer than the ~20 ms of work the loop keeps queued
     dt = st.timed(args.steps)
-    print(f"{pts.shape[0]} points, {args.steps} steps: {dt / args.steps * 1e3:.4f} ms per step, host {st.t_step / (args.steps + 20) * 1e6:.0f} us per step")
+    print(f"{pts.shape[0]} points, {args.steps} steps: {dt / args.steps * 1e3:.4f} ms per step, host {st.t_step / (args.steps + 20) * 1e6:.0f} us per step, "
+          f"library call {st.kernel_ms():.4f} ms by HIP events, gather {st.gather_ms()} ms, {st.depth} steps in flight")
 
 
 def report(out):
@@ -74,5 +79,6 @@ if __name__ == "__main__":
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--streams", type=int, default=1)
     ap.add_argument("--collectives", action="store_true")
+    ap.add_argument("--freeze", action="store_true", help="gc.freeze() before the timed steps (what bench.py does)")
     a = ap.parse_args()
     run(a) if a.mode == "run" else report(a.out)
