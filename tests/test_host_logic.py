@@ -586,3 +586,19 @@ def test_spp_slices_is_host_arithmetic_with_an_explicit_cu_count():
     assert h.sdirt_psf_spp_slices(64, 20000, 32) == 2            # one XCD of a partitioned chip
     assert h.sdirt_psf_spp_slices(1023, 4096, 256) == 2 and h.sdirt_psf_spp_slices(64, 1024, 256) == 1
     assert h.sdirt_psf_spp_slices(0, 4096, 256) == 1 and h.sdirt_psf_spp_slices(64, 0, 256) == 1
+
+
+def test_bench_defaults_to_strong_scaling_and_names_the_baseline_config():
+    """`bench.py --gpus N` measures what SURVEY.md §8e states unless told otherwise: the ONE volume of the workload cut into
+    N shards (a weak-scaling default would have put the first 8-GPU record on a 131072-point volume BASELINE
+    does not name)."""
+    import subprocess
+    import sys
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    flat = " ".join(p.stdout.split())
+    assert "--scaling {weak,strong}" in flat and "strong (default; SURVEY.md §8e" in flat and "--detail-file" in flat
+    import bench
+    assert bench.volume_points(1, "c2").shape == (16384, 3) and bench.volume_points(8, "c3").shape == (65536, 3)
+    from sdirt_amd import dist as sd
+    assert [b - a for a, b in sd.shard_bounds(16384, 8)] == [2048] * 8
