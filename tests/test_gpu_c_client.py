@@ -111,7 +111,9 @@ def test_c_program_on_a_batch_with_both_subpixels(tmp_path, oracle):
     lo, ro, co, ok, tp, tc = oracle.psf(st, pts, x2, y2, xc, yc, ks, dp=dp, return_trips=True)
     assert ok and np.array_equal(trips, tp) and np.array_equal(trips_c, tc), (trips, tp, trips_c, tc)
     assert ulp(cen, co) <= 1
-    assert np.abs(L - lo).max() < 2e-6 and np.abs(R - ro).max() < 2e-6, (np.abs(L - lo).max(), np.abs(R - ro).max())
+    # 4096 samples per point: the whole-batch bar of tests/test_gpu_full_size.py (measured there: <= 3.9e-6)
+    assert np.abs(L - lo).max() < 5e-6 and np.abs(R - ro).max() < 5e-6, (np.abs(L - lo).max(), np.abs(R - ro).max())
+    print(f"psf_client, 12 points x 4096 spp vs oracle: {np.abs(L - lo).max():.2e} / {np.abs(R - ro).max():.2e}, rounds {rounds}")
     assert rounds <= 3
 
 
