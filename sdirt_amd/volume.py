@@ -32,6 +32,26 @@ from . import _hostrng, _lib
 from .basics import DEFAULT_WAVE, GEO_SPP
 
 
+_STREAMS = {}      # (device index, role, i) -> the package's stream of that role on that device
+_GROUPS = {}       # id of the parent process group -> (mask communicator, gather communicator)
+
+
+def _stream(dev, role, i=0):
+    key = (torch.device(dev).index or 0, role, i)
+    if key not in _STREAMS:
+        _STREAMS[key] = torch.cuda.Stream(dev)
+    return _STREAMS[key]
+
+
+def _groups(dist, parent):
+    """Two communicators beside `parent` (every rank of it calls this at the same point of its program)."""
+    key = id(parent) if parent is not None else 0
+    if key not in _GROUPS or _GROUPS[key][2] is not dist.group.WORLD:
+        ranks = None if parent is None else dist.get_process_group_ranks(parent)
+        _GROUPS[key] = (dist.new_group(ranks), dist.new_group(ranks), dist.group.WORLD)
+    return _GROUPS[key][:2]
+
+
 class _Slot:
     __slots__ = ("out", "u_host", "u_bits", "scratch", "ctl_host", "lanes", "ev_kernel", "ev_read", "ev_gather", "args", "lane_args",
                  "stream", "k0", "k1", "used")
@@ -83,14 +103,19 @@ class VolumeStepper:
         if self.n_local and lens._spp_slices(self.n_local, self.spp) != 1:
             raise ValueError("VolumeStepper is for batches with one workgroup per point (sdirt_psf_spp_slices == 1); "
                              "few points with many samples: Lensgroup.psf_lr")
-        self._main = torch.cuda.current_stream(dev)
-        self.render_streams = [torch.cuda.Stream(dev) for _ in range(streams)] if streams > 1 else [self._main]
-        self.rb_stream = torch.cuda.Stream(dev)
+        # The render stream(s) are the package's own, never the caller's current stream: the legacy default stream
+        # synchronises implicitly with every blocking stream of the process (RCCL's internal ones among them: +0.12 ms per
+        # 2048-point step with nothing but the mask all-reduce in the loop, profiles/r06/stream_reuse.txt).  And they --
+        # like the read-back and comm streams and the two communicators below -- are made ONCE per device / parent group
+        # and shared by every stepper of the process: HIP maps streams onto its hardware queues round-robin and a queue
+        # runs in order, so a process that keeps creating streams ends up with its render stream behind somebody's small
+        # kernels and event waits (the same sweep of ten steppers: a rank of 8 at 0.89 instead of 0.93 of its share).
+        self.render_streams = [_stream(dev, "render", i) for i in range(max(1, streams))]
+        self.rb_stream = _stream(dev, "readback")
         # (`gather` may be switched between two fences: the stream and the communicator exist whenever the batch is sharded)
-        self.comm_stream = torch.cuda.Stream(dev) if self.multi else None
+        self.comm_stream = _stream(dev, "comm") if self.multi else None
         # communicators of their own: the collectives of one process group share one internal stream
-        self.mask_group = dist.new_group() if self.multi else None
-        self.gather_group = dist.new_group() if self.multi else None
+        self.mask_group, self.gather_group = _groups(dist, group) if self.multi else (None, None)
         with torch.cuda.device(dev):
             self.po = lens._points_to_object_now(self.points) if self.n_local else torch.empty((0, 3), device=dev)
         self.centers = torch.empty((max(self.n_local, 1), 2), dtype=torch.float32, device=dev)

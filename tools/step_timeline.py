@@ -29,7 +29,7 @@ def run(args):
     lens = bench.build_lens(dev)
     pts = bench.volume_points(1, "c2")[:: 16384 // args.n].contiguous().to(dev)
     torch.manual_seed(0)
-    st = VolumeStepper(lens, pts, pts.shape[0], 65, 4096, bench.DP, gather=args.collectives, force_collectives=args.collectives,
+    st = VolumeStepper(lens, pts, pts.shape[0], 65, 4096, bench.DP, gather=args.collectives and not args.no_gather, force_collectives=args.collectives,
                        streams=args.streams, time_steps=True)
     for _ in range(20):
         st.step()
@@ -79,6 +79,7 @@ if __name__ == "__main__":
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--streams", type=int, default=1)
     ap.add_argument("--collectives", action="store_true")
+    ap.add_argument("--no-gather", action="store_true", help="--collectives without the all-gather (the mask all-reduce only)")
     ap.add_argument("--freeze", action="store_true", help="gc.freeze() before the timed steps (what bench.py does)")
     a = ap.parse_args()
     run(a) if a.mode == "run" else report(a.out)
