@@ -15,8 +15,11 @@ OR-reduced over the ranks (one small all-reduce per step), and the [N/world, 2, 
 all-gathered to every rank with ONE RCCL collective per step (485 MB received per rank and step at N = 8) on a side
 stream under the next step's kernel -- `value` includes it, `value_no_gather` is the same loop without it; `gather`
 carries the bytes a rank receives per step, the all-gather's own time on its stream and `gather_bound` (does it take
-longer than the kernel it hides under?).  `--scaling weak`: every rank renders its own 16384-point slab of a
-32x32x(16*N) volume.
+longer than the kernel it hides under?) and `volume_checksums_equal` (every rank's copy of the volume holds every rank's
+shard bit for bit).  The run ends with `gather.trial`: the same K timed steps with the shards exchanged as seven concurrent
+peer transfers per rank ('direct') instead of RCCL's all-gather, under a deadline; the faster one is `value`, both are
+reported (`value_allgather`, `value_direct`; SDIRT_GATHER_TRIAL=0 or a set SDIRT_GATHER_ALGO skips it).  `--scaling weak`:
+every rank renders its own 16384-point slab of a 32x32x(16*N) volume.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--scaling strong|weak]   (N > 1: starts its own N ranks)
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
@@ -105,7 +108,7 @@ LINE_LIMIT = 4000      # bytes: the driver keeps the parsed line whole only when
 _TOP = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
         "dtype", "data", "world_size", "backend", "psfs_per_sec", "render_streams", "kernel_ms", "value_no_gather",
         "ms_per_step_no_gather", "value_two_streams", "ms_per_step_two_streams", "ms_per_step_sustained", "value_sustained",
-        "sustained_steps", "value_pcie_inclusive")
+        "sustained_steps", "value_pcie_inclusive", "value_allgather", "value_direct")
 _CFG = ("workload", "name", "points_per_gpu", "spp", "ks", "parallelism", "gather", "newton_trip_policy",
         "relaunches_in_timed_region", "miopen_find_mode", "miopen_find_seconds", "backend")
 
@@ -144,7 +147,9 @@ def compact(res):
     if g:
         out["gather"] = {k: g[k] for k in ("algo", "backend", "world_size", "gb_received_per_rank_per_step",
                                            "collectives_per_step", "ms", "GBps_received_per_rank", "compute_ms",
-                                           "gather_bound") if k in g}
+                                           "gather_bound", "volume_checksums_equal") if k in g}
+        if g.get("trial"):
+            out["gather"]["trial"] = {k: v for k, v in g["trial"].items() if k != "what"}
     also = res.get("also")
     if also:
         summ = {}
@@ -938,6 +943,65 @@ def bench_tcp(args, emit=True):
     return res
 
 
+TRIAL_DEADLINE_S = float(os.environ.get("SDIRT_BENCH_TRIAL_DEADLINE_S", "120"))
+
+
+def gather_algo_trial(loop, steps, dt_default, res, rays):
+    """N > 1, LAST thing of the run (every rank calls it; `res` is rank 0's finished record, None elsewhere): the same K
+    timed steps once more with the shards exchanged as seven concurrent peer transfers per rank (dist.all_gather_shards
+    algo 'direct') instead of RCCL's all-gather -- xGMI is a full mesh of point-to-point links, and which of the two
+    feeds a rank's seven links better is a question for the node.  Measured like the
+    headline (VolumeStepper.timed: K steps between two fences, MAX over ranks, so every rank sees the same figures and
+    takes the same decision), checksums compared as for the headline; on its own communicator, so nothing of the
+    product's is touched.  The faster of the two becomes `value` (a margin of 3 %), both stay in `gather.trial`.
+
+    An experiment must not cost the record: it runs under a deadline.  If it has not returned by then, or raises,
+    rank 0 prints the record it already has (RCCL's all-gather, complete) and every rank leaves at once -- there is no
+    orderly way out of a collective that a peer never entered."""
+    import threading
+    import torch.distributed as dist
+
+    def leave(why):
+        if res is not None:
+            res["gather"]["trial"] = {"allgather_ms_per_step": dt_default / steps * 1e3, "direct": why, "adopted": "allgather"}
+            emit_line(res)
+        sys.stderr.flush()
+        os._exit(0)
+    done = threading.Event()
+    watch = threading.Thread(target=lambda: done.wait(TRIAL_DEADLINE_S) or leave(f"no result within {TRIAL_DEADLINE_S:.0f} s"), daemon=True)
+    watch.start()
+    keep = (loop.gather_group, loop.gather_algo)
+    try:
+        if os.environ.get("SDIRT_BENCH_FAKE_TRIAL") == "hang":       # (tests: the deadline path)
+            time.sleep(10 * TRIAL_DEADLINE_S)
+        if os.environ.get("SDIRT_BENCH_FAKE_TRIAL") == "raise":
+            raise RuntimeError("SDIRT_BENCH_FAKE_TRIAL")
+        loop.gather_group, loop.gather_algo = dist.new_group(), "direct"
+        for _ in range(3):                 # the peer connections come up with the first transfers
+            loop.step()
+        loop.fence()
+        dt_direct = loop.timed(steps)
+        ok = loop.verify_gather()
+    except Exception as e:                 # noqa: BLE001 -- whatever it is, the record comes first
+        leave(f"{type(e).__name__}: {str(e)[:200]}")
+    finally:
+        done.set()
+    loop.gather_group, loop.gather_algo = keep
+    if res is not None:
+        adopt = bool(ok) and dt_direct < 0.97 * dt_default
+        res["gather"]["trial"] = {"allgather_ms_per_step": dt_default / steps * 1e3, "direct_ms_per_step": dt_direct / steps * 1e3,
+                                  "direct_volume_checksums_equal": ok, "adopted": "direct" if adopt else "allgather",
+                                  "what": "the K timed steps once more with algo 'direct' (one send + one receive per peer in one "
+                                          "group), same fences, MAX over ranks; adopted as `value` when checksums hold and it "
+                                          "is more than 3 % faster"}
+        res["value_allgather"], res["value_direct"] = rays / dt_default, rays / dt_direct
+        if adopt:
+            res["value"], res["ms_per_step"] = rays / dt_direct, dt_direct / steps * 1e3
+            res["psfs_per_sec"] = res["psfs_per_sec"] * dt_default / dt_direct
+            res["gather"]["algo"] = "direct"
+            res["gather"]["volume_checksums_equal"] = ok
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -1053,6 +1117,8 @@ def main():
     dt = loop.timed(args.steps)
     relaunches = loop.relaunches - relaunch0
     k_event_ms = loop.kernel_ms()
+    # N > 1: every rank's copy of the volume holds every rank's shard, bit for bit (checksums of the last step's blocks)
+    gather_ok = loop.verify_gather() if gather_default else None
     host_us = loop.t_step / args.steps * 1e6
     # the all-gathers of the timed steps as the comm stream saw them (start = the shard is final and the previous
     # gather has left the stream, end = every rank's shard has arrived here); MAX over ranks like the wall time
@@ -1211,7 +1277,7 @@ def main():
             gb = 2 * (n_total - n_local) * KS * KS * 4 / 1e9      # received per rank and step
             compute_ms = k_ms[dom]
             width = max(b_ - a_ for a_, b_ in sd.shard_bounds(n_total, world))
-            res["gather"] = {"algo": os.environ.get("SDIRT_GATHER_ALGO", "allgather"),
+            res["gather"] = {"algo": os.environ.get("SDIRT_GATHER_ALGO", "allgather"), "volume_checksums_equal": gather_ok,
                              "backend": dist.get_backend(), "world_size": dist.get_world_size(),
                              "gb_received_per_rank_per_step": gb, "collectives_per_step": 1,
                              "block": f"[{width}, 2, {KS}, {KS}] fp32 per rank, rendered in place (SDIRT_PSF_INTERLEAVED)",
@@ -1233,6 +1299,11 @@ def main():
             res["also"] = also_block(args, lens, device)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(lens, points_all, pupil_last)
+    else:
+        res = None
+    if gather_default and "SDIRT_GATHER_ALGO" not in os.environ and os.environ.get("SDIRT_GATHER_TRIAL", "1") == "1":
+        gather_algo_trial(loop, args.steps, dt, res, n_total * SPP * args.steps)
+    if rank == 0:
         emit_line(res)
     if world > 1:
         dist.barrier()

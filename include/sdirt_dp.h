@@ -521,6 +521,15 @@ int sdirt_dp_cost_volume(const void* x /*dev*/, const void* y /*dev*/, int32_t b
                          int32_t channels, int32_t d_max, int32_t height, int32_t width,
                          int32_t half_precision, void* cost /*dev, out*/, void* stream);
 
+/* The same volume between pixel-major tensors: x, y stored [B,H,W,C] (what a channels_last [B,C,H,W] tensor is in memory)
+ * -> cost stored [B,D,H,W,2C] (a channels_last_3d [B,2C,D,H,W] tensor), element for element what sdirt_dp_cost_volume
+ * writes (dfdp/dddnet/dddnet.py:136-148).  The layout the hourglass's 3-D convolutions (dddnet.py:409-446) compute in:
+ * nothing is transposed between the feature network and the first of them.  16-byte accesses when `channels` is a
+ * multiple of 8 (fp16) / 4 (fp32) and the three pointers are 16-byte aligned, element-wise otherwise. */
+int sdirt_dp_cost_volume_nhwc(const void* x /*dev*/, const void* y /*dev*/, int32_t batch,
+                              int32_t channels, int32_t d_max, int32_t height, int32_t width,
+                              int32_t half_precision, void* cost /*dev, out*/, void* stream);
+
 /* Adjoint of sdirt_dp_cost_volume for training the depth network: grad_cost [B,2C,D,H,W] ->
  * grad_x, grad_y [B,C,H,W] (each input element sums the gradients of the volume elements it was
  * copied to, fp32 accumulation). */

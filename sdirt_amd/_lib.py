@@ -108,6 +108,7 @@ SIGNATURES = {
     "sdirt_mlp_pack": (C.c_int, [C.POINTER(_P), C.POINTER(_P), C.POINTER(_I32), _I32, _P, _P]),
     "sdirt_psfnet_mlp": (C.c_int, [_P, C.POINTER(_I32), _I32, _P, _I64, _I32, _P, _P]),
     "sdirt_dp_cost_volume": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P]),
+    "sdirt_dp_cost_volume_nhwc": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P]),
     "sdirt_tone_curve": (C.c_int, [_P, _I64, _I32, _P, _P]),
     "sdirt_avg_pool_windows": (C.c_int, [_P, _I64, _I32, _I32, _I32, _I32, _P, _P]),
     "sdirt_dp_cost_volume_backward": (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P, _P]),

@@ -42,6 +42,38 @@ k_dp_cost_volume(const T* __restrict__ x, const T* __restrict__ y, int B, int C,
     }
 }
 
+// The same volume for feature maps stored pixel-major (the storage of a channels_last tensor: [B, H, W, C]) into a volume
+// stored [B, D, H, W, 2C] (channels_last_3d) -- the layout MIOpen's 3-D convolutions of the hourglass compute in, so that
+// nothing is transposed on the way from the feature network to the first of them.  One thread per 16-byte group of
+// channels of one (b, i, h, w): a pixel's 2C channels are one contiguous run, loads and stores are both coalesced.
+template <typename T, int VL>
+__global__ void __launch_bounds__(256)
+k_dp_cost_volume_nhwc(const T* __restrict__ x, const T* __restrict__ y, int B, int C, int D, int H, int W,
+                      T* __restrict__ cost)
+{
+    typedef T vec __attribute__((ext_vector_type(VL)));
+    const int groups = 2 * C / VL, half = C / VL;
+    const int64_t total = (int64_t)B * D * H * W * groups;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (int64_t)gridDim.x * blockDim.x) {
+        const int g = (int)(t % groups);
+        int64_t rest = t / groups;
+        const int w = (int)(rest % W); rest /= W;
+        const int h = (int)(rest % H); rest /= H;
+        const int i = (int)(rest % D);
+        const int b = (int)(rest / D);
+        const int gap = i - D / 2;
+        const bool right = g >= half;
+        const int lo = gap > 0 ? gap : 0, hi = gap < 0 ? W + gap : W;     // columns that receive data
+        const int ws = right ? w - gap : w;                               // y is read at w - gap
+        vec v = {};
+        if (w >= lo && w < hi)
+            v = *reinterpret_cast<const vec*>((right ? y : x) + (((int64_t)b * H + h) * W + ws) * C +
+                                              (int64_t)(right ? g - half : g) * VL);
+        *reinterpret_cast<vec*>(cost + t * VL) = v;
+    }
+}
+
 // Adjoint of the cost volume: every input element collects the gradient of the (up to D) volume
 // elements it was copied to.  One thread per input element, reads coalesced along w.
 template <typename T>
@@ -113,6 +145,29 @@ extern "C" int sdirt_dp_cost_volume(const void* x, const void* y, int32_t batch,
         k_dp_cost_volume<float><<<grid, 256, 0, as_stream(stream)>>>(
             static_cast<const float*>(x), static_cast<const float*>(y), batch, channels, d_max, height, width,
             static_cast<float*>(cost));
+    LAUNCH_CHECK();
+    return SDIRT_OK;
+}
+
+extern "C" int sdirt_dp_cost_volume_nhwc(const void* x, const void* y, int32_t batch, int32_t channels,
+                                         int32_t d_max, int32_t height, int32_t width, int32_t half_precision,
+                                         void* cost, void* stream)
+{
+    if (!x || !y || !cost || batch < 0 || channels < 1 || d_max < 1 || height < 1 || width < 1)
+        return fail(SDIRT_ERR_INVALID_ARGUMENT, "bad argument");
+    if (d_max / 2 >= width) return fail(SDIRT_ERR_INVALID_ARGUMENT, "d_max/2 must be < width");
+    if (batch == 0) return SDIRT_OK;
+    // 16-byte groups where the channel count and the pointers allow it, single elements otherwise
+    const int vl = half_precision ? 8 : 4;
+    const bool wide = channels % vl == 0 && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)cost) & 15) == 0;
+    const int64_t total = (int64_t)batch * d_max * height * width * (2 * channels / (wide ? vl : 1));
+    const int grid = (int)std::min<int64_t>((total + 255) / 256, 256 * 64);
+    hipStream_t st = as_stream(stream);
+#define SDIRT_CV(T, VL) k_dp_cost_volume_nhwc<T, VL><<<grid, 256, 0, st>>>(static_cast<const T*>(x), static_cast<const T*>(y), \
+                            batch, channels, d_max, height, width, static_cast<T*>(cost))
+    if (half_precision) { if (wide) SDIRT_CV(_Float16, 8); else SDIRT_CV(_Float16, 1); }
+    else { if (wide) SDIRT_CV(float, 4); else SDIRT_CV(float, 1); }
+#undef SDIRT_CV
     LAUNCH_CHECK();
     return SDIRT_OK;
 }

@@ -45,12 +45,21 @@ class _CostVolume(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, y, d_max):
         B, C, H, W = x.shape
-        x, y = x.contiguous(), y.to(x.dtype).contiguous()
-        cost = torch.empty((B, 2 * C, d_max, H, W), dtype=x.dtype, device=x.device)
-        _lib.check(_lib.lib().sdirt_dp_cost_volume(dptr(x), dptr(y), B, C, d_max, H, W,
-                                                   1 if x.dtype == torch.float16 else 0,
-                                                   dptr(cost), stream_ptr(x.device)))
+        y = y.to(x.dtype)
         ctx.shape, ctx.d_max = (B, C, H, W), d_max
+        half = 1 if x.dtype == torch.float16 else 0
+        cl = torch.channels_last
+        if not x.is_contiguous() and x.is_contiguous(memory_format=cl) and y.is_contiguous(memory_format=cl):
+            # pixel-major feature maps (the inference layout of DfDPNet) -> a channels_last_3d volume: what the
+            # hourglass's convolutions compute in, nothing transposed in between
+            cost = torch.empty((B, 2 * C, d_max, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last_3d)
+            _lib.check(_lib.lib().sdirt_dp_cost_volume_nhwc(dptr(x), dptr(y), B, C, d_max, H, W, half,
+                                                            dptr(cost), stream_ptr(x.device)))
+            return cost
+        x, y = x.contiguous(), y.contiguous()
+        cost = torch.empty((B, 2 * C, d_max, H, W), dtype=x.dtype, device=x.device)
+        _lib.check(_lib.lib().sdirt_dp_cost_volume(dptr(x), dptr(y), B, C, d_max, H, W, half,
+                                                   dptr(cost), stream_ptr(x.device)))
         return cost
 
     @staticmethod
@@ -218,9 +227,27 @@ class DfDPNet(nn.Module):
                 nn.init.constant_(m.weight, 1)
                 nn.init.constant_(m.bias, 0)
 
+    #: inference on the GPU (eval mode): BOTH views through the feature network in ONE pass (a batch of two: batch norm
+    #: uses its running statistics in eval mode, so the halves are what two calls give), the 2-D network in channels_last,
+    #: the cost volume and the 3-D hourglass in channels_last_3d -- the layouts MIOpen's MI355X convolution kernels
+    #: compute in (no transposes around them).  512 x 768, fp16 autocast, after the find pass: 2.50 -> 2.1 ms
+    #: (tools/dfdp_ab.py, profiles/r06/dfdp_ab.txt).  Training keeps the reference's two calls (batch statistics per view).
+    inference_layout = True
+
+    def _lay_out(self):
+        if not getattr(self, "_laid_out", False):
+            self.feature.to(memory_format=torch.channels_last)            # 4-D weights only; values, names, dtypes unchanged
+            self.matching.to(memory_format=torch.channels_last_3d)        # 5-D weights only
+            self._laid_out = True
+
     def forward(self, xl, yr):
-        cost = dp_cost_volume(self.feature(xl), self.feature(yr), self.maxdisp)
-        return self.disp(self.matching(cost))
+        if self.training or not self.inference_layout or not xl.is_cuda or xl.shape != yr.shape or xl.dtype != yr.dtype:
+            cost = dp_cost_volume(self.feature(xl), self.feature(yr), self.maxdisp)          # dddnet.py:123-148
+            return self.disp(self.matching(cost))
+        self._lay_out()
+        B = xl.shape[0]
+        f = self.feature(torch.cat((xl, yr)).contiguous(memory_format=torch.channels_last))
+        return self.disp(self.matching(dp_cost_volume(f[:B], f[B:], self.maxdisp)))
 
 
 class Basenet(nn.Module):

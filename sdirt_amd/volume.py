@@ -94,6 +94,9 @@ class VolumeStepper:
         if self.ks > _lib.MAX_KS:
             raise ValueError(f"ks <= {_lib.MAX_KS} (larger grids: Lensgroup.psf_lr)")
         self.gather = bool(gather and self.multi)
+        #: None: dist.all_gather_shards' default (env SDIRT_GATHER_ALGO, else ONE RCCL all-gather); 'direct': one send and one
+        #: receive per peer in a single group (may be switched between two fences, like `gather` and `gather_group`)
+        self.gather_algo = None
         self.time_steps = bool(time_steps)
         h = self.h = _lib.lib()
         dev = self.device
@@ -254,7 +257,8 @@ class VolumeStepper:
                     g0 = torch.cuda.Event(enable_timing=True) if self.time_steps else None
                     if g0 is not None:
                         g0.record(cs)
-                    self._volume = self.sd.all_gather_shards(s.out, self.n_total, self.world, self.gather_group, out=buf, padded=True)
+                    self._volume = self.sd.all_gather_shards(s.out, self.n_total, self.world, self.gather_group, out=buf,
+                                                             algo=self.gather_algo, padded=True)
                     done = torch.cuda.Event(enable_timing=self.time_steps)
                     done.record(cs)
                     if g0 is not None:
@@ -337,6 +341,28 @@ class VolumeStepper:
     def volume(self):
         """The most recently gathered [n_total, 2, ks, ks] volume (after fence())."""
         return self._volume
+
+    def verify_gather(self):
+        """After fence(), gathering on: did the last all-gather deliver every rank's rows to every rank?  Each rank sums the
+        BIT PATTERNS of the block it rendered in the last step (int64 sum of the int32 view: exact, order-free), the sums
+        travel in one small all-reduce, and every rank compares them with the sums of the corresponding rows of ITS copy of
+        the volume.  -> True on every rank iff every rank's copy holds every shard bit for bit; None when nothing was gathered."""
+        if not (self.gather and self.gathers and self._volume is not None):
+            return None
+        dist, dev = self.dist, self.device
+        s = self._slots[(self.steps - 1) % len(self._slots)]
+        sums = torch.zeros(self.world + 1, dtype=torch.int64, device=dev)
+        if self.n_local:
+            sums[self.rank] = s.out[:self.n_local].view(torch.int32).sum(dtype=torch.int64)
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=self.group)
+        vol = self._volume
+        mine = torch.stack([vol[a:b].reshape(-1).view(torch.int32).sum(dtype=torch.int64) if b > a
+                            else torch.zeros((), dtype=torch.int64, device=dev)
+                            for a, b in self.sd.shard_bounds(self.n_total, self.world)])
+        bad = torch.zeros(1, dtype=torch.int64, device=dev)
+        bad[0] = int(not bool((mine == sums[:self.world]).all()))
+        dist.all_reduce(bad, op=dist.ReduceOp.SUM, group=self.group)
+        return int(bad.item()) == 0
 
     def kernel_ms(self):
         """Mean HIP-event time of the slots' most recent library call (upload of 48 KB + pupil mapping + fused kernel)

@@ -135,6 +135,54 @@ def test_dfdp_net_and_cost_volume_kernel_on_the_gpu():
 
 
 @pytest.mark.gpu
+def test_inference_layout_one_feature_pass_pixel_major_tensors():
+    """DfDPNet in eval mode on the GPU: both views through the feature network in one pass, channels_last / channels_last_3d
+    tensors, the cost volume written pixel-major by sdirt_dp_cost_volume_nhwc -- element for element the volume of the
+    planar kernel (16-byte and element-wise forms, fp16 and fp32, ragged widths), the network's output that of the
+    reference's two calls within fp32 convolution noise, parameters (names, values) untouched."""
+    from sdirt_amd.dfdp import DfDPNet, dp_cost_volume
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(11)
+    for shape, d in (((1, 32, 16, 24), 20), ((2, 8, 5, 33), 20), ((2, 5, 7, 33), 6), ((1, 4, 3, 9), 6), ((1, 3, 2, 130), 12)):
+        for dt in (torch.float32, torch.float16):
+            a, b = torch.rand(*shape, generator=g).to(dev, dt), torch.rand(*shape, generator=g).to(dev, dt)
+            want = dp_cost_volume(a, b, d)
+            both = torch.cat((a, b)).contiguous(memory_format=torch.channels_last)       # slices of one pixel-major tensor
+            n = shape[0]
+            got = dp_cost_volume(both[:n], both[n:], d)
+            assert got.is_contiguous(memory_format=torch.channels_last_3d) and not got.is_contiguous()
+            assert torch.equal(got, want), (shape, dt)
+            # the adjoint of the pixel-major form is the planar kernel's
+            wgt = torch.rand(want.shape, generator=g).to(dev, dt)
+            a1, b1 = a.clone().requires_grad_(), b.clone().requires_grad_()
+            (dp_cost_volume(a1, b1, d) * wgt).sum().backward()
+            a2 = a.contiguous(memory_format=torch.channels_last).requires_grad_()
+            b2 = b.contiguous(memory_format=torch.channels_last).requires_grad_()
+            (dp_cost_volume(a2, b2, d) * wgt).sum().backward()
+            assert torch.equal(a1.grad, a2.grad) and torch.equal(b1.grad, b2.grad)
+    fx = load_golden("f10_dfdp_net")
+    net = build(fx).to(dev)
+    before = {k: v.clone() for k, v in net.state_dict().items()}
+    xl, xr, _, _ = inputs(fx)
+    xl, xr = xl.to(dev), xr.to(dev)
+    with torch.no_grad():
+        net.inference_layout = False
+        two = net(xl, xr)
+        net.inference_layout = True
+        one = net(xl, xr)
+        assert net._laid_out and net.feature.start[0].conv.weight.is_contiguous(memory_format=torch.channels_last)
+        assert (one - two).abs().max().item() < 1e-3 and np.abs(one.cpu().numpy() - fx["disp"]).max() < 2e-3
+        with torch.autocast("cuda", dtype=torch.float16):
+            one16 = net(xl, xr)
+        assert np.abs(one16.float().cpu().numpy() - fx["disp"]).max() < 5e-2
+    after = net.state_dict()
+    assert list(after) == list(before) and all(torch.equal(after[k], before[k]) for k in before)
+    net.train()                                                  # training: the reference's two calls (batch statistics per view)
+    out = net(xl, xr)
+    assert out.requires_grad and torch.isfinite(out).all()
+
+
+@pytest.mark.gpu
 def test_cost_volume_other_cuda_dtypes_take_the_reference_formulation():
     """bf16 autocast and float64 gradcheck of the depth network on the GPU: dtypes the
     kernel is not built for go through the reference's own slice-assignment formulation."""

@@ -8,6 +8,7 @@ import tempfile
 import os
 import socket
 import subprocess
+import time
 import sys
 
 import pytest
@@ -195,6 +196,40 @@ def test_bench_strong_scaling_config2_with_eight_ranks_on_one_gpu(algo, tmp_path
     if log:
         with open(os.path.join(log, f"bench_gpus8_dryrun_c2_strong_{algo}.log"), "w") as f:
             f.write(lines[0] + "\n")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fake", [None, "hang", "raise"])
+def test_bench_gather_trial_and_its_deadline(fake, tmp_path):
+    """`bench.py --gpus 4` with no gather algorithm named: the run ends with the K timed steps once more on 'direct'
+    (gather.trial: both figures, checksums of both volumes, which one `value` is) -- and an experiment that hangs or raises
+    (SDIRT_BENCH_FAKE_TRIAL) costs nothing: rank 0 prints the record it already had, every rank leaves, rc 0."""
+    env = _env(SDIRT_BENCH_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "SDIRT_GATHER_ALGO", "SDIRT_GATHER_TRIAL"):
+        env.pop(k, None)
+    if fake:
+        env.update(SDIRT_BENCH_FAKE_TRIAL=fake, SDIRT_BENCH_TRIAL_DEADLINE_S="8")
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "2", "--warmup", "1",
+                        "--workload", "c3", "--sustain-seconds", "0", "--detail-file", str(tmp_path / "detail.json")],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout + p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and len(lines[0]) < 4000, p.stdout
+    res = json.loads(lines[0])
+    g = res["gather"]
+    assert res["n_gpus"] == 4 and res["value"] > 0 and g["volume_checksums_equal"] is True
+    t = g["trial"]
+    if fake is None:
+        assert t["direct_ms_per_step"] > 0 and t["allgather_ms_per_step"] > 0 and t["direct_volume_checksums_equal"] is True
+        assert t["adopted"] in ("allgather", "direct") and g["algo"] == t["adopted"]
+        assert res["value_allgather"] > 0 and res["value_direct"] > 0
+        assert res["value"] == pytest.approx(res["value_" + t["adopted"]], rel=1e-5)
+    else:
+        assert t["adopted"] == "allgather" and g["algo"] == "allgather"
+        assert ("no result within" in t["direct"]) if fake == "hang" else ("SDIRT_BENCH_FAKE_TRIAL" in t["direct"])
+        assert "value_direct" not in res
+    assert time.time() - t0 < 600
 
 
 @pytest.mark.gpu
