@@ -544,6 +544,34 @@ int sdirt_dp_cost_volume_backward(const void* grad_cost /*dev*/, int32_t batch, 
 int sdirt_avg_pool_windows(const void* x /*dev*/, int64_t planes, int32_t height, int32_t width, int32_t k,
                            int32_t half_precision, void* out /*dev*/, void* stream);
 
+/* ---- depth network, inference-time fusions (eval mode; training keeps torch's differentiable ops) ---- */
+
+/* The tail of BasicConv.forward (dfdp/dddnet/dddnet.py:539-543) in eval mode: batch norm with its running statistics
+ * (y = gamma * (x - mean) * invstd + beta, invstd = 1 / sqrt(running_var + eps), evaluated in fp32 in torch's term order)
+ * followed by ReLU when relu != 0 -- ONE pass, in place, over the convolution's output x = [outer][channels][inner]
+ * (planar tensors: outer = batch, inner = the spatial size; channels_last / channels_last_3d tensors: outer = batch x
+ * spatial size, inner = 1).  mean / invstd / gamma / beta: dev fp32 [channels].  half_precision != 0: x is fp16. */
+int sdirt_bn_relu(void* x /*dev, in place*/, int64_t outer, int32_t channels, int64_t inner, const float* mean /*dev*/,
+                  const float* invstd /*dev*/, const float* gamma /*dev*/, const float* beta /*dev*/, int32_t relu,
+                  int32_t half_precision, void* stream);
+
+/* Disp + DisparityRegression (dfdp/dddnet/dddnet.py:543-568): cost [B, 1, d_in, h_in, w_in] (the hourglass's output) ->
+ * trilinear interpolation to [d_out, h_out, w_out] (align_corners = False, as F.interpolate(x, size)) -> softmin over the
+ * d_out shifts -> expectation over the shifts arange(-d_out // 2, d_out // 2) -> disp fp32 [B, 1, h_out, w_out]; all in
+ * fp32 (what autocast runs these ops in), one thread per output pixel.  d_in <= 32, d_out <= 64 (the reference: 10 -> 20);
+ * SDIRT_ERR_UNSUPPORTED beyond.  half_precision != 0: cost is fp16. */
+int sdirt_disparity_regression(const void* cost /*dev*/, int32_t batch, int32_t d_in, int32_t h_in, int32_t w_in,
+                               int32_t d_out, int32_t h_out, int32_t w_out, int32_t half_precision,
+                               float* disp /*dev, out*/, void* stream);
+
+/* nn.Upsample(mode = 'trilinear', align_corners = True) of Conv2x (dfdp/dddnet/dddnet.py:585, 589) between volumes stored
+ * [B, D, H, W, C] (channels_last_3d): x [B, d_in, h_in, w_in, C] -> out [B, d_out, h_out, w_out, C], interpolated in fp32
+ * from the tensor's values in torch's term order and rounded once to its type.  16-byte accesses when `channels` is a
+ * multiple of 8 (fp16) / 4 (fp32) and both pointers are 16-byte aligned. */
+int sdirt_upsample_trilinear_ndhwc(const void* x /*dev*/, int32_t batch, int32_t channels, int32_t d_in, int32_t h_in,
+                                   int32_t w_in, int32_t d_out, int32_t h_out, int32_t w_out, int32_t half_precision,
+                                   void* out /*dev*/, void* stream);
+
 /* PSFNet tone curves (deeplens/psfnet.py:589-620), elementwise over n floats, in place allowed:
  * mode 0 = degamma(img) (code value in [0,1] -> linear luminance, psfnet.py:600-603),
  * mode 1 = clip(gamma(l), 0, 1) (psfnet.py:617-620 followed by the clip of render, :712). */

@@ -173,6 +173,278 @@ extern "C" int sdirt_dp_cost_volume_nhwc(const void* x, const void* y, int32_t b
 }
 
 // ---------------------------------------------------------------------------
+// Inference-time fusions of the depth network (eval mode; training keeps torch's differentiable ops).
+// ---------------------------------------------------------------------------
+
+// BasicConv's tail (dddnet.py:539-543): batch norm with its running statistics, then ReLU, in ONE pass over the convolution's
+// output, in place (MIOpen's inference batch norm + torch's clamp are two).  The arithmetic is torch's batch_norm transform
+// term by term -- gamma * (x - mean) * invstd + beta in fp32, rounded once to the tensor's type.
+// The tensor is [outer][C][inner] (planar: inner = the spatial size) or pixel-major (channels_last: inner = 1, C fastest).
+template <typename T>
+__device__ __forceinline__ T bn_relu_one(T x, float mean, float invstd, float gamma, float beta, int relu)
+{
+    float y = gamma * ((float)x - mean) * invstd + beta;
+    if (relu) y = y < 0.0f ? 0.0f : y;                  // (NaN passes, as clamp_min lets it)
+    return (T)y;
+}
+
+// pixel-major tensors [pixels][C]: a thread keeps ONE group of VL channels (its 4 x VL constants in registers) and walks
+// down the pixels; consecutive threads hold consecutive 16-byte groups, so loads and stores are coalesced.
+// blockDim.x = groups * (pixels per block pass), groups = C / VL.
+template <typename T, int VL>
+__global__ void __launch_bounds__(256)
+k_bn_relu_pixel_major(T* __restrict__ x, int64_t n_pixels, int C, const float* __restrict__ mean,
+                      const float* __restrict__ invstd, const float* __restrict__ gamma, const float* __restrict__ beta, int relu)
+{
+    typedef T vec __attribute__((ext_vector_type(VL)));
+    const int groups = C / VL;
+    const int g = threadIdx.x % groups, ppb = blockDim.x / groups;
+    float m[VL], is[VL], ga[VL], be[VL];
+#pragma unroll
+    for (int j = 0; j < VL; ++j) {
+        m[j] = mean[g * VL + j]; is[j] = invstd[g * VL + j]; ga[j] = gamma[g * VL + j]; be[j] = beta[g * VL + j];
+    }
+    for (int64_t p = (int64_t)blockIdx.x * ppb + threadIdx.x / groups; p < n_pixels; p += (int64_t)gridDim.x * ppb) {
+        vec* q = reinterpret_cast<vec*>(x + p * C + g * VL);
+        vec v = *q;
+#pragma unroll
+        for (int j = 0; j < VL; ++j) v[j] = bn_relu_one<T>(v[j], m[j], is[j], ga[j], be[j], relu);
+        *q = v;
+    }
+}
+
+// planar tensors [planes = B x C][inner]: a workgroup stays inside one plane (its four constants are uniform: scalar loads)
+template <typename T, int VL>
+__global__ void __launch_bounds__(256)
+k_bn_relu_planar(T* __restrict__ x, int C, int64_t inner, int chunks_per_plane, const float* __restrict__ mean,
+                 const float* __restrict__ invstd, const float* __restrict__ gamma, const float* __restrict__ beta, int relu)
+{
+    typedef T vec __attribute__((ext_vector_type(VL)));
+    const int64_t plane = blockIdx.x / chunks_per_plane;
+    const int chunk = blockIdx.x % chunks_per_plane;
+    const int c = (int)(plane % C);
+    const float m = mean[c], is = invstd[c], ga = gamma[c], be = beta[c];
+    T* base = x + plane * inner;
+    const int64_t n_vec = inner / VL;                        // (the host sends inner % VL != 0 through VL = 1)
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int64_t i = ((int64_t)chunk * 4 + it) * 256 + threadIdx.x;
+        if (i < n_vec) {
+            vec* q = reinterpret_cast<vec*>(base + i * VL);
+            vec v = *q;
+#pragma unroll
+            for (int j = 0; j < VL; ++j) v[j] = bn_relu_one<T>(v[j], m, is, ga, be, relu);
+            *q = v;
+        }
+    }
+}
+
+extern "C" int sdirt_bn_relu(void* x, int64_t outer, int32_t channels, int64_t inner, const float* mean, const float* invstd,
+                             const float* gamma, const float* beta, int32_t relu, int32_t half_precision, void* stream)
+{
+    if (!x || !mean || !invstd || !gamma || !beta || outer < 0 || channels < 1 || inner < 1)
+        return fail(SDIRT_ERR_INVALID_ARGUMENT, "bad argument");
+    if (outer * channels * inner == 0) return SDIRT_OK;
+    const int vl = half_precision ? 8 : 4;
+    const bool aligned = ((uintptr_t)x & 15) == 0;
+    hipStream_t st = as_stream(stream);
+    if (inner == 1) {
+        // pixel-major: 16-byte groups of channels when the count allows it, one channel per thread otherwise
+        const bool wide = aligned && channels % vl == 0 && channels / vl <= 256;
+        if (!wide && channels > 256) return fail(SDIRT_ERR_UNSUPPORTED, "pixel-major tensors: channels <= 256 or a multiple of %d up to %d", vl, 256 * vl);
+        const int groups = wide ? channels / vl : channels;
+        const int bdim = groups * (256 / groups), ppb = bdim / groups;
+        const int grid = (int)std::min<int64_t>((outer + ppb - 1) / ppb, 256 * 16);
+#define SDIRT_BN(T, VL) k_bn_relu_pixel_major<T, VL><<<grid, bdim, 0, st>>>(static_cast<T*>(x), outer, channels, mean, invstd, gamma, beta, relu)
+        if (half_precision) { if (wide) SDIRT_BN(_Float16, 8); else SDIRT_BN(_Float16, 1); }
+        else { if (wide) SDIRT_BN(float, 4); else SDIRT_BN(float, 1); }
+#undef SDIRT_BN
+    } else {
+        const bool wide = aligned && inner % vl == 0;
+        const int64_t n_vec = wide ? inner / vl : inner;
+        const int64_t cpp = (n_vec + 1023) / 1024, blocks = outer * channels * cpp;
+        if (cpp > (1 << 30) || blocks > (1ll << 31) - 1) return fail(SDIRT_ERR_UNSUPPORTED, "tensor too large");
+#define SDIRT_BN(T, VL) k_bn_relu_planar<T, VL><<<(unsigned)blocks, 256, 0, st>>>(static_cast<T*>(x), channels, inner, (int)cpp, mean, invstd, gamma, beta, relu)
+        if (half_precision) { if (wide) SDIRT_BN(_Float16, 8); else SDIRT_BN(_Float16, 1); }
+        else { if (wide) SDIRT_BN(float, 4); else SDIRT_BN(float, 1); }
+#undef SDIRT_BN
+    }
+    LAUNCH_CHECK();
+    return SDIRT_OK;
+}
+
+namespace {
+
+// torch's linear-interpolation source index (UpSample.cuh: area_pixel_compute_source_index): align_corners -> scale * dst
+// with scale = (in - 1) / (out - 1); else scale * (dst + 0.5) - 0.5 with scale = in / out, clamped at 0
+struct Lerp { int i0, i1; float l0, l1; };
+__device__ __forceinline__ Lerp lerp_at(int dst, int in, float scale, bool align)
+{
+    float src = align ? scale * (float)dst : scale * ((float)dst + 0.5f) - 0.5f;
+    if (!align && src < 0.0f) src = 0.0f;
+    Lerp r;
+    r.i0 = (int)src;
+    r.i1 = r.i0 + (r.i0 < in - 1 ? 1 : 0);
+    r.l1 = src - (float)r.i0;
+    r.l0 = 1.0f - r.l1;
+    return r;
+}
+inline float lerp_scale(int in, int out, bool align)
+{
+    return align ? (out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.0f) : (float)in / (float)out;
+}
+
+constexpr int kMaxDispIn = 32, kMaxDispOut = 64;
+
+// Disp + DisparityRegression (dddnet.py:543-568): trilinear interpolation of the hourglass's [B, 1, D0, H0, W0] volume to
+// [D, H, W] (align_corners = False), softmin over the D shifts, expectation over shifts -D/2 .. D/2 - 1 -- one thread per
+// output pixel, everything in fp32 (what autocast runs these ops in), ONE [B, 1, H, W] store instead of five passes over a
+// [B, D, H, W] fp32 tensor.  Term order of the interpolation as torch's kernel (UpSampleTrilinear3d.cu).
+// SD0 / SD > 0: the depth sizes as compile-time constants -- every loop unrolls, the depth weights and plane indices fold
+// into the code and `plane` / `v` live in registers (the reference's 10 -> 20); 0: any sizes up to the bounds, arrays in scratch.
+template <typename T, int SD0, int SD>
+__global__ void __launch_bounds__(256)
+k_disparity_regression(const T* __restrict__ cost, int B, int D0_, int H0, int W0, int D_, int H, int W, float sd_, float sh,
+                       float sw, float* __restrict__ disp)
+{
+    constexpr bool FIXED = SD0 > 0;
+    const int D0 = FIXED ? SD0 : D0_, D = FIXED ? SD : D_;
+    const float sd = FIXED ? (float)SD0 / (float)(SD > 0 ? SD : 1) : sd_;
+    const int64_t total = (int64_t)B * H * W;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int w = (int)(t % W);
+        const int h = (int)((t / W) % H);
+        const int b = (int)(t / ((int64_t)W * H));
+        const Lerp lh = lerp_at(h, H0, sh, false), lw = lerp_at(w, W0, sw, false);
+        const T* base = cost + (int64_t)b * D0 * H0 * W0;
+        float plane[FIXED ? SD0 : kMaxDispIn];           // the in-plane part of every input plane at (h, w)
+#pragma unroll
+        for (int k = 0; k < (FIXED ? SD0 : kMaxDispIn); ++k) {
+            if (!FIXED && k >= D0) break;
+            const T* p = base + (int64_t)k * H0 * W0;
+            const float a = (float)p[lh.i0 * W0 + lw.i0], bb = (float)p[lh.i0 * W0 + lw.i1];
+            const float c = (float)p[lh.i1 * W0 + lw.i0], d = (float)p[lh.i1 * W0 + lw.i1];
+            plane[k] = lh.l0 * (lw.l0 * a + lw.l1 * bb) + lh.l1 * (lw.l0 * c + lw.l1 * d);
+        }
+        // softmin = softmax of the negated values: maximum first, as torch's softmax kernels
+        float v[FIXED ? SD : kMaxDispOut];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < (FIXED ? SD : kMaxDispOut); ++i) {
+            if (!FIXED && i >= D) break;
+            const Lerp ld = lerp_at(i, D0, sd, false);
+            v[i] = -(ld.l0 * plane[ld.i0] + ld.l1 * plane[ld.i1]);
+            mx = fmaxf(mx, v[i]);
+        }
+        float sum = 0.0f, acc = 0.0f;
+#pragma unroll
+        for (int i = 0; i < (FIXED ? SD : kMaxDispOut); ++i) {
+            if (!FIXED && i >= D) break;
+            v[i] = expf(v[i] - mx);
+            sum += v[i];
+        }
+        // torch.arange(-maxdisp // 2, maxdisp // 2): floor division of the NEGATED count (odd maxdisp: -(D+1)/2)
+        const int first = -((D + 1) / 2);
+#pragma unroll
+        for (int i = 0; i < (FIXED ? SD : kMaxDispOut); ++i) {
+            if (!FIXED && i >= D) break;
+            acc += (v[i] / sum) * (float)(first + i);
+        }
+        disp[t] = acc;
+    }
+}
+
+// nn.Upsample(scale_factor = 2, mode = 'trilinear', align_corners = True) of Conv2x (dddnet.py:585, 589) -- any output
+// size -- on a volume stored [B, D, H, W, C] (channels_last_3d), 16 bytes of channels per thread: interpolated in fp32 from
+// the tensor's values and rounded once to its type (under autocast torch runs the op in fp32 and the next convolution
+// rounds its input to fp16: the same numbers).  torch's kernel is planar-only: in the channels_last_3d hourglass it stood
+// between two layout copies.
+template <typename T, int VL>
+__global__ void __launch_bounds__(256)
+k_upsample_trilinear_ndhwc(const T* __restrict__ x, int B, int C, int D0, int H0, int W0, int D, int H, int W, float sd, float sh,
+                           float sw, T* __restrict__ out)
+{
+    typedef T vec __attribute__((ext_vector_type(VL)));
+    const int groups = C / VL;
+    const int64_t total = (int64_t)B * D * H * W * groups;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int g = (int)(t % groups);
+        int64_t rest = t / groups;
+        const int w = (int)(rest % W); rest /= W;
+        const int h = (int)(rest % H); rest /= H;
+        const int d = (int)(rest % D);
+        const int b = (int)(rest / D);
+        const Lerp ld = lerp_at(d, D0, sd, true), lh = lerp_at(h, H0, sh, true), lw = lerp_at(w, W0, sw, true);
+        const T* base = x + (int64_t)b * D0 * H0 * W0 * C + (int64_t)g * VL;
+        auto at = [&](int dd, int hh, int ww) {
+            return *reinterpret_cast<const vec*>(base + (((int64_t)dd * H0 + hh) * W0 + ww) * C);
+        };
+        const vec v000 = at(ld.i0, lh.i0, lw.i0), v001 = at(ld.i0, lh.i0, lw.i1), v010 = at(ld.i0, lh.i1, lw.i0),
+                  v011 = at(ld.i0, lh.i1, lw.i1), v100 = at(ld.i1, lh.i0, lw.i0), v101 = at(ld.i1, lh.i0, lw.i1),
+                  v110 = at(ld.i1, lh.i1, lw.i0), v111 = at(ld.i1, lh.i1, lw.i1);
+        vec r;
+#pragma unroll
+        for (int j = 0; j < VL; ++j) {
+            const float lo = lh.l0 * (lw.l0 * (float)v000[j] + lw.l1 * (float)v001[j]) +
+                             lh.l1 * (lw.l0 * (float)v010[j] + lw.l1 * (float)v011[j]);
+            const float hi = lh.l0 * (lw.l0 * (float)v100[j] + lw.l1 * (float)v101[j]) +
+                             lh.l1 * (lw.l0 * (float)v110[j] + lw.l1 * (float)v111[j]);
+            r[j] = (T)(ld.l0 * lo + ld.l1 * hi);
+        }
+        *reinterpret_cast<vec*>(out + t * VL) = r;
+    }
+}
+
+}  // namespace
+
+extern "C" int sdirt_disparity_regression(const void* cost, int32_t batch, int32_t d_in, int32_t h_in, int32_t w_in,
+                                          int32_t d_out, int32_t h_out, int32_t w_out, int32_t half_precision, float* disp,
+                                          void* stream)
+{
+    if (!cost || !disp || batch < 0 || d_in < 1 || h_in < 1 || w_in < 1 || d_out < 1 || h_out < 1 || w_out < 1)
+        return fail(SDIRT_ERR_INVALID_ARGUMENT, "bad argument");
+    if (d_in > kMaxDispIn || d_out > kMaxDispOut)
+        return fail(SDIRT_ERR_UNSUPPORTED, "d_in <= %d and d_out <= %d (got %d, %d)", kMaxDispIn, kMaxDispOut, d_in, d_out);
+    const int64_t total = (int64_t)batch * h_out * w_out;
+    if (total == 0) return SDIRT_OK;
+    const int grid = (int)std::min<int64_t>((total + 255) / 256, 256 * 64);
+    const float sd = lerp_scale(d_in, d_out, false), sh = lerp_scale(h_in, h_out, false), sw = lerp_scale(w_in, w_out, false);
+    hipStream_t st = as_stream(stream);
+#define SDIRT_DR(T, A, B_) k_disparity_regression<T, A, B_><<<grid, 256, 0, st>>>(static_cast<const T*>(cost), batch, d_in, h_in, w_in, \
+                               d_out, h_out, w_out, sd, sh, sw, disp)
+    // dddnet.py:112, 409-446: maxdisp 20, and the hourglass ends at the cost volume's own 20 planes (20 -> 20: the depth
+    // weights fold to the identity, the interpolation is the in-plane x 4); 10 -> 20: the same network on a half-depth volume
+    const int shape = d_out == 20 ? (d_in == 20 ? 2 : d_in == 10 ? 1 : 0) : 0;
+    if (half_precision) { if (shape == 2) SDIRT_DR(_Float16, 20, 20); else if (shape == 1) SDIRT_DR(_Float16, 10, 20); else SDIRT_DR(_Float16, 0, 0); }
+    else { if (shape == 2) SDIRT_DR(float, 20, 20); else if (shape == 1) SDIRT_DR(float, 10, 20); else SDIRT_DR(float, 0, 0); }
+#undef SDIRT_DR
+    LAUNCH_CHECK();
+    return SDIRT_OK;
+}
+
+extern "C" int sdirt_upsample_trilinear_ndhwc(const void* x, int32_t batch, int32_t channels, int32_t d_in, int32_t h_in,
+                                              int32_t w_in, int32_t d_out, int32_t h_out, int32_t w_out,
+                                              int32_t half_precision, void* out, void* stream)
+{
+    if (!x || !out || batch < 0 || channels < 1 || d_in < 1 || h_in < 1 || w_in < 1 || d_out < 1 || h_out < 1 || w_out < 1)
+        return fail(SDIRT_ERR_INVALID_ARGUMENT, "bad argument");
+    if (batch == 0) return SDIRT_OK;
+    const int vl = half_precision ? 8 : 4;
+    const bool wide = channels % vl == 0 && (((uintptr_t)x | (uintptr_t)out) & 15) == 0;
+    const int64_t total = (int64_t)batch * d_out * h_out * w_out * (channels / (wide ? vl : 1));
+    const int grid = (int)std::min<int64_t>((total + 255) / 256, 256 * 64);
+    const float sd = lerp_scale(d_in, d_out, true), sh = lerp_scale(h_in, h_out, true), sw = lerp_scale(w_in, w_out, true);
+    hipStream_t st = as_stream(stream);
+#define SDIRT_UP(T, VL) k_upsample_trilinear_ndhwc<T, VL><<<grid, 256, 0, st>>>(static_cast<const T*>(x), batch, channels, d_in, \
+                            h_in, w_in, d_out, h_out, w_out, sd, sh, sw, static_cast<T*>(out))
+    if (half_precision) { if (wide) SDIRT_UP(_Float16, 8); else SDIRT_UP(_Float16, 1); }
+    else { if (wide) SDIRT_UP(float, 4); else SDIRT_UP(float, 1); }
+#undef SDIRT_UP
+    LAUNCH_CHECK();
+    return SDIRT_OK;
+}
+
+// ---------------------------------------------------------------------------
 // The context branches of the depth network's feature extractor (dfdp/dddnet/dddnet.py:376-385): nn.AvgPool2d with a
 // window of 32 x 32 / 8 x 8 and the same stride on [B, 128, H/4, W/4] maps.  torch's kernel gives one THREAD the
 // whole window (1024 strided reads): 240 us per call at 512 x 768, four calls per frame = 13 % of config 5's frame

@@ -7,7 +7,7 @@ same parameter names, so its checkpoints load unchanged:
             average-pool context branches, fusion)                        dddnet.py:358-407
   cost      signed-shift DP cost volume [B, 64, 20, H/4, W/4]              dddnet.py:136-148
             -> ONE HIP kernel (sdirt_dp_cost_volume) instead of zero-fill + 40 sliced copies
-  matching  3-D conv hourglass -> [B, 1, 10, H/4, W/4]                     dddnet.py:409-446
+  matching  3-D conv hourglass -> [B, 1, 20, H/4, W/4]                     dddnet.py:409-446
   disp      trilinear x(2, 4, 4) upsample, softmin over the 20 shifts, expectation over
             shifts -10..9                                                  dddnet.py:543-568
 
@@ -118,6 +118,81 @@ class WindowAverage(nn.AvgPool2d):
         return super().forward(x)
 
 
+#: eval mode, CUDA tensors, no autograd (torch.no_grad()): BasicConv's batch norm + ReLU as ONE in-place pass
+#: (sdirt_bn_relu), its convolution with a cached fp16 copy of the weights under fp16 autocast (autocast re-casts every
+#: weight on every entry of an autocast region: 22 casts per frame), Conv2x's upsampling between channels_last_3d volumes
+#: (sdirt_upsample_trilinear_ndhwc) and Disp as one kernel (sdirt_disparity_regression).  Same arithmetic in the same
+#: precision as the torch ops they stand for; False: the torch ops.
+inference_fusions = True
+
+
+def _layout(x):
+    """(outer, inner) of a [B, C, *spatial] tensor as sdirt_bn_relu counts them, or None for strides it does not take."""
+    spatial = 1
+    for n in x.shape[2:]:
+        spatial *= n
+    if x.is_contiguous():
+        return x.shape[0], spatial
+    fmt = {4: torch.channels_last, 5: torch.channels_last_3d}.get(x.dim())
+    vl = 8 if x.dtype == torch.float16 else 4
+    if fmt is not None and x.is_contiguous(memory_format=fmt) and (x.shape[1] <= 256 or (x.shape[1] % vl == 0 and x.shape[1] <= 256 * vl)):
+        return x.shape[0] * spatial, 1
+    return None
+
+
+def _bn_tables(bn, device):
+    """(mean, invstd, gamma, beta) fp32 on `device`, cached on the module until one of its tensors is written."""
+    src = (bn.running_mean, bn.running_var, bn.weight, bn.bias)
+    key = (str(device), float(bn.eps)) + tuple((t._version, t.data_ptr()) if t is not None else None for t in src)
+    hit = bn.__dict__.get("_sdirt_tables")
+    if hit is None or hit[0] != key:
+        with torch.no_grad():
+            mean = bn.running_mean.detach().to(device, torch.float32).contiguous()
+            invstd = torch.rsqrt(bn.running_var.detach().to(device, torch.float32) + bn.eps).contiguous()
+            gamma = bn.weight.detach().to(device, torch.float32).contiguous() if bn.weight is not None else torch.ones_like(mean)
+            beta = bn.bias.detach().to(device, torch.float32).contiguous() if bn.bias is not None else torch.zeros_like(mean)
+        hit = bn.__dict__["_sdirt_tables"] = (key, (mean, invstd, gamma, beta))
+    return hit[1]
+
+
+def _bn_relu_(x, bn, relu):
+    """dddnet.py:539-543 on a convolution's output, eval mode: one in-place pass; shapes / dtypes / strides the kernel does
+    not take go through the torch ops (chosen here, before anything is launched)."""
+    if bn is None:
+        return F.relu(x, inplace=True) if relu else x
+    lay = _layout(x) if x.dtype in (torch.float16, torch.float32) and bn.track_running_stats and bn.running_mean is not None else None
+    if lay is None:
+        x = bn(x)
+        return F.relu(x, inplace=True) if relu else x
+    mean, invstd, gamma, beta = _bn_tables(bn, x.device)
+    _lib.check(_lib.lib().sdirt_bn_relu(dptr(x), lay[0], x.shape[1], lay[1], dptr(mean), dptr(invstd), dptr(gamma), dptr(beta),
+                                        1 if relu else 0, 1 if x.dtype == torch.float16 else 0, stream_ptr(x.device)))
+    return x
+
+
+def _conv_cached(conv, x):
+    """conv(x); under fp16 autocast with a cached fp16 copy of the (fp32) weight -- the cast autocast would make, made once
+    per weight update instead of once per autocast region."""
+    w = conv.weight
+    if not (torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.float16 and w.dtype == torch.float32
+            and conv.bias is None and getattr(conv, "padding_mode", "zeros") == "zeros"):
+        return conv(x)
+    key = (w._version, w.data_ptr(), w.stride())
+    hit = conv.__dict__.get("_sdirt_w16")
+    if hit is None or hit[0] != key:
+        hit = conv.__dict__["_sdirt_w16"] = (key, w.detach().to(torch.float16))           # (keeps the memory format)
+    w16 = hit[1]
+    if isinstance(conv, nn.ConvTranspose3d):
+        return F.conv_transpose3d(x, w16, None, conv.stride, conv.padding, conv.output_padding, conv.groups, conv.dilation)
+    if isinstance(conv, nn.ConvTranspose2d):
+        return F.conv_transpose2d(x, w16, None, conv.stride, conv.padding, conv.output_padding, conv.groups, conv.dilation)
+    if isinstance(conv, nn.Conv3d):
+        return F.conv3d(x, w16, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+    if isinstance(conv, nn.Conv2d):
+        return F.conv2d(x, w16, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+    return conv(x)
+
+
 class BasicConv(nn.Module):
     """conv (2-D / 3-D, optionally transposed, no bias) [+ batch norm] [+ ReLU]; dddnet.py:513-541."""
 
@@ -130,6 +205,8 @@ class BasicConv(nn.Module):
         self.use_bn, self.relu = bn, relu
 
     def forward(self, x):
+        if inference_fusions and x.is_cuda and not self.training and not torch.is_grad_enabled():
+            return _bn_relu_(_conv_cached(self.conv, x), self.bn if self.use_bn else None, self.relu)
         x = self.conv(x)
         if self.use_bn:
             x = self.bn(x)
@@ -174,8 +251,18 @@ class Conv2x(nn.Module):
         self.conv2 = BasicConv(cout * 2, cout, False, is_3d, kernel_size=3, stride=1, padding=1)
         self.up2 = nn.Upsample(scale_factor=2, mode="trilinear", align_corners=True)
 
+    def _up2(self, x):
+        if (inference_fusions and x.is_cuda and x.dim() == 5 and not torch.is_grad_enabled() and not x.is_contiguous()
+                and x.is_contiguous(memory_format=torch.channels_last_3d) and x.dtype in (torch.float16, torch.float32)):
+            B, C, D, H, W = x.shape
+            out = torch.empty((B, C, 2 * D, 2 * H, 2 * W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last_3d)
+            _lib.check(_lib.lib().sdirt_upsample_trilinear_ndhwc(dptr(x), B, C, D, H, W, 2 * D, 2 * H, 2 * W,
+                                                                 1 if x.dtype == torch.float16 else 0, dptr(out), stream_ptr(x.device)))
+            return out
+        return self.up2(x)
+
     def forward(self, x, rem):
-        x = self.conv1(self.up2(x))
+        x = self.conv1(self._up2(x))
         assert x.size() == rem.size()
         return self.conv2(torch.cat((x, rem), 1))
 
@@ -203,6 +290,14 @@ class Disp(nn.Module):
         self.maxdisp = maxdisp
 
     def forward(self, x):
+        if (inference_fusions and x.is_cuda and not torch.is_grad_enabled() and x.shape[1] == 1 and x.shape[2] <= 32
+                and self.maxdisp <= 64 and x.dtype in (torch.float16, torch.float32)):
+            x = x.contiguous()
+            B, _, D0, H0, W0 = x.shape
+            out = torch.empty((B, 1, 4 * H0, 4 * W0), dtype=torch.float32, device=x.device)
+            _lib.check(_lib.lib().sdirt_disparity_regression(dptr(x), B, D0, H0, W0, self.maxdisp, 4 * H0, 4 * W0,
+                                                             1 if x.dtype == torch.float16 else 0, dptr(out), stream_ptr(x.device)))
+            return out
         x = F.interpolate(x, [self.maxdisp, x.shape[3] * 4, x.shape[4] * 4], mode="trilinear",
                           align_corners=False)
         p = F.softmin(torch.squeeze(x, 1), dim=1)

@@ -178,8 +178,101 @@ def test_inference_layout_one_feature_pass_pixel_major_tensors():
     after = net.state_dict()
     assert list(after) == list(before) and all(torch.equal(after[k], before[k]) for k in before)
     net.train()                                                  # training: the reference's two calls (batch statistics per view)
-    out = net(xl, xr)
+    out = net(torch.cat((xl, xl.flip(-1))), torch.cat((xr, xr.flip(-1))))     # (two samples: a 1 x 1 context map needs them)
     assert out.requires_grad and torch.isfinite(out).all()
+
+
+@pytest.mark.gpu
+def test_inference_fusions_equal_the_torch_ops_they_stand_for():
+    """Eval mode under torch.no_grad() on the GPU: batch norm + ReLU in one in-place pass (sdirt_bn_relu), Conv2x's
+    upsampling between channels_last_3d volumes (sdirt_upsample_trilinear_ndhwc), Disp as one kernel
+    (sdirt_disparity_regression), cached fp16 weights under autocast -- each against the torch ops of dddnet.py:539-568,
+    585-589 on the same tensors, then the whole network with the switch on and off."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    import sdirt_amd.dfdp as D
+    dev = "cuda:0"
+    g = torch.Generator(device=dev).manual_seed(3)
+    rnd = lambda *s: torch.randn(*s, device=dev, generator=g)  # noqa: E731
+    # --- batch norm + ReLU: planar and pixel-major, 16-byte and element-wise forms, with and without ReLU
+    for shape in ((2, 32, 6, 16, 24), (1, 64, 10, 32, 48), (2, 32, 17, 24), (1, 5, 7, 9), (2, 3, 3, 5, 7)):
+        C = shape[1]
+        bn = (nn.BatchNorm3d if len(shape) == 5 else nn.BatchNorm2d)(C).to(dev).eval()
+        with torch.no_grad():
+            bn.running_mean.copy_(rnd(C)); bn.running_var.copy_(rnd(C).abs() + 0.3)
+            bn.weight.copy_(rnd(C)); bn.bias.copy_(rnd(C))
+        for dt, tol in ((torch.float32, 2e-6), (torch.float16, 1e-3)):
+            for fmt in (torch.contiguous_format, torch.channels_last_3d if len(shape) == 5 else torch.channels_last):
+                for relu in (True, False):
+                    x = (3 * rnd(*shape)).to(dt).contiguous(memory_format=fmt)
+                    with torch.no_grad():
+                        want = bn(x.float())
+                        want = F.relu(want) if relu else want
+                        got = D._bn_relu_(x.clone(memory_format=torch.preserve_format), bn, relu)
+                    assert got.dtype == dt and got.stride() == x.stride()
+                    err = (got.float() - want).abs().max().item()
+                    assert err <= tol * max(1.0, want.abs().max().item()), (shape, dt, fmt, relu, err)
+    # a statistics update is seen (the tables are cached per module)
+    with torch.no_grad():
+        x = rnd(2, 32, 17, 24)
+        a = D._bn_relu_(x.clone(), bn2 := nn.BatchNorm2d(32).to(dev).eval(), True)
+        bn2.running_mean.add_(1.0)
+        b = D._bn_relu_(x.clone(), bn2, True)
+        assert not torch.equal(a, b) and torch.allclose(b, F.relu(bn2(x)), atol=1e-6)
+    # --- Conv2x's upsampling on channels_last_3d volumes
+    up = nn.Upsample(scale_factor=2, mode="trilinear", align_corners=True)
+    conv2x = D.Conv2x(64, 64).to(dev).eval()
+    for shape in ((1, 64, 5, 32, 48), (2, 8, 3, 5, 7), (1, 5, 2, 3, 4), (1, 4, 1, 6, 5)):
+        for dt, tol in ((torch.float32, 2e-6), (torch.float16, 1e-3)):
+            x = rnd(*shape).to(dt).contiguous(memory_format=torch.channels_last_3d)
+            with torch.no_grad():
+                got = conv2x._up2(x)
+                want = up(x.float())
+            assert got.shape == want.shape and got.dtype == dt and got.is_contiguous(memory_format=torch.channels_last_3d)
+            assert (got.float() - want).abs().max().item() <= tol * max(1.0, want.abs().max().item()), (shape, dt)
+    # --- Disp: trilinear x (2, 4, 4) + softmin + expectation over the shifts
+    def disp_ref(x, maxdisp):
+        x = F.interpolate(x.float(), [maxdisp, x.shape[3] * 4, x.shape[4] * 4], mode="trilinear", align_corners=False)
+        p = F.softmin(torch.squeeze(x, 1), dim=1)
+        shifts = torch.arange(-maxdisp // 2, maxdisp // 2, device=x.device).view(1, -1, 1, 1)
+        return torch.sum(p * shifts, 1, keepdim=True)
+    for shape, md in (((1, 1, 20, 32, 48), 20), ((1, 1, 10, 32, 48), 20), ((2, 1, 10, 8, 12), 20), ((1, 1, 3, 5, 7), 5), ((1, 1, 1, 2, 3), 4), ((1, 1, 32, 4, 4), 64)):
+        for dt in (torch.float32, torch.float16):
+            x = (4 * rnd(*shape)).to(dt)
+            with torch.no_grad():
+                got = D.Disp(md).to(dev)(x)
+                want = disp_ref(x, md)
+            assert got.shape == want.shape and got.dtype == torch.float32
+            assert (got - want).abs().max().item() <= 2e-5 * md, (shape, md, dt, (got - want).abs().max().item())
+    # --- the whole network, switch on / off (fp32, then as Basenet.forward runs it: fp16 autocast)
+    fx = load_golden("f10_dfdp_net")
+    net = build(fx).to(dev)
+    xl, xr, _, _ = inputs(fx)
+    xl, xr = xl.to(dev), xr.to(dev)
+    try:
+        with torch.no_grad():
+            D.inference_fusions = False
+            off = net(xl, xr)
+            with torch.autocast("cuda", dtype=torch.float16):
+                off16 = net(xl, xr)
+            D.inference_fusions = True
+            on = net(xl, xr)
+            with torch.autocast("cuda", dtype=torch.float16):
+                on16 = net(xl, xr)
+                assert "_sdirt_w16" in net.matching.start[0].conv.__dict__               # cached fp16 weights in use
+                on16b = net(xl, xr)
+    finally:
+        D.inference_fusions = True
+    assert (on - off).abs().max().item() < 2e-4 and np.abs(on.cpu().numpy() - fx["disp"]).max() < 2e-3
+    assert (on16 - on16b).abs().max().item() < 2e-3          # (MIOpen's picks need not repeat bit for bit)
+    assert (on16 - off16).abs().max().item() < 2e-2 and np.abs(on16.float().cpu().numpy() - fx["disp"]).max() < 5e-2
+    # a weight update invalidates the cached copy
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        net.matching.start[0].conv.weight.mul_(1.5)
+        assert not torch.equal(net(xl, xr), on16)
+    # with autograd on (fine-tuning with frozen statistics) the differentiable torch ops run
+    out = net(xl, xr)
+    assert out.requires_grad
 
 
 @pytest.mark.gpu
