@@ -544,6 +544,12 @@ int sdirt_dp_cost_volume_backward(const void* grad_cost /*dev*/, int32_t batch, 
 int sdirt_avg_pool_windows(const void* x /*dev*/, int64_t planes, int32_t height, int32_t width, int32_t k,
                            int32_t half_precision, void* out /*dev*/, void* stream);
 
+/* The same window average READING a pixel-major map (what a channels_last tensor is in memory): x [batch, height, width,
+ * channels] -> out [batch, channels, height / k, width / k] (planar, like sdirt_avg_pool_windows).  channels: a multiple of 8 (fp16) / 4 (fp32), at most 2048 / 1024;
+ * x 16-byte aligned; SDIRT_ERR_UNSUPPORTED otherwise. */
+int sdirt_avg_pool_windows_nhwc(const void* x /*dev*/, int32_t batch, int32_t height, int32_t width, int32_t channels,
+                                int32_t k, int32_t half_precision, void* out /*dev*/, void* stream);
+
 /* ---- depth network, inference-time fusions (eval mode; training keeps torch's differentiable ops) ---- */
 
 /* The tail of BasicConv.forward (dfdp/dddnet/dddnet.py:539-543) in eval mode: batch norm with its running statistics

@@ -111,6 +111,7 @@ SIGNATURES = {
     "sdirt_dp_cost_volume_nhwc": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P]),
     "sdirt_tone_curve": (C.c_int, [_P, _I64, _I32, _P, _P]),
     "sdirt_avg_pool_windows": (C.c_int, [_P, _I64, _I32, _I32, _I32, _I32, _P, _P]),
+    "sdirt_avg_pool_windows_nhwc": (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P]),
     "sdirt_bn_relu": (C.c_int, [_P, _I64, _I32, _I64, _P, _P, _P, _P, _I32, _I32, _P]),
     "sdirt_disparity_regression": (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P]),
     "sdirt_upsample_trilinear_ndhwc": (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P]),

@@ -480,6 +480,63 @@ __global__ void __launch_bounds__(256) k_avg_pool_windows(const T* __restrict__ 
     }
 }
 
+// The same window average reading a pixel-major map [B, H, W, C] (channels_last) as it lies -> the planar [B, C, H/k, W/k] the
+// other kernel writes (a few hundred values per plane: the 1 x 1 convolution behind it gets what it got before): one workgroup
+// per output pixel, a thread owns a 16-byte group of channels and every (256 / groups)-th pixel of the window; the partial
+// sums meet in LDS.  fp32 accumulation, one multiplication by 1 / k^2, like the planar kernel.
+template <class T, int VL>
+__global__ void __launch_bounds__(256) k_avg_pool_windows_nhwc(const T* __restrict__ x, int H, int W, int C, int k, T* __restrict__ out)
+{
+    typedef T vec __attribute__((ext_vector_type(VL)));
+    extern __shared__ float part[];                             // [lanes][C]
+    const int groups = C / VL, lanes = blockDim.x / groups;
+    const int g = threadIdx.x % groups, lane = threadIdx.x / groups;
+    const int OH = H / k, OW = W / k;
+    const int ox = blockIdx.x % OW, oy = (blockIdx.x / OW) % OH, b = blockIdx.x / (OW * OH);
+    const T* __restrict__ src = x + (((int64_t)b * H + (int64_t)oy * k) * W + (int64_t)ox * k) * C + g * VL;
+    float acc[VL];
+#pragma unroll
+    for (int j = 0; j < VL; ++j) acc[j] = 0.0f;
+#pragma unroll 4
+    for (int p = lane; p < k * k; p += lanes) {
+        const vec v = *reinterpret_cast<const vec*>(src + ((int64_t)(p / k) * W + p % k) * C);
+#pragma unroll
+        for (int j = 0; j < VL; ++j) acc[j] += (float)v[j];
+    }
+#pragma unroll
+    for (int j = 0; j < VL; ++j) part[lane * C + g * VL + j] = acc[j];
+    __syncthreads();
+    const float inv = 1.0f / (float)(k * k);
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float s_ = 0.0f;
+        for (int l = 0; l < lanes; ++l) s_ += part[l * C + c];
+        out[(((int64_t)b * C + c) * OH + oy) * OW + ox] = (T)(s_ * inv);
+    }
+}
+
+extern "C" int sdirt_avg_pool_windows_nhwc(const void* x, int32_t batch, int32_t height, int32_t width, int32_t channels, int32_t k,
+                                           int32_t half_precision, void* out, void* stream)
+{
+    if (!x || !out || batch < 0 || height < 1 || width < 1 || channels < 1 || k < 1 || height % k || width % k)
+        return fail(SDIRT_ERR_INVALID_ARGUMENT, "bad argument (the window must divide height and width)");
+    const int vl = half_precision ? 8 : 4;
+    if (channels % vl != 0 || channels / vl > 256 || ((uintptr_t)x & 15))
+        return fail(SDIRT_ERR_UNSUPPORTED, "channels must be a multiple of %d (at most %d) and x 16-byte aligned", vl, 256 * vl);
+    const int64_t blocks = (int64_t)batch * (height / k) * (width / k);
+    if (blocks == 0) return SDIRT_OK;
+    if (blocks > (1ll << 31) - 1) return fail(SDIRT_ERR_INVALID_ARGUMENT, "too many windows");
+    const int groups = channels / vl, lanes = std::max(1, std::min(256 / groups, k * k));
+    const size_t lds = sizeof(float) * (size_t)lanes * channels;
+    if (half_precision)
+        k_avg_pool_windows_nhwc<_Float16, 8><<<(unsigned)blocks, groups * lanes, lds, as_stream(stream)>>>(
+            static_cast<const _Float16*>(x), height, width, channels, k, static_cast<_Float16*>(out));
+    else
+        k_avg_pool_windows_nhwc<float, 4><<<(unsigned)blocks, groups * lanes, lds, as_stream(stream)>>>(
+            static_cast<const float*>(x), height, width, channels, k, static_cast<float*>(out));
+    LAUNCH_CHECK();
+    return SDIRT_OK;
+}
+
 extern "C" int sdirt_avg_pool_windows(const void* x, int64_t planes, int32_t height, int32_t width, int32_t k,
                                       int32_t half_precision, void* out, void* stream)
 {

@@ -90,11 +90,19 @@ class _WindowAverage(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, k):
         B, C, H, W = x.shape
+        ctx.k = k
+        vl = 8 if x.dtype == torch.float16 else 4
+        if (not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last) and C % vl == 0 and C // vl <= 256
+                and x.data_ptr() % 16 == 0):
+            # a pixel-major map (the inference layout of DfDPNet): averaged as it lies (no re-laying copy of the map in front)
+            out = torch.empty((B, C, H // k, W // k), dtype=x.dtype, device=x.device)
+            _lib.check(_lib.lib().sdirt_avg_pool_windows_nhwc(dptr(x), B, H, W, C, k, 1 if x.dtype == torch.float16 else 0,
+                                                              dptr(out), stream_ptr(x.device)))
+            return out
         x = x.contiguous()
         out = torch.empty((B, C, H // k, W // k), dtype=x.dtype, device=x.device)
         _lib.check(_lib.lib().sdirt_avg_pool_windows(dptr(x), B * C, H, W, k, 1 if x.dtype == torch.float16 else 0,
                                                      dptr(out), stream_ptr(x.device)))
-        ctx.k = k
         return out
 
     @staticmethod

@@ -313,5 +313,9 @@ def test_window_average_equals_avg_pool2d(dtype, k, shape):
     (ours(x1) * w).sum().backward()
     (ref(x2) * w).sum().backward()
     assert torch.allclose(x1.grad, x2.grad, rtol=0, atol=1e-7)
+    if shape[1] % 8 == 0:                                    # the same map pixel-major (DfDPNet's inference layout)
+        c = ours(x.contiguous(memory_format=torch.channels_last))
+        assert c.shape == b.shape and c.is_contiguous()
+        assert (c.float() - b.float()).abs().max().item() <= tol * max(1.0, b.float().abs().max().item())
     odd = torch.randn(1, 2, 10, 13, device="cuda").to(dtype)
     assert torch.equal(WindowAverage((4, 4), stride=(4, 4))(odd), torch.nn.AvgPool2d((4, 4), stride=(4, 4))(odd))
