@@ -188,11 +188,19 @@ def compact(res):
 
 
 DETAIL_PATH = None     # --detail-file: where the full record of the run goes (default bench_detail.json beside bench.py)
+_EMIT = {"lock": None, "done": False}      # ONE line, whoever prints it (the main thread, or the gather trial's deadline thread)
 
 
 def emit_line(res):
     """Rank 0's result: the FULL record into the detail file (and onto stderr under --verbose), its compact() form as the
     ONE JSON line on stdout."""
+    import threading
+    if _EMIT["lock"] is None:
+        _EMIT["lock"] = threading.Lock()
+    with _EMIT["lock"]:
+        if _EMIT["done"]:
+            return
+        _EMIT["done"] = True
     path = DETAIL_PATH or os.path.join(ROOT, "bench_detail.json")
     try:
         with open(path, "w") as f:

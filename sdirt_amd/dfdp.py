@@ -134,6 +134,11 @@ class WindowAverage(nn.AvgPool2d):
 inference_fusions = True
 
 
+def _hooked(m):
+    """Forward hooks on a submodule (feature taps, quantisation observers ...) see the module called: no fusion past them."""
+    return bool(m._forward_hooks or m._forward_pre_hooks)
+
+
 def _layout(x):
     """(outer, inner) of a [B, C, *spatial] tensor as sdirt_bn_relu counts them, or None for strides it does not take."""
     spatial = 1
@@ -213,7 +218,8 @@ class BasicConv(nn.Module):
         self.use_bn, self.relu = bn, relu
 
     def forward(self, x):
-        if inference_fusions and x.is_cuda and not self.training and not torch.is_grad_enabled():
+        if (inference_fusions and x.is_cuda and not self.training and not torch.is_grad_enabled()
+                and not _hooked(self.conv) and not _hooked(self.bn)):
             return _bn_relu_(_conv_cached(self.conv, x), self.bn if self.use_bn else None, self.relu)
         x = self.conv(x)
         if self.use_bn:

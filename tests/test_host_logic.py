@@ -575,6 +575,34 @@ def test_the_one_json_line_stays_under_4_kb_and_keeps_the_evidence():
     assert all(0.0 < row[eff] <= 1.03 for row in line["sweep_summary"].values())      # physical figures only
 
 
+def test_the_multi_gpu_line_keeps_the_gather_evidence():
+    """The N > 1 line: `gather` with the checksum flag and the algorithm trial (both figures, which one `value` is),
+    `value_allgather` / `value_direct` / `value_no_gather` as top-level scalars -- under 4000 bytes with everything on."""
+    import json
+    import bench
+    full = {"metric": "rays/sec rf50mm 65x65 DP-PSF @4096spp", "value": 5.1e10, "unit": "rays/s", "n_gpus": 8, "steps": 20, "warmup": 5,
+            "ms_per_step": 1.31, "higher_is_better": True, "scaling": "strong", "world_size": 8, "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic", "backend": "nccl", "value_no_gather": 5.6e10, "ms_per_step_no_gather": 1.19,
+            "value_allgather": 4.2e10, "value_direct": 5.1e10, "render_streams": 2, "kernel_ms": 1.15,
+            "config": {"workload": "BASELINE config 2: " + "x" * 300, "name": "c2", "points_per_gpu": 2048, "spp": 4096, "ks": 65,
+                       "parallelism": "p" * 200, "gather": True, "newton_trip_policy": "reference", "relaunches_in_timed_region": 0},
+            "roofline": {"bound": "valu", "achieved": 60.0, "peak": 8000.0, "unit": "GB/s", "frac": 0.0075, "traffic": 5.6e8,
+                         "valu_flops": {"frac": 0.24, "achieved": 37.9}, "valu_issue": {"frac": 0.71, "issue_bound": {"frac": 0.93}, "stale": False},
+                         "kernel": "k" * 100, "note": "n" * 500},
+            "gather": {"algo": "direct", "backend": "nccl", "world_size": 8, "gb_received_per_rank_per_step": 0.484557,
+                       "collectives_per_step": 1, "ms": 1.28, "GBps_received_per_rank": 378.0, "compute_ms": 1.15, "gather_bound": True,
+                       "volume_checksums_equal": True, "block": "b" * 80, "what": "w" * 300,
+                       "trial": {"allgather_ms_per_step": 1.6, "direct_ms_per_step": 1.31, "direct_volume_checksums_equal": True,
+                                 "adopted": "direct", "what": "w" * 300}}}
+    line = bench.compact(full)
+    assert len(json.dumps(line)) < bench.LINE_LIMIT
+    g = line["gather"]
+    assert g["volume_checksums_equal"] is True and g["algo"] == "direct" and g["gather_bound"] is True
+    assert g["trial"] == {"allgather_ms_per_step": 1.6, "direct_ms_per_step": 1.31, "direct_volume_checksums_equal": True, "adopted": "direct"}
+    assert line["value_allgather"] == 4.2e10 and line["value_direct"] == 5.1e10 and line["value_no_gather"] == 5.6e10
+    assert line["scaling"] == "strong" and line["n_gpus"] == 8 and line["config"]["points_per_gpu"] == 2048
+
+
 def test_spp_slices_is_host_arithmetic_with_an_explicit_cu_count():
     """sdirt_psf_spp_slices(n_points, spp, n_cus) with n_cus > 0 touches no device (this suite runs without one): one
     workgroup per point once the points alone give four workgroups per CU, the spp axis cut otherwise -- and the cut
