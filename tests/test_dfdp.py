@@ -276,6 +276,50 @@ def test_inference_fusions_equal_the_torch_ops_they_stand_for():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("size", [(128, 128), (256, 384)])
+def test_inference_path_reproduces_the_hourglass_output_not_only_the_disparity(size):
+    """With seeded weights the softmin is nearly uniform (the fixture's disparities are -0.5 +- 3e-4), so a disparity map
+    says little about the tensors behind it.  This compares what Disp RECEIVES -- the hourglass's [B, 1, 20, H/4, W/4] volume --
+    between the reference's op sequence on the CPU (the path the F10 fixture pins) and the GPU inference path (one feature
+    pass, pixel-major tensors, fused batch norm / upsampling, cached fp16 weights), relative to the volume's own scale."""
+    import sdirt_amd.dfdp as D
+    fx = load_golden("f10_dfdp_net")
+    net = build(fx)
+    g = torch.Generator().manual_seed(7)
+    xl = torch.rand(1, 3, *size, generator=g)
+    xr = torch.roll(xl, 2, dims=-1) * 0.9 + 0.05 * torch.rand(1, 3, *size, generator=g)
+    seen = {}
+    hook = net.disp.register_forward_pre_hook(lambda m, args: seen.__setitem__("x", args[0].detach().float().cpu().contiguous()))
+    try:
+        with torch.no_grad():
+            net(xl, xr)
+            want = seen.pop("x")
+            net = net.to("cuda:0")
+            net(xl.cuda(), xr.cuda())
+            got32 = seen.pop("x")
+            with torch.autocast("cuda", dtype=torch.float16):
+                net(xl.cuda(), xr.cuda())
+            got16 = seen.pop("x")
+            D.inference_fusions = False
+            net.inference_layout = False
+            with torch.autocast("cuda", dtype=torch.float16):
+                net(xl.cuda(), xr.cuda())
+            ref16 = seen.pop("x")
+    finally:
+        hook.remove()
+        D.inference_fusions = True
+    scale = want.abs().max().item()
+    assert want.shape == (1, 1, 20, size[0] // 4, size[1] // 4) and want.std().item() > 0.02 * scale      # a tensor with structure
+    e32 = (got32 - want).abs().max().item() / scale
+    e16 = (got16 - want).abs().max().item() / scale
+    r16 = (ref16 - want).abs().max().item() / scale
+    print(f"hourglass output {tuple(want.shape)}: scale {scale:.3e}; GPU inference path vs CPU reference ops: fp32 {e32:.2e}, "
+          f"fp16 autocast {e16:.2e} (the reference's op sequence under the same autocast: {r16:.2e}) of the scale")
+    assert e32 < 2e-3
+    assert e16 < max(3e-2, 2.0 * r16)
+
+
+@pytest.mark.gpu
 def test_cost_volume_other_cuda_dtypes_take_the_reference_formulation():
     """bf16 autocast and float64 gradcheck of the depth network on the GPU: dtypes the
     kernel is not built for go through the reference's own slice-assignment formulation."""
