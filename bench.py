@@ -175,6 +175,9 @@ def compact(res):
     for k in ("kernels_ms",):
         if k in res and len(json.dumps(res[k])) < 200:
             out[k] = res[k]
+    hg = res.get("hip_graph") or ((also or {}).get("c5") or {}).get("hip_graph")
+    if hg:
+        out["c5_ms_per_step_hip_graph" if also else "ms_per_step_hip_graph"] = hg.get("ms_per_step") or str(hg.get("error"))[:60]
     if res.get("detail"):
         out["detail"] = res["detail"]
     out = _r(out)
@@ -821,6 +824,23 @@ def bench_c5(args, emit=True):
     find = os.environ.get("SDIRT_C5_FIND", "1") == "1"
     torch.backends.cudnn.benchmark = find
     wall, ms, first_s, steps, disp = measure(max(args.warmup, 3))
+    # the same frame captured once in a hipGraph and replayed (sdirt_amd.graphs.GraphedCall): same kernels, same arguments,
+    # no hand-over gaps between the ~85 dependent launches.  A side figure: a capture that fails costs only itself.
+    graph_ms = graph_err = None
+    try:
+        from sdirt_amd.graphs import GraphedCall
+        frame = GraphedCall(chain, warmup=2, device=dev)
+        for _ in range(3):
+            frame()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            g_disp = frame()
+        torch.cuda.synchronize(dev)
+        graph_ms = (time.perf_counter() - t0) / steps * 1e3
+        graph_diff = float((g_disp.float() - disp.float()).abs().max())
+    except Exception as e:                  # noqa: BLE001
+        graph_err = f"{type(e).__name__}: {str(e)[:200]}"
     torch.backends.cudnn.benchmark = was
     # the PSF network alone (both passes of PSFNet.pred): 786432 rows x 4.78 MFLOP, the largest kernel of this package
     # in the frame
@@ -840,6 +860,9 @@ def bench_c5(args, emit=True):
                                   "full-size PSF network (seeded weights) -> DfDPNet forward (fp16 autocast), rf50mm", "name": "c5",
                       "miopen_find_mode": bool(find), "miopen_find_seconds": first_s if find else None, "first_calls_s": first_s},
            "kernels_ms": dict(ms, psfnet_mlp=mlp_ms),
+           "hip_graph": ({"ms_per_step": graph_ms, "value": 1e3 / graph_ms, "max_abs_diff_vs_eager": graph_diff,
+                          "what": "the same frame captured once (sdirt_amd.graphs.GraphedCall) and replayed, wall time over the same number of frames"}
+                         if graph_ms is not None else {"error": graph_err}),
            "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_PEAK_F16, "unit": "TFLOP/s", "frac": tf / MFMA_PEAK_F16,
                         "traffic": None, "kernel": "k_psfnet_mlp (3 -> 128 -> 512 x 9 -> 441, both passes of PSFNet.pred: 786432 rows)",
                         "algorithmic_flops_per_launch": flops,
@@ -902,7 +925,7 @@ def also_block(args, lens, device):
         try:
             r = fn()
             keep = ("metric", "value", "unit", "steps", "ms_per_step", "config", "roofline", "kernels_ms", "staged",
-                    "value_pcie_inclusive", "reference_harness", "shard_sweep")
+                    "value_pcie_inclusive", "reference_harness", "shard_sweep", "hip_graph")
             out[name] = {k: r[k] for k in keep if k in r}
         except Exception as e:       # a broken side line must not cost the headline
             out[name] = {"error": f"{type(e).__name__}: {e}"}

@@ -366,6 +366,13 @@ def test_tone_curve_kernels_equal_the_torch_chain():
     assert (back - x).abs().max().item() < 1e-2               # gamma ~ inverse of degamma (two blended fits)
 
 
+def _eager_frame(m, net, img, depth, foc):
+    with torch.no_grad():
+        pair = m.render(img, depth, foc)
+        with torch.autocast("cuda", dtype=torch.float16):
+            return pair, net(pair[:, :3].contiguous(), pair[:, 3:].contiguous())
+
+
 def test_config5_image_simulation_then_depth_network_in_one_chain():
     """BASELINE config 5 as ONE chain at its real size (2_dfdp_net.py:273-344 renders, :165-230 feeds
     the depth network): seeded synthetic RGB-D frame 512 x 768 -> PSFNet.render with the full-size
@@ -412,3 +419,24 @@ def test_config5_image_simulation_then_depth_network_in_one_chain():
     print(f"config 5 chain: fused vs op-by-op render {d_render:.2e}; fp16-autocast vs fp32 disparity {d_disp:.2e} px")
     assert d_render <= 1.5e-3
     assert d_disp <= 5e-2
+
+    # the whole frame captured once in a hipGraph (sdirt_amd.graphs.GraphedCall) and replayed: the same kernels on the same
+    # buffers -- the simulated pair equals the eager call's, also after the static inputs were refreshed in place
+    from sdirt_amd.graphs import GraphedCall
+
+    def frame():
+        with torch.no_grad():
+            pair = m.render(img, depth, foc)
+            with torch.autocast("cuda", dtype=torch.float16):
+                return pair, net(pair[:, :3].contiguous(), pair[:, 3:].contiguous())
+    graphed = GraphedCall(frame, warmup=2, device=DEV)
+    pair_g, disp_g = graphed()
+    torch.cuda.synchronize()
+    assert torch.equal(pair_g, dp) and float((disp_g.float() - disp16.float()).abs().max()) <= 2e-3
+    img2 = torch.rand(1, 3, H, W, device=DEV, generator=g)
+    want_pair, want_disp = (t.clone() for t in _eager_frame(m, net, img2, depth, foc))
+    img.copy_(img2)
+    pair_g, disp_g = graphed()
+    torch.cuda.synchronize()
+    assert torch.equal(pair_g, want_pair) and float((disp_g.float() - want_disp.float()).abs().max()) <= 2e-3
+    assert not torch.equal(want_pair, dp)
