@@ -339,8 +339,9 @@ class DfDPNet(nn.Module):
     #: inference on the GPU (eval mode): BOTH views through the feature network in ONE pass (a batch of two: batch norm
     #: uses its running statistics in eval mode, so the halves are what two calls give), the 2-D network in channels_last,
     #: the cost volume and the 3-D hourglass in channels_last_3d -- the layouts MIOpen's MI355X convolution kernels
-    #: compute in (no transposes around them).  512 x 768, fp16 autocast, after the find pass: 2.50 -> 2.1 ms
-    #: (tools/dfdp_ab.py, profiles/r06/dfdp_ab.txt).  Training keeps the reference's two calls (batch statistics per view).
+    #: compute in (no transposes around them).  512 x 768, fp16 autocast, after the find pass: 2.50 -> 1.94 ms, 1.45 with
+    #: `inference_fusions` (tools/dfdp_ab.py, profiles/r06/dfdp_ab.txt).  Training keeps the reference's two calls (batch
+    #: statistics per view).
     inference_layout = True
 
     def _lay_out(self):
