@@ -160,6 +160,27 @@ def all_gather_shards(local, n_total, world, group=None, out=None, algo=None, pa
     return torch.cat([out[r * width:r * width + (b - a)] for r, (a, b) in enumerate(bounds)])
 
 
+def gathered_volume_holds_every_shard(volume, own, n_total, group=None):
+    """Did the gather deliver every rank's rows to every rank?  `own` = the rows THIS rank contributed ([n_local, ...], may be
+    empty), `volume` = its copy of the gathered [n_total, ...] volume.  Each rank sums the BIT PATTERNS of `own` (int64 sum of
+    the int32 view: exact, order-free), the sums travel in one small all-reduce, every rank compares them with the sums of the
+    corresponding rows of its copy, and the verdicts are reduced: True on every rank iff every copy holds every shard bit for
+    bit.  Two collectives of a few bytes, whatever the volume's size."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    dev = volume.device
+    bits = lambda t: t.reshape(-1).view(torch.int32).sum(dtype=torch.int64)  # noqa: E731
+    sums = torch.zeros(world, dtype=torch.int64, device=dev)
+    if own.numel():
+        sums[rank] = bits(own.contiguous())
+    dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+    mine = torch.stack([bits(volume[a:b]) if b > a else torch.zeros((), dtype=torch.int64, device=dev)
+                        for a, b in shard_bounds(n_total, world)])
+    bad = torch.zeros(1, dtype=torch.int64, device=dev)
+    bad[0] = int(not bool((mine == sums).all()))
+    dist.all_reduce(bad, op=dist.ReduceOp.SUM, group=group)
+    return int(bad.item()) == 0
+
+
 class ShardedPSF:
     """psf_lr over a point grid partitioned across the ranks of `group`.
 

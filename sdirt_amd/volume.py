@@ -343,26 +343,13 @@ class VolumeStepper:
         return self._volume
 
     def verify_gather(self):
-        """After fence(), gathering on: did the last all-gather deliver every rank's rows to every rank?  Each rank sums the
-        BIT PATTERNS of the block it rendered in the last step (int64 sum of the int32 view: exact, order-free), the sums
-        travel in one small all-reduce, and every rank compares them with the sums of the corresponding rows of ITS copy of
-        the volume.  -> True on every rank iff every rank's copy holds every shard bit for bit; None when nothing was gathered."""
+        """After fence(), gathering on: every rank's copy of the most recently gathered volume holds every rank's block of the
+        last step, bit for bit (dist.gathered_volume_holds_every_shard: checksums of the bit patterns, two tiny collectives).
+        -> the same bool on every rank; None when nothing was gathered."""
         if not (self.gather and self.gathers and self._volume is not None):
             return None
-        dist, dev = self.dist, self.device
         s = self._slots[(self.steps - 1) % len(self._slots)]
-        sums = torch.zeros(self.world + 1, dtype=torch.int64, device=dev)
-        if self.n_local:
-            sums[self.rank] = s.out[:self.n_local].view(torch.int32).sum(dtype=torch.int64)
-        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=self.group)
-        vol = self._volume
-        mine = torch.stack([vol[a:b].reshape(-1).view(torch.int32).sum(dtype=torch.int64) if b > a
-                            else torch.zeros((), dtype=torch.int64, device=dev)
-                            for a, b in self.sd.shard_bounds(self.n_total, self.world)])
-        bad = torch.zeros(1, dtype=torch.int64, device=dev)
-        bad[0] = int(not bool((mine == sums[:self.world]).all()))
-        dist.all_reduce(bad, op=dist.ReduceOp.SUM, group=self.group)
-        return int(bad.item()) == 0
+        return self.sd.gathered_volume_holds_every_shard(self._volume, s.out[:self.n_local], self.n_total, self.group)
 
     def kernel_ms(self):
         """Mean HIP-event time of the slots' most recent library call (upload of 48 KB + pupil mapping + fused kernel)

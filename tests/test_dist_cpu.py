@@ -64,6 +64,16 @@ def _worker(rank, world, port, n_total, ks, out_dir):
     g2 = sd.all_gather_shards(mine, n_total, world, algo="direct")
     assert torch.equal(g1, g2) and g1.shape[0] == n_total
 
+    # the checksum test of a gathered volume (bench.py's gather.volume_checksums_equal): true for what the gather delivered,
+    # false ON EVERY RANK as soon as one rank's copy differs in one bit of one row
+    rows = torch.arange((b - a) * 6, dtype=torch.float32).reshape(b - a, 2, 3) + 1000.0 * rank
+    vol = sd.all_gather_shards(rows, n_total, world)
+    assert sd.gathered_volume_holds_every_shard(vol, rows, n_total) is True
+    broken = vol.clone()
+    if rank == world - 1 and n_total:
+        broken.view(torch.int32)[n_total // 2, 1, 2] ^= 1          # the last bit of one value, on one rank only
+    assert sd.gathered_volume_holds_every_shard(broken, rows, n_total) is False
+
     # batch-global trip table: the LAST rank holds the slow ray on surface 1
     need = [10, 3 + (rank == world - 1), 0, 2]
     curved = [True, True, False, True]
