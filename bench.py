@@ -1011,8 +1011,14 @@ def gather_algo_trial(loop, steps, dt_default, res, rays):
         for _ in range(3):                 # the peer connections come up with the first transfers
             loop.step()
         loop.fence()
+        loop.gather_ms()                   # (forget the events of the warm-up)
         dt_direct = loop.timed(steps)
         ok = loop.verify_gather()
+        g_ms = loop.gather_ms()            # the exchange's own time on the comm stream, MAX over ranks like the headline's
+        if g_ms is not None:
+            gm = torch.tensor([g_ms], dtype=torch.float64, device=loop.device)
+            dist.all_reduce(gm, op=dist.ReduceOp.MAX)
+            g_ms = float(gm.item())
     except Exception as e:                 # noqa: BLE001 -- whatever it is, the record comes first
         leave(f"{type(e).__name__}: {str(e)[:200]}")
     finally:
@@ -1021,7 +1027,7 @@ def gather_algo_trial(loop, steps, dt_default, res, rays):
     if res is not None:
         adopt = bool(ok) and dt_direct < 0.97 * dt_default
         res["gather"]["trial"] = {"allgather_ms_per_step": dt_default / steps * 1e3, "direct_ms_per_step": dt_direct / steps * 1e3,
-                                  "direct_volume_checksums_equal": ok, "adopted": "direct" if adopt else "allgather",
+                                  "direct_volume_checksums_equal": ok, "direct_gather_ms": g_ms, "adopted": "direct" if adopt else "allgather",
                                   "what": "the K timed steps once more with algo 'direct' (one send + one receive per peer in one "
                                           "group), same fences, MAX over ranks; adopted as `value` when checksums hold and it "
                                           "is more than 3 % faster"}
@@ -1029,8 +1035,11 @@ def gather_algo_trial(loop, steps, dt_default, res, rays):
         if adopt:
             res["value"], res["ms_per_step"] = rays / dt_direct, dt_direct / steps * 1e3
             res["psfs_per_sec"] = res["psfs_per_sec"] * dt_default / dt_direct
-            res["gather"]["algo"] = "direct"
-            res["gather"]["volume_checksums_equal"] = ok
+            g = res["gather"]
+            g["algo"], g["volume_checksums_equal"] = "direct", ok
+            if g_ms:
+                g["ms"], g["GBps_received_per_rank"] = g_ms, g["gb_received_per_rank_per_step"] / (g_ms * 1e-3)
+                g["gather_bound"] = bool(g_ms > g["compute_ms"])
 
 
 def main():

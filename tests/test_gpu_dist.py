@@ -222,6 +222,7 @@ def test_bench_gather_trial_and_its_deadline(fake, tmp_path):
     t = g["trial"]
     if fake is None:
         assert t["direct_ms_per_step"] > 0 and t["allgather_ms_per_step"] > 0 and t["direct_volume_checksums_equal"] is True
+        assert t["direct_gather_ms"] > 0
         assert t["adopted"] in ("allgather", "direct") and g["algo"] == t["adopted"]
         assert res["value_allgather"] > 0 and res["value_direct"] > 0
         assert res["value"] == pytest.approx(res["value_" + t["adopted"]], rel=1e-5)

@@ -593,12 +593,13 @@ def test_the_multi_gpu_line_keeps_the_gather_evidence():
                        "collectives_per_step": 1, "ms": 1.28, "GBps_received_per_rank": 378.0, "compute_ms": 1.15, "gather_bound": True,
                        "volume_checksums_equal": True, "block": "b" * 80, "what": "w" * 300,
                        "trial": {"allgather_ms_per_step": 1.6, "direct_ms_per_step": 1.31, "direct_volume_checksums_equal": True,
-                                 "adopted": "direct", "what": "w" * 300}}}
+                                 "direct_gather_ms": 1.28, "adopted": "direct", "what": "w" * 300}}}
     line = bench.compact(full)
     assert len(json.dumps(line)) < bench.LINE_LIMIT
     g = line["gather"]
     assert g["volume_checksums_equal"] is True and g["algo"] == "direct" and g["gather_bound"] is True
-    assert g["trial"] == {"allgather_ms_per_step": 1.6, "direct_ms_per_step": 1.31, "direct_volume_checksums_equal": True, "adopted": "direct"}
+    assert g["trial"] == {"allgather_ms_per_step": 1.6, "direct_ms_per_step": 1.31, "direct_volume_checksums_equal": True,
+                          "direct_gather_ms": 1.28, "adopted": "direct"}
     assert line["value_allgather"] == 4.2e10 and line["value_direct"] == 5.1e10 and line["value_no_gather"] == 5.6e10
     assert line["scaling"] == "strong" and line["n_gpus"] == 8 and line["config"]["points_per_gpu"] == 2048
 
