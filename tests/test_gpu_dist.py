@@ -123,7 +123,7 @@ def test_config3_whole_grid_sharded_over_eight_ranks(tmp_path, oracle):
 def test_bench_starts_its_own_ranks():
     """`python bench.py --gpus 2` with no launcher around it: spawns 2 ranks, prints ONE JSON
     line carrying both rates, exits 0.  (gloo dry-run backend: both ranks share cuda:0.)"""
-    env = _env(SDIRT_BENCH_BACKEND="gloo")
+    env = _env(SDIRT_BENCH_BACKEND="gloo", SDIRT_GATHER_TRIAL="0")       # (the trial has its own test below)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
@@ -143,7 +143,7 @@ def test_bench_config3_with_eight_ranks_on_one_gpu():
     8 ranks x 8192 points, 8192 spp, ks 21, pupil broadcast, mask all-reduce, all-gather of the
     65536-point volume to every rank -- on the ONE GPU of this pool (gloo dry-run backend: the
     control path is the node's, the numbers mean nothing).  One JSON line, n_gpus 8, rc 0."""
-    env = _env(SDIRT_BENCH_BACKEND="gloo")
+    env = _env(SDIRT_BENCH_BACKEND="gloo", SDIRT_GATHER_TRIAL="0")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2",
