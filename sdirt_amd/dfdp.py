@@ -344,17 +344,22 @@ class DfDPNet(nn.Module):
     #: statistics per view).
     inference_layout = True
 
-    def _lay_out(self):
-        if not getattr(self, "_laid_out", False):
-            self.feature.to(memory_format=torch.channels_last)            # 4-D weights only; values, names, dtypes unchanged
-            self.matching.to(memory_format=torch.channels_last_3d)        # 5-D weights only
-            self._laid_out = True
+    def _lay_out(self, pixel_major):
+        """The weights' memory format follows the path that is about to run: channels_last / channels_last_3d for the inference
+        path, planar for the reference's op sequence (training above all: MIOpen's training kernels were seen to fault on
+        pixel-major weights with small maps under fp16 autocast).  Strides only -- values, names, dtypes, the Parameter
+        objects an optimiser holds stay; a switch re-lays ~5 MB, once per change of mode."""
+        if getattr(self, "_laid_out", False) != pixel_major:
+            self.feature.to(memory_format=torch.channels_last if pixel_major else torch.contiguous_format)
+            self.matching.to(memory_format=torch.channels_last_3d if pixel_major else torch.contiguous_format)
+            self._laid_out = pixel_major
 
     def forward(self, xl, yr):
         if self.training or not self.inference_layout or not xl.is_cuda or xl.shape != yr.shape or xl.dtype != yr.dtype:
+            self._lay_out(False)
             cost = dp_cost_volume(self.feature(xl), self.feature(yr), self.maxdisp)          # dddnet.py:123-148
             return self.disp(self.matching(cost))
-        self._lay_out()
+        self._lay_out(True)
         B = xl.shape[0]
         f = self.feature(torch.cat((xl, yr)).contiguous(memory_format=torch.channels_last))
         return self.disp(self.matching(dp_cost_volume(f[:B], f[B:], self.maxdisp)))

@@ -12,7 +12,9 @@ forward + backward is captured the same way, psfnet.py: train_psfnet(pipelined=T
 
 Everything the chain launches must be launched on torch's current stream (this package's kernels are: basics.stream_ptr),
 must not synchronise with the host, and must have made its one-off choices before the capture (MIOpen's find pass, cached
-fp16 weights, packed MLP weights, trip tables): that is what the warm-up calls are for.
+fp16 weights, packed MLP weights, trip tables): that is what the warm-up calls are for.  A graph replays POINTERS: whatever
+the chain reads besides the static inputs (weights, cached copies, tables) must stay where it was -- a module that is trained
+or re-laid (DfDPNet switches its weights' memory format between its inference and its training path) needs a new capture.
 """
 import torch
 

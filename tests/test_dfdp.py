@@ -180,6 +180,9 @@ def test_inference_layout_one_feature_pass_pixel_major_tensors():
     net.train()                                                  # training: the reference's two calls (batch statistics per view)
     out = net(torch.cat((xl, xl.flip(-1))), torch.cat((xr, xr.flip(-1))))     # (two samples: a 1 x 1 context map needs them)
     assert out.requires_grad and torch.isfinite(out).all()
+    # ... on planar weights again (the layout follows the path), the same Parameter objects, the same values
+    assert not net._laid_out and net.feature.start[0].conv.weight.is_contiguous()
+    assert all(torch.equal(net.state_dict()[k], before[k]) for k in before if "running" not in k and "num_batches" not in k)
 
 
 @pytest.mark.gpu
@@ -273,6 +276,19 @@ def test_inference_fusions_equal_the_torch_ops_they_stand_for():
     # with autograd on (fine-tuning with frozen statistics) the differentiable torch ops run
     out = net(xl, xr)
     assert out.requires_grad
+    # ... and a training step goes through the reference's op sequence whatever layout the weights were left in (the
+    # inference calls above re-laid them): two samples, fp16 autocast, loss scaling as 2_dfdp_net.py's loop
+    net.train()
+    opt = torch.optim.AdamW(net.parameters(), 1e-4)
+    scaler = torch.amp.GradScaler("cuda")
+    x2, y2 = torch.cat((xl, xl.flip(-1))), torch.cat((xr, xr.flip(-1)))
+    with torch.autocast("cuda", dtype=torch.float16):
+        loss = (net(x2, y2).float() + 0.5).abs().mean()
+    scaler.scale(loss).backward()
+    grads = [p.grad for p in net.parameters() if p.grad is not None]
+    assert len(grads) > 40 and all(torch.isfinite(g).all() for g in grads) and any(float(g.abs().max()) > 0 for g in grads)
+    scaler.step(opt)
+    scaler.update()
 
 
 @pytest.mark.gpu
