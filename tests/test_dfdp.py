@@ -292,7 +292,7 @@ def test_inference_fusions_equal_the_torch_ops_they_stand_for():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("size", [(128, 128), (256, 384)])
+@pytest.mark.parametrize("size", [(128, 128), (256, 384), (192, 320)])
 def test_inference_path_reproduces_the_hourglass_output_not_only_the_disparity(size):
     """With seeded weights the softmin is nearly uniform (the fixture's disparities are -0.5 +- 3e-4), so a disparity map
     says little about the tensors behind it.  This compares what Disp RECEIVES -- the hourglass's [B, 1, 20, H/4, W/4] volume --
@@ -302,8 +302,9 @@ def test_inference_path_reproduces_the_hourglass_output_not_only_the_disparity(s
     fx = load_golden("f10_dfdp_net")
     net = build(fx)
     g = torch.Generator().manual_seed(7)
-    xl = torch.rand(1, 3, *size, generator=g)
-    xr = torch.roll(xl, 2, dims=-1) * 0.9 + 0.05 * torch.rand(1, 3, *size, generator=g)
+    B = 2 if size == (192, 320) else 1             # (192 x 320: a batch of two, quarter-size maps the 32 x 32 windows do not divide)
+    xl = torch.rand(B, 3, *size, generator=g)
+    xr = torch.roll(xl, 2, dims=-1) * 0.9 + 0.05 * torch.rand(B, 3, *size, generator=g)
     seen = {}
     hook = net.disp.register_forward_pre_hook(lambda m, args: seen.__setitem__("x", args[0].detach().float().cpu().contiguous()))
     try:
@@ -325,7 +326,7 @@ def test_inference_path_reproduces_the_hourglass_output_not_only_the_disparity(s
         hook.remove()
         D.inference_fusions = True
     scale = want.abs().max().item()
-    assert want.shape == (1, 1, 20, size[0] // 4, size[1] // 4) and want.std().item() > 0.02 * scale      # a tensor with structure
+    assert want.shape == (B, 1, 20, size[0] // 4, size[1] // 4) and want.std().item() > 0.02 * scale      # a tensor with structure
     e32 = (got32 - want).abs().max().item() / scale
     e16 = (got16 - want).abs().max().item() / scale
     r16 = (ref16 - want).abs().max().item() / scale
