@@ -231,6 +231,10 @@ def test_bench_gather_trial_and_its_deadline(fake, tmp_path):
         assert ("no result within" in t["direct"]) if fake == "hang" else ("SDIRT_BENCH_FAKE_TRIAL" in t["direct"])
         assert "value_direct" not in res
     assert time.time() - t0 < 600
+    log = os.environ.get("SDIRT_TEST_LOG_DIR")
+    if log:
+        with open(os.path.join(log, f"bench_gpus4_dryrun_c3_trial_{fake or 'ran'}.log"), "w") as f:
+            f.write(lines[0] + "\n")
 
 
 @pytest.mark.gpu
