@@ -28,7 +28,8 @@ Rank 0 prints ONE JSON line (see the driver contract) of less than 4 KB: the con
 dominant kernel, k_psf_lr; the figures that say something -- valu_flops_frac, valu_issue_frac -- as flat scalars),
 `cpu_baseline` (oracle/: a C port of the reference's CPU path, OpenMP over the host cores, and a PyTorch-CPU
 restatement of the reference's whole-tensor execution model, on a bounded sample of the same workload; oracle/ is only
-loaded for that leg), `also_summary` ([value, ms_per_step, roofline frac] of the staged SoA chain, f1, c4, c3, tcp, c5)
+loaded for that leg), `also_summary` ([value, ms_per_step, roofline frac] of the staged SoA chain, f1, c4, c3, tcp, fit =
+the loop of 1_fit_psfnet.py, c5 = config 5 end to end)
 and `sweep_summary` (the strong-scaling compute side on this one GPU).  The FULL record -- per-kernel tables, counter
 provenance, notes -- goes to the file named under `detail` (--detail-file, default bench_detail.json) and, with
 --verbose, to stderr.
@@ -76,7 +77,7 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s HBM3E
 VALU_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: vector fp32 (FMA counted as 2; the parity contract forbids contraction)
 # the two workloads either side of the hot path: not PSF-volume renders
-EXTRA_WORKLOADS = ("f1", "tcp", "staged", "sweep", "c5")
+EXTRA_WORKLOADS = ("f1", "tcp", "staged", "sweep", "c5", "fit")
 
 
 _JSON_FD = None
@@ -873,6 +874,45 @@ def bench_c5(args, emit=True):
     return res
 
 
+def bench_fit(args, emit=True):
+    """The loop of 1_fit_psfnet.py at its own settings (PSFNet.train_psfnet, psfnet.py:101-168; 1_fit_psfnet.py:36: bs 64, spp
+    20000, ks 21, the full-size MLP): every iteration ray-traces a fresh batch of 64 PSFs (64 x 20000 primary + 64 x 2048
+    chief-ray rays through the fused kernel, trip tables verified on the device) and takes one AdamW step on the PSF
+    network under fp16 autocast with loss scaling -- forward + backward replayed from a hipGraph, batches ray-traced two
+    ahead on a second stream (train_psfnet(pipelined=True), the default on the GPU).  A step = one iteration; `value` =
+    iterations per second over max(steps, 1000) iterations of ONE train_psfnet call, its set-up (optimiser, graph capture:
+    ~0.1 s) included, after a 20-iteration call that has found the trip tables."""
+    import tempfile
+    from sdirt_amd.psfnet import PSFNet
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback exists)"
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    np.random.seed(0)
+    m = PSFNet(os.path.join(ROOT, "sdirt_amd", "data", "rf50mm.json"), sensor_res=(512, 768), kernel_size=21, device=dev)
+    m.refocus(-1000 + m.d_sensor)
+    iters = max(args.steps, 1000)
+    with tempfile.TemporaryDirectory() as tmp:
+        kw = dict(bs=64, lr=1e-4, spp=20000, evaluate_every=10 ** 9, result_dir=tmp, figures=False)
+        m.train_psfnet(iters=20, **kw)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        losses = m.train_psfnet(iters=iters - 1, **kw)               # (the loop runs iters + 1 steps, as the reference's)
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+    n = len(losses)
+    res = {"metric": "iterations/sec of 1_fit_psfnet.py's loop (64 ray-traced 21x21 PSFs @20000spp + one AdamW step of the PSF network)",
+           "value": n / dt, "unit": "iterations/s", "n_gpus": 1, "steps": n, "warmup": 20, "ms_per_step": dt / n * 1e3,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 rays / f16 autocast network", "data": "synthetic",
+           "rays_per_sec": n * 64 * 20000 / dt,
+           "config": {"workload": "1_fit_psfnet.py:36 train_psfnet(bs=64, spp=20000), rf50mm, ks 21, MLP 3-128-512x9-441, AdamW + cosine "
+                                  "schedule, fp16 autocast + loss scaling; PSF batches from the fused HIP kernel", "name": "fit",
+                      "host_relaunches_total": int(m.trips.relaunches), "device_corrections_total": int(m.trips.device_relaunches)},
+           "loss_first_last": [float(losses[0]), float(losses[-1])]}
+    if emit:
+        emit_line(res)
+    return res
+
+
 def quick_volume(workload, steps, device):
     """K steps of another PSF-volume workload (WORKLOADS) through the headline's loop (VolumeStepper) -- for the `also`
     block of the default line."""
@@ -902,8 +942,8 @@ def quick_volume(workload, steps, device):
 def also_block(args, lens, device):
     """The other driver-timed lines of the default run: the staged SoA chain (HBM-bound kernels; call by call and through
     the fused entries), the per-pixel PSF convolution f1 (HBM-bound), config 4 (rf35mm, the second prescription), one
-    GPU's share of config 3 (8192 points x 8192 spp, 21 x 21), the reference's own timing harness (tcp), config 5 end to
-    end (c5) -- five steps each -- and the strong-scaling compute side (shard_sweep: 50 steps per shard size)."""
+    GPU's share of config 3 (8192 points x 8192 spp, 21 x 21), the reference's own timing harness (tcp), the loop of
+    1_fit_psfnet.py (fit: 1000 iterations), config 5 end to end (c5) -- and the strong-scaling compute side (shard_sweep)."""
     import copy
     q = copy.copy(args)
     q.steps, q.warmup, q.sustain_seconds = 20, 2, 0.0
@@ -918,6 +958,7 @@ def also_block(args, lens, device):
                      ("c4", lambda: quick_volume("c4", 20, device)),
                      ("c3", lambda: quick_volume("c3", 20, device)),
                      ("tcp", lambda: bench_tcp(q, emit=False)),
+                     ("fit", lambda: bench_fit(q, emit=False)),
                      ("c5", lambda: bench_c5(q, emit=False)),
                      # last: it opens (and closes) a world-1 RCCL process group in this process
                      ("shard_sweep", lambda: bench_sweep(q, emit=False, lens=lens))):
@@ -1077,7 +1118,8 @@ def main():
                          "timing harness PSFNet.time_compare_psf (psfnet.py:570-586); staged: the reference's own "
                          "call sequence sample -> trace -> propagate -> forward_integral on SoA rays in HBM; sweep: config 2 "
                          "cut to the step of one rank of a 1 / 2 / 4 / 8-GPU strong-scaling run, collectives on a world-1 RCCL "
-                         "group; c5: config 5 end to end (RGB-D frame -> PSFNet.render -> DfDP net forward)")
+                         "group; c5: config 5 end to end (RGB-D frame -> PSFNet.render -> DfDP net forward); fit: the loop of "
+                         "1_fit_psfnet.py (a ray-traced batch of 64 PSFs @20000 spp + one AdamW step per iteration)")
     ap.add_argument("--staged-ks", default="65,21", help="--workload staged: the grid sizes to run the chain for")
     ap.add_argument("--staged-chain", choices=("both", "calls"), default="both",
                     help="--workload staged: `calls` times the call-by-call chain only (the profiling recipe: one kernel "
@@ -1091,7 +1133,8 @@ def main():
         claim_stdout()
     if args.workload in EXTRA_WORKLOADS:
         assert args.gpus == 1, f"--workload {args.workload} is a single-GPU measurement"
-        return {"f1": bench_f1, "tcp": bench_tcp, "staged": bench_staged, "sweep": bench_sweep, "c5": bench_c5}[args.workload](args)
+        return {"f1": bench_f1, "tcp": bench_tcp, "staged": bench_staged, "sweep": bench_sweep, "c5": bench_c5,
+                "fit": bench_fit}[args.workload](args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
     global KS, SPP, GRID_Z

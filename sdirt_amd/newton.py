@@ -151,7 +151,9 @@ class TripPlanner:
             # planner outlives edits of the prescription it serves)
             sig = None
             if identity:
-                sig = (curved_sig, tuple((tuple(int(x) for x in t), tuple(int(x) for x in m)) for t, m in zip(tables, masks)))
+                # (the arrays' bytes: ~1 us per pass; element by element this line was 0.12 ms of every psf call)
+                sig = (curved_sig, tuple((np.asarray(t, dtype=np.int64).tobytes(), np.asarray(m, dtype=np.int64).tobytes())
+                                         for t, m in zip(tables, masks)))
                 if sig in self._accepted:
                     for k, t in zip(keys, tables):
                         self.learn(k, t)

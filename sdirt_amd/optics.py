@@ -90,6 +90,15 @@ class PendingPSF:
 class Lensgroup:
     """optics.py:22-116.  `device` must be a CUDA (ROCm) device for anything that traces."""
 
+    #: psf_lr(defer=True) of the fitting shape (few points, many samples) through ONE library call (sdirt_psf_call, as the
+    #: synchronous call) instead of the general path's separate launches.  Alone it is the faster producer -- 0.25 against
+    #: 0.30 ms per 64 x 20000 batch with two in flight, 0.18 against 0.27 ms of host work (tools/psf_defer_ab.py) -- but beside
+    #: the fitting loop's hipGraph it is the slower one (1.05 against 0.84 ms per iteration): its kernels follow each other
+    #: without the host's gaps, a generation of its workgroups fills every wave slot of the chip, and the graph's chain of
+    #: small dependent kernels waits it out.  Off by default (train_psfnet is the caller of defer=True); a pure data
+    #: generator may switch it on.
+    defer_one_call = False
+
     def __init__(self, filename=None, sensor_res=(1024, 1024), use_roc=False,
                  post_computation=True, device=None):
         self.device = _as_device(device)
@@ -194,7 +203,7 @@ class Lensgroup:
 
     # nn.Module-style switches: the reference's Lensgroup / PSFNet inherit them from DeepObj(nn.Module)
     # (basics.py:165-213) and its scripts call them (dfdp/factory.py:15,31-32: lens.to(device), lens.eval())
-    _DEVICE_CACHES = ("_stage_ring", "_sample_stream", "_readback_stream", "_ctl_pools", "_p2o_cache", "_ctl_host",
+    _DEVICE_CACHES = ("_stage_ring", "_sample_stream", "_readback_stream", "_ctl_pools", "_p2o_cache", "_ctl_host", "_ctl_host_ring",
                       "_right_streak", "_n_cus", "_pinned_out")
 
     def train(self, mode=True):
@@ -889,13 +898,15 @@ class Lensgroup:
                 raise ValueError(f"defer=True / out=[N, 2, ks, ks] need ks <= {_lib.MAX_KS}")
             return self._psf_lr_staged(points, po, N, ks, wvln, spp, center, dp, normalize, want_r,
                                        _default_r_zero, pupil_xy, center_pupil_xy, out, center_out, single_point)
-        if (center and not defer and pupil_xy is None and center_pupil_xy is None and N > 0
+        if (center and pupil_xy is None and center_pupil_xy is None and N > 0 and (not defer or self.defer_one_call)
                 and self.trip_policy == "reference" and self.mask_reduce is None and self.pupil_mapping == "device"
                 and self.kernel_events is None and self._spp_slices(N, spp) > 1):
-            # the synchronous call of the fitting shape (few points, many samples): launch-latency-bound,
-            # so everything between the random draw and the stream synchronisation is ONE library call
+            # the fitting shape (few points, many samples): launch-latency-bound, so everything between the random
+            # draw and the check of what the device did is ONE library call -- followed by a stream synchronisation
+            # (the synchronous call) or by a PendingPSF that waits for the call's own event (defer=True: the fitting
+            # loop keeps two batches in flight; ~0.1 ms of host work per batch instead of ~0.4 through the general path)
             return self._psf_call_one(points, po, N, ks, wvln, spp, dp, normalize, want_r, _default_r_zero, out,
-                                      center_out, single_point)
+                                      center_out, single_point, defer=defer)
         both_drawn = None
         if pupil_xy is None and center and center_pupil_xy is None:
             # both sample sets of the call in one draw / upload (same numbers, same order)
@@ -1152,9 +1163,23 @@ class Lensgroup:
             R = R.squeeze(0) if R is not None else None
         return L, R
 
+    def _ctl_host_slot(self):
+        """A page-locked control-block mirror for one call in flight (ring of eight; a slot whose call has not been waited
+        for yet is settled first -- its numbers are read before anybody may overwrite them)."""
+        ring = self.__dict__.setdefault("_ctl_host_ring", {"slots": [], "next": 0})
+        if len(ring["slots"]) < 8:
+            ring["slots"].append([torch.empty(_lib.CTL_WORDS, dtype=torch.int32, pin_memory=True), None])
+            return ring["slots"][-1]
+        slot = ring["slots"][ring["next"]]
+        ring["next"] = (ring["next"] + 1) % 8
+        if slot[1] is not None:
+            slot[1].wait()
+        return slot
+
     def _psf_call_one(self, points, po, N, ks, wvln, spp, dp, normalize, want_r, default_r_zero, out, center_out,
-                      single_point):
-        """psf_lr(center=True) for sdirt_psf_spp_slices(N, spp) > 1, synchronous form, through sdirt_psf_call:
+                      single_point, defer=False):
+        """psf_lr(center=True) for sdirt_psf_spp_slices(N, spp) > 1 through sdirt_psf_call (defer: the check of what the
+        device did moves into the returned PendingPSF, which waits for the call's own event instead of the stream):
         the host draws the 2 spp + 2 x 2048 uniforms (one torch.rand, the reference's order) into page-locked
         memory; ONE library call enqueues their upload, the two pupil mappings, both rounds of the
         device-verified render and the copy of the control block back; the host waits for the stream and
@@ -1183,9 +1208,8 @@ class Lensgroup:
         n = 2 * (spp + Sc)
         words = int(h.sdirt_psf_call_scratch_bytes(N, spp, Sc) // 4)
         scratch = self._zeroed_control_block(words)
-        hbuf = self.__dict__.get("_ctl_host")
-        if hbuf is None:
-            hbuf = self.__dict__["_ctl_host"] = torch.empty(_lib.CTL_WORDS, dtype=torch.int32, pin_memory=True)
+        slot = self._ctl_host_slot()
+        hbuf = slot[0]
         stage, uploaded = self._staging(n, rows=1)
         st = stream_ptr(self.device)
         _hostrng.rand_into(stage[0])                         # the reference's four draws, in one (see _pupil_samples_pair)
@@ -1196,44 +1220,55 @@ class Lensgroup:
             dptr(cen), dptr(L), dptr(R), dptr(scratch), C.c_void_p(hbuf.data_ptr()), st))
         stream = torch.cuda.current_stream(self.device)
         uploaded.record(stream)
-        stream.synchronize()
-        hh = hbuf.numpy().view(np.uint32).copy()
-        # the pupil points the device mapped: behind the control block and the partial sums in `scratch`
-        base = words - 2 * n
-        xy = scratch[base + n:].view(torch.float32)
-        x2, y2, xc, yc = xy[:spp], xy[spp:2 * spp], xy[2 * spp:2 * spp + Sc], xy[2 * spp + Sc:]
-        self.last_pupil_points = (x2, y2, xc, yc)
-        state = {"any": int(hh[_lib.CTL_ANY_VALID])}
-        self.__dict__["_right_streak"] = streak + 1 if hh[_lib.CTL_STATUS] == 0 else 0
-        rounds = [(tables, [hh[_lib.CTL_MASKS:_lib.CTL_MASKS + K], hh[_lib.CTL_MASKS + 64:_lib.CTL_MASKS + 64 + K]])]
-        if hh[_lib.CTL_STATUS] and not (flags & _lib.PSF_ONE_ROUND):
-            unpack = lambda w: np.array([((int(w[k >> 2]) >> ((k & 3) * 8)) & 0xFF) for k in range(K)],
-                                        np.int32).astype(np.int8).astype(np.int32)
-            rounds.append(([unpack(hh[_lib.CTL_TRIPS2:_lib.CTL_TRIPS2 + 16]),
-                            unpack(hh[_lib.CTL_TRIPS2 + 16:_lib.CTL_TRIPS2 + 32])],
-                           [hh[_lib.CTL_MASKS + 128:_lib.CTL_MASKS + 128 + K],
-                            hh[_lib.CTL_MASKS + 192:_lib.CTL_MASKS + 192 + K]]))
+        done = torch.cuda.Event()
+        done.record(stream)
+        keep = (po, scratch, stage, cen)                      # alive until the call has run
 
-        def launch(tabs):                                    # a further, host-driven round (rare)
-            ctl = self._zeroed_control_block(2 * MS + 1)
-            masks, anyv = ctl[:2 * MS].view(2, MS), ctl[2 * MS:]
-            _lib.check(h.sdirt_psf_lr_centered(
-                handle, handle_c, dptr(po), N, dptr(x2), dptr(y2), spp, dptr(xc), dptr(yc), Sc, float(pupilz),
-                float(self.d_sensor), float(self.pixel_size), ks, dp_ref, (C.c_int32 * K)(*[int(t) for t in tabs[0]]),
-                (C.c_int32 * K)(*[int(t) for t in tabs[1]]), flags, dptr(cen), dptr(anyv), dptr(L), dptr(R),
-                dptr(masks[0]), dptr(masks[1]), stream_ptr(self.device)))
-            host = ctl.cpu().numpy()
-            state["any"] = int(host[2 * MS])
-            m = host[:2 * MS].reshape(2, MS)[:, :K].astype(np.int64) & 0xFFFFFFFF
-            return [m[0], m[1]]
-        self.trips.run_many(keys, curved, list(range(K)), launch, done=rounds)
-        assert state["any"] == 1, "No sampled rays is valid."   # optics.py:902
-        if R is None and want_r:
-            R = torch.zeros_like(L)
-        if single_point:
-            L = L.squeeze(0)
-            R = R.squeeze(0) if R is not None else None
-        return L, R
+        def finish():
+            done.synchronize()
+            hh = hbuf.numpy().view(np.uint32).copy()
+            slot[1] = None
+            # the pupil points the device mapped: behind the control block and the partial sums in `scratch`
+            base = words - 2 * n
+            xy = keep[1][base + n:].view(torch.float32)
+            x2, y2, xc, yc = xy[:spp], xy[spp:2 * spp], xy[2 * spp:2 * spp + Sc], xy[2 * spp + Sc:]
+            self.last_pupil_points = (x2, y2, xc, yc)
+            state = {"any": int(hh[_lib.CTL_ANY_VALID])}
+            self.__dict__["_right_streak"] = self.__dict__.get("_right_streak", 0) + 1 if hh[_lib.CTL_STATUS] == 0 else 0
+            rounds = [(tables, [hh[_lib.CTL_MASKS:_lib.CTL_MASKS + K], hh[_lib.CTL_MASKS + 64:_lib.CTL_MASKS + 64 + K]])]
+            if hh[_lib.CTL_STATUS] and not (flags & _lib.PSF_ONE_ROUND):
+                unpack = lambda w: np.array([((int(w[k >> 2]) >> ((k & 3) * 8)) & 0xFF) for k in range(K)],
+                                            np.int32).astype(np.int8).astype(np.int32)
+                rounds.append(([unpack(hh[_lib.CTL_TRIPS2:_lib.CTL_TRIPS2 + 16]),
+                                unpack(hh[_lib.CTL_TRIPS2 + 16:_lib.CTL_TRIPS2 + 32])],
+                               [hh[_lib.CTL_MASKS + 128:_lib.CTL_MASKS + 128 + K],
+                                hh[_lib.CTL_MASKS + 192:_lib.CTL_MASKS + 192 + K]]))
+
+            def launch(tabs):                                    # a further, host-driven round (rare)
+                ctl = self._zeroed_control_block(2 * MS + 1)
+                masks, anyv = ctl[:2 * MS].view(2, MS), ctl[2 * MS:]
+                _lib.check(h.sdirt_psf_lr_centered(
+                    handle, handle_c, dptr(po), N, dptr(x2), dptr(y2), spp, dptr(xc), dptr(yc), Sc, float(pupilz),
+                    float(self.d_sensor), float(self.pixel_size), ks, dp_ref, (C.c_int32 * K)(*[int(t) for t in tabs[0]]),
+                    (C.c_int32 * K)(*[int(t) for t in tabs[1]]), flags, dptr(cen), dptr(anyv), dptr(L), dptr(R),
+                    dptr(masks[0]), dptr(masks[1]), stream_ptr(self.device)))
+                host = ctl.cpu().numpy()
+                state["any"] = int(host[2 * MS])
+                m = host[:2 * MS].reshape(2, MS)[:, :K].astype(np.int64) & 0xFFFFFFFF
+                return [m[0], m[1]]
+            self.trips.run_many(keys, curved, list(range(K)), launch, done=rounds)
+            assert state["any"] == 1, "No sampled rays is valid."   # optics.py:902
+            L_, R_ = L, R
+            if R_ is None and want_r:
+                R_ = torch.zeros_like(L_)
+            if single_point:
+                L_ = L_.squeeze(0)
+                R_ = R_.squeeze(0) if R_ is not None else None
+            return L_, R_
+
+        pending = PendingPSF(finish)
+        slot[1] = pending
+        return pending if defer else pending.wait()
 
     def psf_rgb(self, points, ks=31, spp=GEO_SPP, center=True, param_list=None, pupil_xy=None,
                 center_pupil_xy=None):

@@ -66,11 +66,10 @@ class PSFNet(Lensgroup):
         return z * (self.d_max - self.d_min) + self.d_min
 
     def _warp_z(self, z_gauss, foc_z):
-        # psfnet.py:190-193 / 229-232
-        z = torch.zeros_like(z_gauss)
-        z[z_gauss > 0] = (1 - foc_z) * z_gauss[z_gauss > 0] / 3 + foc_z
-        z[z_gauss < 0] = foc_z * z_gauss[z_gauss < 0] / 3 + foc_z
-        return z
+        # psfnet.py:190-193 / 229-232: z[z_gauss > 0] = (1 - foc_z) * z_gauss / 3 + foc_z, z[z_gauss < 0] = foc_z * z_gauss / 3 + foc_z,
+        # 0 where z_gauss == 0 -- the same elementwise arithmetic without the four boolean-mask gathers / scatters
+        zero = torch.zeros_like(z_gauss)
+        return torch.where(z_gauss > 0, (1 - foc_z) * z_gauss / 3 + foc_z, torch.where(z_gauss < 0, foc_z * z_gauss / 3 + foc_z, zero))
 
     def get_training_data(self, bs=256, spp=4096, _defer=False):
         """psfnet.py:170-202: (inp [bs,3] in [-1,1]^2 x [0,1], psf [bs,ks,ks] on the GPU).
@@ -133,10 +132,11 @@ class PSFNet(Lensgroup):
         Returns the list of per-step training losses.
 
         pipelined (default: on for CUDA devices): the loop is launch-bound at the reference's
-        batch size (64 rows through 11 small GEMMs, forward and backward), so forward + backward
-        are captured once in a hipGraph and replayed, the optimiser runs as one fused kernel
-        without reading the inf-check back, and batch i+1 is ray-traced on a second stream
-        while step i runs.  Same draws from the RNGs in the same order (prefetching stops at an
+        batch size (64 rows through 11 small GEMMs, forward and backward), so the WHOLE step --
+        forward, backward, the loss scaler's unscale / inf check, the fused AdamW update, the
+        scaler's update -- is captured once in a hipGraph and replayed (the learning rate of the
+        step is a device scalar the host fills from the schedule before each replay), and batch
+        i+1 is ray-traced on a second stream while step i runs.  Same draws from the RNGs in the same order (prefetching stops at an
         evaluation step, whose test-set draws come first, and resumes after it), same arithmetic
         per step; `pipelined=False` is the plain loop.  figures=False: no matplotlib, no iterN.png (the
         checkpoints and the logged test errors stay); with figures on, matplotlib is imported before the first step,
@@ -150,8 +150,18 @@ class PSFNet(Lensgroup):
         on_gpu = torch.device(self.device).type == "cuda"
         pipelined = on_gpu if pipelined is None else (pipelined and on_gpu)
         l2, l1 = torch.nn.MSELoss(reduction="mean"), torch.nn.L1Loss(reduction="mean")
-        optim = torch.optim.AdamW(psfnet.parameters(), lr, **({"fused": True} if pipelined else {}))
-        sche = torch.optim.lr_scheduler.CosineAnnealingLR(optim, T_max=int(iters) // 3, eta_min=0)
+        if pipelined:
+            # the step runs inside a graph: the learning rate is a device scalar (a Python float would be frozen into the
+            # capture), and the schedule is evaluated in Python floats on a stand-in optimiser -- the very numbers the plain
+            # loop's scheduler hands its optimiser -- and filled into that scalar before each replay
+            lr_dev = torch.tensor(float(lr), dtype=torch.float32, device=self.device)
+            optim = torch.optim.AdamW(psfnet.parameters(), lr_dev, fused=True, capturable=True)
+            shadow = torch.optim.SGD([torch.zeros(1)], lr)
+            sche = torch.optim.lr_scheduler.CosineAnnealingLR(shadow, T_max=int(iters) // 3, eta_min=0)
+            shadow.step()                                     # (nothing to update; tells the scheduler its order of calls is fine)
+        else:
+            optim = torch.optim.AdamW(psfnet.parameters(), lr)
+            sche = torch.optim.lr_scheduler.CosineAnnealingLR(optim, T_max=int(iters) // 3, eta_min=0)
         scaler = torch.amp.GradScaler("cuda", enabled=on_gpu)
         amp = lambda: torch.autocast("cuda", dtype=torch.float16, enabled=on_gpu)  # noqa: E731
 
@@ -223,22 +233,38 @@ class PSFNet(Lensgroup):
             main.wait_event(first[2])
             static_inp.copy_(first[0]); static_psf.copy_(first[1])
 
-            def fwd_bwd():
+            def whole_step():
                 with amp():
                     loss = l2(psfnet(static_inp), static_psf)
                 scaler.scale(loss).backward()
+                scaler.step(optim)                            # fused AdamW: unscale, inf check and update on the device
+                scaler.update()
                 return loss
 
+            # warm-up off the capture stream (lazy state: the optimiser's moments, the scaler's scale) -- on a COPY of the
+            # run's state: whatever three extra steps on the first batch did is put back before the capture
+            saved = {k: v.detach().clone() for k, v in psfnet.state_dict().items()}
             side.wait_stream(main)
-            with torch.cuda.stream(side):                     # warm-up off the capture stream
+            with torch.cuda.stream(side):
                 for _ in range(3):
                     optim.zero_grad(set_to_none=True)
-                    fwd_bwd()
+                    whole_step()
+                with torch.no_grad():
+                    for k, v in psfnet.state_dict().items():
+                        v.copy_(saved[k])
+                    for st in optim.state.values():
+                        for t in st.values():
+                            if torch.is_tensor(t):
+                                t.zero_()
+                    scaler._scale.fill_(scaler._init_scale)
+                    scaler._growth_tracker.zero_()
             main.wait_stream(side)
             optim.zero_grad(set_to_none=True)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                static_loss = fwd_bwd()
+                static_loss = whole_step()
+            # the capture itself ran no kernel, but its Python side advanced the scaler's bookkeeping exactly as one
+            # step + update does; nothing to undo there
             queue = [first]
             evals_done = [0]
 
@@ -257,10 +283,9 @@ class PSFNet(Lensgroup):
                 main.wait_event(ready)
                 static_inp.copy_(inp); static_psf.copy_(psf)
                 inp.record_stream(main); psf.record_stream(main)
+                lr_dev.fill_(shadow.param_groups[0]["lr"])     # this step's rate, as the plain loop's optimiser reads it
                 graph.replay()                                 # grads are rewritten, not accumulated
                 refill()
-                scaler.step(optim)
-                scaler.update()
                 sche.step()
                 losses.append(static_loss.detach().clone())
                 if (i + 1) % evaluate_every == 0:
