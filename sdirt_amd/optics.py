@@ -92,11 +92,13 @@ class Lensgroup:
 
     #: psf_lr(defer=True) of the fitting shape (few points, many samples) through ONE library call (sdirt_psf_call, as the
     #: synchronous call) instead of the general path's separate launches.  Alone it is the faster producer -- 0.25 against
-    #: 0.30 ms per 64 x 20000 batch with two in flight, 0.18 against 0.27 ms of host work (tools/psf_defer_ab.py) -- but beside
-    #: the fitting loop's hipGraph it is the slower one (1.05 against 0.84 ms per iteration): its kernels follow each other
-    #: without the host's gaps, a generation of its workgroups fills every wave slot of the chip, and the graph's chain of
-    #: small dependent kernels waits it out.  Off by default (train_psfnet is the caller of defer=True); a pure data
-    #: generator may switch it on.
+    #: 0.30 ms per 64 x 20000 batch with two in flight, 0.18 against 0.27 ms of host work (tools/psf_defer_ab.py).  Beside
+    #: the fitting loop's hipGraph it is bimodal (tools/fit_ab.py, six fresh train_psfnet calls per setting): 0.73 ms per
+    #: iteration against the general path's 0.79 in most calls, 1.03-1.09 in the others -- and in three runs out of three
+    #: inside bench.py's process -- when the PSF batches and the step end up serialised (a batch's workgroups are one
+    #: generation that fills every wave slot of the chip; the general path's separate launches leave the gaps the step's
+    #: small kernels slip through).  Off by default: train_psfnet, the caller of defer=True, keeps the path whose worst case
+    #: is the better one; a pure data generator may switch it on.
     defer_one_call = False
 
     def __init__(self, filename=None, sensor_res=(1024, 1024), use_roc=False,

@@ -26,6 +26,8 @@ from .render_psf import local_psf_render_fast, psfnet_render
 DMIN = 200      # [mm]  psfnet.py:15
 DMAX = 20000    # [mm]  psfnet.py:16
 
+_SIDE_PRIORITY = 0      # (tools/fit_budget_ab.py varies it)
+
 _PSFNET_SENSOR_Z = {"rf35mm": 80.447, "rf50mm": 62.25}          # psfnet.py:42-48
 
 
@@ -205,7 +207,7 @@ class PSFNet(Lensgroup):
                     evaluate(i, inp, psf)
         else:
             main = torch.cuda.current_stream(self.device)
-            side = torch.cuda.Stream(self.device)
+            side = torch.cuda.Stream(self.device, priority=_SIDE_PRIORITY)
 
             produced = [0]
 
